@@ -1,0 +1,128 @@
+"""ctypes mirrors of include/noahmp_hip.h, built from abi_spec.py.
+
+Only plumbing lives here: structure definitions, the loader of the in-tree HIP
+shared library, and helpers that pack numpy arrays / torch tensors into a
+``noahmp_step_args`` block.  There is NO CPU fallback: if the HIP library is
+missing, :func:`load_library` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi_spec import STEP_FIELDS, TABLE_FIELDS, ERROR_CODES, NSNOW
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnoahmp_hip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+def _step_ctype(kind):
+    return {"i": C.c_int32, "f": C.c_float, "pf": C.c_void_p, "pi": C.c_void_p}[kind]
+
+
+class StepArgs(C.Structure):
+    """noahmp_step_args (include/noahmp_hip.h); mirrors the noahmplsm argument list, drv:11-44."""
+    _fields_ = [(n, _step_ctype(k)) for n, k, lev, io, ln in STEP_FIELDS]
+
+
+def _tbl_ctype(kind, shape):
+    t = C.c_int32 if kind == "i" else C.c_float
+    for d in shape:           # Fortran (a,b) -> C [b][a]: wrap fastest dim first
+        t = t * d
+    return t
+
+
+class Tables(C.Structure):
+    """noahmp_tables: image of the reference's module tables (lsm:43-103, 215-259, 417-424)."""
+    _fields_ = [(n, _tbl_ctype(k, s)) for n, k, s, src in TABLE_FIELDS]
+
+
+class Status(C.Structure):
+    _fields_ = [("code", C.c_int32), ("i", C.c_int32), ("j", C.c_int32),
+                ("n_land", C.c_int32), ("n_glacier", C.c_int32), ("n_skipped", C.c_int32),
+                ("kernel_ms", C.c_float)]
+
+
+FIELD_INFO = {n: (k, lev, io) for n, k, lev, io, ln in STEP_FIELDS}
+ARRAY_FIELDS = [n for n, k, lev, io, ln in STEP_FIELDS if k in ("pf", "pi")]
+
+
+def nlev(lev, nsoil, nk_atm=2):
+    return {None: 1, "atm": nk_atm, "soil": nsoil, "snow": NSNOW, "snso": NSNOW + nsoil}[lev]
+
+
+def tables_to_dict(t):
+    """Tables -> {name: numpy array in Fortran index order (e.g. saim[veg, month])}."""
+    out = {}
+    for n, k, s, src in TABLE_FIELDS:
+        v = getattr(t, n)
+        if s:
+            a = np.ctypeslib.as_array(v).copy()
+            out[n] = a.T.copy() if len(s) > 1 else a
+        else:
+            out[n] = v
+    return out
+
+
+def tables_from_dict(d):
+    t = Tables()
+    for n, k, s, src in TABLE_FIELDS:
+        if s:
+            dt = np.int32 if k == "i" else np.float32
+            a = np.asarray(d[n], dtype=dt)
+            assert a.shape == tuple(s), (n, a.shape, s)
+            src_arr = np.ascontiguousarray(a.T) if len(s) > 1 else np.ascontiguousarray(a)
+            C.memmove(C.addressof(getattr(t, n)), src_arr.ctypes.data, src_arr.nbytes)
+        else:
+            setattr(t, n, int(d[n]) if k == "i" else float(d[n]))
+    return t
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load the in-tree HIP engine.  Fails loudly when it is missing (no CPU fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "HIP engine %s not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    lib = C.CDLL(p)
+    lib.noahmp_hip_abi_version.restype = C.c_int
+    lib.noahmp_hip_sizeof_step_args.restype = C.c_size_t
+    lib.noahmp_hip_sizeof_tables.restype = C.c_size_t
+    lib.noahmp_hip_device_count.restype = C.c_int
+    lib.noahmp_hip_set_device.argtypes = [C.c_int]
+    lib.noahmp_hip_set_tables.argtypes = [C.POINTER(Tables)]
+    lib.noahmp_hip_step.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_void_p, C.POINTER(Status)]
+    lib.noahmp_hip_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.noahmp_hip_error_string.argtypes = [C.c_int]
+    lib.noahmp_hip_error_string.restype = C.c_char_p
+    lib.noahmp_hip_last_error.restype = C.c_char_p
+    lib.noahmp_hip_finalize.restype = None
+    if lib.noahmp_hip_sizeof_step_args() != C.sizeof(StepArgs):
+        raise RuntimeError("ABI drift: sizeof(noahmp_step_args) %d != ctypes %d"
+                           % (lib.noahmp_hip_sizeof_step_args(), C.sizeof(StepArgs)))
+    if lib.noahmp_hip_sizeof_tables() != C.sizeof(Tables):
+        raise RuntimeError("ABI drift: sizeof(noahmp_tables)")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "noahmp_hip_abi_version", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
+    "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
+    "noahmp_hip_step", "noahmp_hip_set_option", "noahmp_hip_error_string",
+    "noahmp_hip_last_error", "noahmp_hip_finalize",
+]
+
+
+def error_name(code):
+    return ERROR_CODES.get(code, ("unknown", ""))[0]

@@ -1,0 +1,150 @@
+"""Seeded synthetic workloads: the BASELINE.json configs as SURVEY.md section 8(d) specifies them.
+
+RNG: ``numpy.random.Generator(Philox(seed))`` (counter-based, reproducible across platforms).
+All fields are float32 / int32 in the column store's Fortran layout.
+"""
+import math
+
+import numpy as np
+
+from .state import ColumnStore, ModelConfig
+from .init import noahmp_init
+
+F = np.float32
+CONUS_VEG = np.array([2, 5, 7, 8, 10, 11, 14, 15, 19], dtype=np.int32)
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
+
+
+def diurnal_forcing(store, hour, t_offset=None, t_base=283.0, rain_hours=(10, 11, 12), rain_mm=2.0):
+    """SURVEY 8d config-1 forcing at local hour `hour` (0..23), broadcast over the tile."""
+    a = store.a
+    cfg = store.cfg
+    cosz = max(0.0, math.sin(math.pi * (hour - 6.0) / 12.0))
+    a["coszin"][...] = F(cosz)
+    a["swdown"][...] = F(800.0 * cosz)
+    a["glw"][...] = F(320.0 + 20.0 * cosz)
+    t = F(t_base + 8.0 * cosz)
+    if t_offset is None:
+        a["t3d"][...] = t
+    else:
+        a["t3d"][...] = (t + t_offset)[:, None, :].astype(F)
+    a["qv3d"][...] = F(0.006)
+    a["u_phy"][...] = F(3.0)
+    a["v_phy"][...] = F(1.0)
+    a["p8w3d"][...] = F(95000.0)
+    a["dz8w"][...] = F(2.0 * cfg.zlvl)                       # hdrv:344
+    a["rainbl"][...] = F(rain_mm if (hour % 24) in rain_hours else 0.0)   # mm per step (hdrv:343)
+    return cosz
+
+
+def _base_store(ni, nj, cfg):
+    s = ColumnStore(ni, nj, cfg)
+    a = s.a
+    a["xland"][...] = 1.0
+    a["xice"][...] = 0.0
+    a["xlatin"][...] = 30.0
+    a["vegmax"][...] = 90.0
+    # what the HRLDAS cold start leaves at -1e20 and the harness must zero
+    for nm in ("sfcrunoff", "udrunoff", "acsnom", "acsnow", "rechxy", "deeprechxy", "qsfc", "albedo",
+               "smoiseq", "smcwtdxy", "xlaixy", "taussxy"):
+        a[nm][...] = 0.0
+    a["zsnsoxy"][...] = 0.0
+    return s
+
+
+def first_step_fixups(store):
+    """hdrv:374-384: on the first step HRLDAS overwrites EAH/TAH/CH/CM."""
+    a = store.a
+    a["eahxy"][...] = (a["p8w3d"][:, 0, :] * a["qv3d"][:, 0, :]) / (F(0.622) + a["qv3d"][:, 0, :])
+    a["tahxy"][...] = a["t3d"][:, 0, :]
+    a["chxy"][...] = 0.1
+    a["cmxy"][...] = 0.1
+
+
+def config1(tables, cfg=None):
+    """Single column, veg 7 (grassland), soil 6 (loam), lat 30, namelist defaults."""
+    cfg = cfg or ModelConfig()
+    s = _base_store(1, 1, cfg)
+    a = s.a
+    a["ivgtyp"][...] = 7
+    a["isltyp"][...] = 6
+    a["vegfra"][...] = 60.0
+    a["tmn"][...] = 285.0
+    a["tsk"][...] = 283.0
+    a["tslb"][...] = np.array([283.0, 284.0, 285.0, 285.5], dtype=F)[None, :, None]
+    a["smois"][...] = np.array([0.25, 0.27, 0.30, 0.31], dtype=F)[None, :, None]
+    a["snow"][...] = 0.0
+    a["snowh"][...] = 0.0
+    diurnal_forcing(s, 0)
+    noahmp_init(s, tables)
+    return s
+
+
+def config2(tables, ni=1024, nj=1024, seed=2, cfg=None):
+    """1M synthetic land columns, 4 soil / 0 snow, dynamic_veg off (DVEG=1), opt_run=1."""
+    cfg = cfg or ModelConfig(idveg=1)
+    r = _rng(seed)
+    s = _base_store(ni, nj, cfg)
+    a = s.a
+    shp = (nj, ni)
+    a["ivgtyp"][...] = CONUS_VEG[r.integers(0, len(CONUS_VEG), size=shp)]
+    a["isltyp"][...] = r.integers(1, 13, size=shp).astype(np.int32)
+    a["vegfra"][...] = r.uniform(20.0, 90.0, size=shp).astype(F)
+    a["vegmax"][...] = np.maximum(a["vegfra"], F(90.0))
+    a["tmn"][...] = r.uniform(278.0, 292.0, size=shp).astype(F)
+    toff = np.clip(r.normal(0.0, 5.0, size=shp), -7.5, 15.0).astype(F)     # keep T > 275 K: no snow
+    s.t_offset = toff
+    a["tsk"][...] = F(283.0) + toff
+    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+        a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
+        a["smois"][:, k, :] = F(sm) + r.uniform(-0.05, 0.05, size=shp).astype(F)
+    a["snow"][...] = 0.0
+    a["snowh"][...] = 0.0
+    diurnal_forcing(s, 0, t_offset=toff)
+    noahmp_init(s, tables)
+    return s
+
+
+def config3(tables, ni=4608, nj=1536, seed=3, cfg=None, snow_frac=0.30, urban_frac=0.02,
+            glacier_frac=0.01):
+    """CONUS-1km-like: ~7.08 M columns, 30 % snow-covered (ISNOW 0..-3), 2 % urban, 1 % glacier."""
+    cfg = cfg or ModelConfig()
+    r = _rng(seed)
+    s = _base_store(ni, nj, cfg)
+    a = s.a
+    shp = (nj, ni)
+    a["ivgtyp"][...] = CONUS_VEG[r.integers(0, len(CONUS_VEG), size=shp)]
+    a["isltyp"][...] = r.integers(1, 13, size=shp).astype(np.int32)
+    u = r.random(size=shp)
+    a["ivgtyp"][u < urban_frac] = cfg.isurban
+    gl = (u >= urban_frac) & (u < urban_frac + glacier_frac)
+    a["ivgtyp"][gl] = cfg.isice
+    a["isltyp"][gl] = 16
+    a["vegfra"][...] = r.uniform(20.0, 90.0, size=shp).astype(F)
+    a["vegmax"][...] = np.maximum(a["vegfra"], F(90.0))
+    a["tmn"][...] = r.uniform(272.0, 290.0, size=shp).astype(F)
+    tair = np.clip(r.normal(272.0, 8.0, size=shp), 245.0, 300.0).astype(F)
+    has_snow = (r.random(size=shp) < snow_frac) | gl
+    tair = np.where(has_snow, np.minimum(tair, F(272.0)), np.maximum(tair, F(274.5))).astype(F)
+    s.t_offset = (tair - F(283.0)).astype(F)
+    a["tsk"][...] = tair
+    swe = r.uniform(5.0, 300.0, size=shp).astype(F)
+    rho = r.uniform(100.0, 350.0, size=shp).astype(F)
+    a["snow"][...] = np.where(has_snow, swe, F(0.0))
+    a["snowh"][...] = np.where(has_snow, swe / rho, F(0.0))
+    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+        a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
+        a["smois"][:, k, :] = F(sm) + r.uniform(-0.05, 0.05, size=shp).astype(F)
+    diurnal_forcing(s, 0, t_offset=s.t_offset)
+    noahmp_init(s, tables)
+    return s
+
+
+def mixed_small(tables, ni=64, nj=8, seed=7, cfg=None, **kw):
+    """Small config-3-style tile for parity tests (every branch family present)."""
+    return config3(tables, ni=ni, nj=nj, seed=seed, cfg=cfg,
+                   snow_frac=kw.get("snow_frac", 0.4), urban_frac=kw.get("urban_frac", 0.05),
+                   glacier_frac=kw.get("glacier_frac", 0.05))
