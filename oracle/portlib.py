@@ -1,0 +1,34 @@
+"""TEST INFRASTRUCTURE (oracle) -- ctypes loader for the C restatement (oracle/_build).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from noahmp_amd.abi import StepArgs, Tables, Status
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_PATH = os.path.join(_HERE, "_build", "libnoahmp_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "port"])
+
+
+class PortLib:
+    def __init__(self, autobuild=True):
+        if autobuild:
+            build()
+        self.lib = C.CDLL(PORT_PATH)
+        self.lib.nmp_oracle_set_tables.argtypes = [C.POINTER(Tables)]
+        self.lib.nmp_oracle_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
+
+    def set_tables(self, tables):
+        self.lib.nmp_oracle_set_tables(C.byref(tables))
+
+    def noahmplsm(self, store, itimestep, yr, julian):
+        a = store.step_args(itimestep, yr, julian)
+        st = Status()
+        self.lib.nmp_oracle_step(C.byref(a), C.byref(st))
+        return st
