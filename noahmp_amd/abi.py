@@ -93,6 +93,13 @@ def load_library(path=None):
         raise RuntimeError(
             "HIP engine %s not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process
+    # cannot both own the device.  Importing torch first makes the loader resolve this library's
+    # libamdhip64.so.7 dependency to the copy torch already mapped (same SONAME).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     lib.noahmp_hip_abi_version.restype = C.c_int
     lib.noahmp_hip_sizeof_step_args.restype = C.c_size_t

@@ -1,0 +1,100 @@
+// Noah-MP column engine for MI355X (gfx950) -- device-side common definitions.
+//
+// Execution model: one GPU thread advances one land column through one NOAHMP_SFLX step
+// (reference phys/module_sf_noahmplsm.F90:518, "lsm").  Per-column scalars live in VGPRs;
+// the 7-entry snow/soil layer arrays (index -2..4) live either in wavefront-private scratch
+// or in LDS laid out [layer][thread] so that the runtime layer index (ISNOW-dependent) never
+// causes a bank conflict: lane t always hits bank (t mod 32) whatever layer it addresses.
+// All arithmetic is float32 in the reference's operation order; no fast-math, no contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "noahmp_hip.h"
+
+namespace nmp {
+
+#define NMP_DEV __device__ __forceinline__
+#define L(i) ((i) + 2)   // layer -2..4 -> slot 0..6
+constexpr int NL = 7;
+constexpr int NSOIL = NOAHMP_NSOIL;
+constexpr int NSNOW = NOAHMP_NSNOW;
+
+// physical constants, lsm:12-28 and lsm:180-188
+constexpr float GRAV = 9.80616f, SB = 5.67E-08f, VKC = 0.40f, TFRZ = 273.16f, HSUB = 2.8440E06f,
+                HVAP = 2.5104E06f, HFUS = 0.3336E06f, CWAT = 4.188E06f, CICE = 2.094E06f,
+                CPAIR = 1004.64f, TKWAT = 0.6f, TKICE = 2.2f, RAIR = 287.04f, RW = 461.269f,
+                DENH2O = 1000.f, DENICE = 917.f;
+constexpr float TIMEAN = 10.5f, FSATMX = 0.38f, M_MELT = 2.50f, Z0SNO = 0.002f, SSI = 0.03f,
+                SWEMX = 1.00f;
+
+// Layer array view.  STRIDE==1: plain per-thread array (registers / scratch).
+// STRIDE==block size: LDS column-interleaved storage.
+template <int STRIDE>
+struct LArr {
+  float* p;
+  NMP_DEV float& operator[](int i) const { return p[i * STRIDE]; }
+};
+
+NMP_DEV float fmin2(float a, float b) { return (a < b) ? a : b; }   // Fortran MIN/MAX lowering
+NMP_DEV float fmax2(float a, float b) { return (a > b) ? a : b; }
+
+// REAL**INTEGER: square-and-multiply in the order flang/compiler-rt use (T**4 = (T*T)*(T*T)).
+NMP_DEV float powi2(float a) { return a * a; }
+NMP_DEV float powi3(float a) { return a * (a * a); }
+NMP_DEV float powi4(float a) { float b = a * a; return b * b; }
+NMP_DEV float powi5(float a) { float b = a * a; return a * (b * b); }
+
+struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)
+  int dveg, crs, btr, run, sfc, frz, inf, rad, alb, snf, tbot, stc;
+};
+
+struct Parm {  // REDPRM output (lsm:9282-9335): per-column, in registers instead of module globals
+  int nroot;
+  float rgl, rsmin, hs, rsmax, topt;
+  float bexp, smcmax, smcref, psisat, dksat, dwsat, smcwlt, quartz;
+  float slope, csoil, zbot, czil, kdt, frzx;
+};
+
+// launch-uniform context (kernel argument, lands in SGPRs)
+struct Ctx {
+  const noahmp_tables* __restrict__ T;
+  Opt O;
+  float dt;
+  float zsoil[NL];   // zsoil[L(1..4)], drv:392-395
+  int isurban;
+};
+
+// per-column scalar state of one NOAHMP_SFLX call (lsm:518-543); layer arrays are separate
+struct Col {
+  // in
+  float lat, julian, cosz, shdfac, shdmax, sfctmp, sfcprs, psfc, uu, vv, q2, soldn, lwdn, prcp,
+        tbot, co2air, o2air, foln, zlvl;
+  int yearlen, ice, ist, isc, vegtyp;
+  // inout
+  float albold, sneqvo, tah, eah, fwet, canliq, canice, tv, tg, qsfc, qsnow;
+  int isnow;
+  float snowh, sneqv, zwt, wa, wt, wslake, lfmass, rtmass, stmass, wood, stblcp, fastcp, lai, sai,
+        cm, ch, tauss, smcwtd, deeprech, rech;
+  // out
+  float fsa, fsr, fira, fsh, ssoil, fcev, fgev, fctr, ecan, etran, edir, trad, tgb, tgv, t2mv, t2mb,
+        q2v, q2b, runsrf, runsub, apar, psn, sav, sag, fsno, nee, gpp, npp, fveg, albedo, qsnbot,
+        ponding, ponding1, ponding2, rssun, rssha, bgap, wgap, chv, chb, emissi, shg, shc, shb, evg,
+        evb, ghv, ghb, irg, irc, irb, tr, evc, chleaf, chuc, chv2, chb2, fpice;
+  // SFLX-internal hand-offs ENERGY -> WATER/ERROR (lsm:547-760)
+  float thair, qair, eair, rhoair, qprecc, qprecl, solad0, solad1, solai0, solai1, swdown;
+  float elai, esai, htop, igs, btran, latheav, latheag, qmelt, fsrv, fsrg;
+  int frozen_canopy, frozen_ground;
+  int err;
+};
+
+template <class A>
+struct Lay {        // the layer arrays of a column
+  A stc, zsnso, dzsnso;              // -2..4
+  A smc, sh2o, sice, smceq, btrani;  // 1..4 (stored in slots L(1)..L(4))
+  A snice, snliq, ficeold;           // -2..0
+  A imelt;                           // -2..4, phase-change flag stored as float 0/1/2
+};
+
+NMP_DEV void raise(Col& s, int code) { if (!s.err) s.err = code; }
+
+}  // namespace nmp

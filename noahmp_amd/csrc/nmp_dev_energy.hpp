@@ -1,0 +1,1097 @@
+// Noah-MP column engine for MI355X -- energy phase device code.
+// Follows ENERGY and its callees in the reference (phys/module_sf_noahmplsm.F90, "lsm"),
+// statement order preserved so results track the float32 reference.
+// Layer loops are written as fully unrolled, predicated loops over the 7 fixed slots so that
+// temporaries with compile-time indices stay in VGPRs; only the state arrays in `Lay` are
+// addressed with run-time layer indices.
+#pragma once
+#include "nmp_dev_common.hpp"
+
+namespace nmp {
+
+// ESAT lsm:5272-5321
+NMP_DEV void esat(float t, float& esw, float& esi, float& desw, float& desi) {
+  esw = 100.f * (6.107799961f + t * (4.436518521E-01f + t * (1.428945805E-02f + t * (2.650648471E-04f +
+        t * (3.031240396E-06f + t * (2.034080948E-08f + t * 6.136820929E-11f))))));
+  esi = 100.f * (6.109177956f + t * (5.034698970E-01f + t * (1.886013408E-02f + t * (4.176223716E-04f +
+        t * (5.824720280E-06f + t * (4.838803174E-08f + t * 1.838826904E-10f))))));
+  desw = 100.f * (4.438099984E-01f + t * (2.857002636E-02f + t * (7.938054040E-04f + t * (1.215215065E-05f +
+         t * (1.036561403E-07f + t * (3.532421810e-10f + t * -7.090244804E-13f))))));
+  desi = 100.f * (5.030305237E-01f + t * (3.773255020E-02f + t * (1.267995369E-03f + t * (2.477563108E-05f +
+         t * (3.005693132E-07f + t * (2.158542548E-09f + t * 7.131097725E-12f))))));
+}
+NMP_DEV float tdc(float t) { return fminf(50.f, fmaxf(-50.f, (t - TFRZ))); }   // lsm:3247
+
+// TDFCND lsm:2014-2118
+NMP_DEV float tdfcnd(const Parm& P, float smc, float sh2o) {
+  float satratio = smc / P.smcmax;
+  float thks = powf(7.7f, P.quartz) * powf(2.0f, 1.f - P.quartz);
+  float xunfroz = sh2o / smc;
+  float xu = xunfroz * P.smcmax;
+  float thksat = powf(thks, 1.f - P.smcmax) * powf(TKICE, P.smcmax - xu) * powf(0.57f, xu);
+  float gammd = (1.f - P.smcmax) * 2700.f;
+  float thkdry = (0.135f * gammd + 64.7f) / (2700.f - 0.947f * gammd);
+  float ake;
+  if ((sh2o + 0.0005f) < smc) ake = satratio;
+  else ake = (satratio > 0.1f) ? (log10f(satratio) + 1.0f) : 0.0f;
+  return ake * (thksat - thkdry) + thkdry;
+}
+
+// THERMOPROP lsm:1845-1954 + CSNOW lsm:1957-2011
+template <class A>
+NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>& y, float* df,
+                        float* hcpct, float* fact) {
+  const int isnow = s.isnow;
+#pragma unroll
+  for (int iz = -2; iz <= 0; iz++) {
+    if (iz > isnow) {
+      float dz = y.dzsnso[L(iz)];
+      float snicev = fminf(1.f, y.snice[L(iz)] / (dz * DENICE));
+      float epore = 1.f - snicev;
+      float snliqv = fminf(epore, y.snliq[L(iz)] / (dz * DENH2O));
+      float bdsnoi = (y.snice[L(iz)] + y.snliq[L(iz)]) / dz;
+      hcpct[L(iz)] = CICE * snicev + CWAT * snliqv;
+      df[L(iz)] = 3.2217E-6f * (bdsnoi * bdsnoi);   // BDSNOI**2. (lsm:2004)
+    }
+  }
+  const bool urban = (s.vegtyp == c.isurban);
+#pragma unroll
+  for (int iz = 1; iz <= NSOIL; iz++) {
+    float smc = y.smc[L(iz)], sh2o = y.sh2o[L(iz)];
+    float sice = smc - sh2o;
+    hcpct[L(iz)] = sh2o * CWAT + (1.0f - P.smcmax) * P.csoil + (P.smcmax - smc) * CPAIR + sice * CICE;
+    df[L(iz)] = urban ? 3.24f : tdfcnd(P, smc, sh2o);
+  }
+#pragma unroll
+  for (int iz = -2; iz <= NSOIL; iz++)
+    if (iz > isnow) fact[L(iz)] = c.dt / (hcpct[L(iz)] * y.dzsnso[L(iz)]);
+  if (isnow == 0)
+    df[L(1)] = (df[L(1)] * y.dzsnso[L(1)] + 0.35f * s.snowh) / (s.snowh + y.dzsnso[L(1)]);
+  else
+    df[L(1)] = (df[L(1)] * y.dzsnso[L(1)] + df[L(0)] * y.dzsnso[L(0)]) / (y.dzsnso[L(0)] + y.dzsnso[L(1)]);
+}
+
+// SNOW_AGE lsm:2547-2596
+NMP_DEV void snow_age(float dt, float tg, float sneqvo, float sneqv, float& tauss, float& fage) {
+  if (sneqv <= 0.0f) tauss = 0.f;
+  else if (sneqv > 800.f) tauss = 0.f;
+  else {
+    float dela0 = 1.E-6f * dt;
+    float arg = 5.E3f * (1.f / TFRZ - 1.f / tg);
+    float age1 = expf(arg);
+    float age2 = expf(fminf(0.f, 10.f * arg));
+    float tage = age1 + age2 + 0.3f;
+    float dela = dela0 * tage;
+    float dels = fmaxf(0.0f, sneqv - sneqvo) / SWEMX;
+    float sge = (tauss + dela) * (1.0f - dels);
+    tauss = fmaxf(0.f, sge);
+  }
+  fage = tauss / (tauss + 1.f);
+}
+
+struct TwoStreamOut { float fab, fre, ftd, fti, frev, freg; };
+
+// TWOSTREAM lsm:2768-3016 for one band (rho,tau,albgrd,albgri,omegas of that band), ic 0=direct 1=diffuse
+NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float vai, float fwet, float t,
+                               float albgrd, float albgri, float rho, float tau, float omegas,
+                               float fveg, float& gdir, float& bgap, float& wgap) {
+  const noahmp_tables* T = c.T;
+  const float PAI = 3.14159265f;
+  float gap, kopen;
+  if (vai == 0.0f) {
+    gap = 1.0f; kopen = 1.0f;
+  } else {
+    gap = 0.f; kopen = 0.f;
+    if (c.O.rad == 1) {
+      float rc = T->rc[v];
+      float denfveg = -logf(fmaxf(1.0f - fveg, 0.01f)) / (PAI * powi2(rc));
+      float hd = T->hvt[v] - T->hvb[v];
+      float bb = 0.5f * hd;
+      float thetap = atanf(bb / rc * tanf(acosf(fmaxf(0.01f, cosz))));
+      bgap = expf(-denfveg * PAI * powi2(rc) / cosf(thetap));
+      float fa = vai / (1.33f * PAI * powf(rc, 3.0f) * (bb / rc) * denfveg);
+      float newvai = hd * fa;
+      wgap = (1.0f - bgap) * expf(-0.5f * newvai / cosz);
+      gap = fminf(1.0f - fveg, bgap + wgap);
+      kopen = 0.05f;
+    }
+    if (c.O.rad == 2) { gap = 0.0f; kopen = 0.0f; }
+    if (c.O.rad == 3) { gap = 1.0f - fveg; kopen = 1.0f - fveg; }
+  }
+  float coszi = fmaxf(0.001f, cosz);
+  float chil = fminf(fmaxf(T->xl[v], -0.4f), 0.6f);
+  if (fabsf(chil) <= 0.01f) chil = 0.01f;
+  float phi1 = 0.5f - 0.633f * chil - 0.330f * chil * chil;
+  float phi2 = 0.877f * (1.f - 2.f * phi1);
+  gdir = phi1 + phi2 * coszi;
+  float ext = gdir / coszi;
+  float avmu = (1.f - phi1 / phi2 * logf((phi1 + phi2) / phi1)) / phi2;
+  float omegal = rho + tau;
+  float tmp0 = gdir + phi2 * coszi;
+  float tmp1 = phi1 * coszi;
+  float asu = 0.5f * omegal * gdir / tmp0 * (1.f - tmp1 / tmp0 * logf((tmp1 + tmp0) / tmp1));
+  float betadl = (1.f + avmu * ext) / (omegal * avmu * ext) * asu;
+  float betail = 0.5f * (rho + tau + (rho - tau) * powi2((1.f + chil) / 2.f)) / omegal;
+  float tmp2;
+  if (t > TFRZ) {
+    tmp0 = omegal; tmp1 = betadl; tmp2 = betail;
+  } else {
+    tmp0 = (1.f - fwet) * omegal + fwet * omegas;
+    tmp1 = ((1.f - fwet) * omegal * betadl + fwet * omegas * T->betads) / tmp0;
+    tmp2 = ((1.f - fwet) * omegal * betail + fwet * omegas * T->betais) / tmp0;
+  }
+  float omega = tmp0, betad = tmp1, betai = tmp2;
+  float b = 1.f - omega + omega * betai;
+  float cc = omega * betai;
+  tmp0 = avmu * ext;
+  float d = tmp0 * omega * betad;
+  float f = tmp0 * omega * (1.f - betad);
+  tmp1 = b * b - cc * cc;
+  float h = sqrtf(tmp1) / avmu;
+  float sigma = tmp0 * tmp0 - tmp1;
+  if (fabsf(sigma) < 1.e-6f) sigma = copysignf(1.e-6f, sigma);
+  float p1 = b + avmu * h, p2 = b - avmu * h, p3 = b + tmp0, p4 = b - tmp0;
+  float s1 = expf(-h * vai), s2 = expf(-ext * vai);
+  float alb = (ic == 0) ? albgrd : albgri;
+  float u1 = b - cc / alb, u2 = b - cc * alb, u3 = f + cc * alb;
+  tmp2 = u1 - avmu * h;
+  float tmp3 = u1 + avmu * h;
+  float d1 = p1 * tmp2 / s1 - p2 * tmp3 * s1;
+  float tmp4 = u2 + avmu * h;
+  float tmp5 = u2 - avmu * h;
+  float d2 = tmp4 / s1 - tmp5 * s1;
+  float h1 = -d * p4 - cc * f;
+  float tmp6 = d - h1 * p3 / sigma;
+  float tmp7 = (d - cc - h1 / sigma * (u1 + tmp0)) * s2;
+  float h2 = (tmp6 * tmp2 / s1 - p2 * tmp7) / d1;
+  float h3 = -(tmp6 * tmp3 * s1 - p1 * tmp7) / d1;
+  float h4 = -f * p3 - cc * d;
+  float tmp8 = h4 / sigma;
+  float tmp9 = (u3 - tmp8 * (u2 - tmp0)) * s2;
+  float h5 = -(tmp8 * tmp4 / s1 + tmp9) / d2;
+  float h6 = (tmp8 * tmp5 * s1 + tmp9) / d2;
+  float h7 = (cc * tmp2) / (d1 * s1);
+  float h8 = (-cc * tmp3 * s1) / d1;
+  float h9 = tmp4 / (d2 * s1);
+  float h10 = (-tmp5 * s1) / d2;
+  TwoStreamOut o;
+  if (ic == 0) {
+    o.ftd = s2 * (1.0f - gap) + gap;
+    o.fti = (h4 * s2 / sigma + h5 * s1 + h6 / s1) * (1.0f - gap);
+    o.fre = (h1 / sigma + h2 + h3) * (1.0f - gap) + albgrd * gap;
+    o.frev = (h1 / sigma + h2 + h3) * (1.0f - gap);
+    o.freg = albgrd * gap;
+  } else {
+    o.ftd = 0.f;
+    o.fti = (h9 * s1 + h10 / s1) * (1.0f - kopen) + kopen;
+    o.fre = (h7 + h8) * (1.0f - kopen) + albgri * kopen;
+    o.frev = (h7 + h8) * (1.0f - kopen) + albgri * kopen;
+    o.freg = 0.f;
+  }
+  o.fab = 1.f - o.fre - (1.f - albgrd) * o.ftd - (1.f - albgri) * o.fti;
+  return o;
+}
+
+struct RadOut { float fsun, laisun, laisha, parsun, parsha; };
+
+// RADIATION lsm:2120-2240 (ALBEDO lsm:2243-2423 + SURRAD lsm:2426-2544)
+NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
+  const noahmp_tables* T = c.T;
+  const int v = s.vegtyp - 1;
+  const float MPE = 1.E-6f;
+  float albd[2] = {0, 0}, albi[2] = {0, 0}, albgrd[2] = {0, 0}, albgri[2] = {0, 0}, fabd[2] = {0, 0},
+        fabi[2] = {0, 0}, ftdd[2] = {0, 0}, ftid[2] = {0, 0}, ftii[2] = {0, 0};
+  float frevd[2] = {0, 0}, frevi[2] = {0, 0}, fregd[2] = {0, 0}, fregi[2] = {0, 0};
+  float fsun = 0.f;
+  s.bgap = 0.f; s.wgap = 0.f;
+  const float vai = s.elai + s.esai;
+  if (s.cosz > 0.f) {                                   // lsm:2356: whole block skipped at night
+    float wl = s.elai / fmaxf(vai, MPE);
+    float ws = s.esai / fmaxf(vai, MPE);
+    float rho[2], tau[2], albsnd[2], albsni[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++) {
+      rho[ib] = fmaxf(T->rhol[ib][v] * wl + T->rhos[ib][v] * ws, MPE);
+      tau[ib] = fmaxf(T->taul[ib][v] * wl + T->taus[ib][v] * ws, MPE);
+    }
+    float fage;
+    snow_age(c.dt, s.tg, s.sneqvo, s.sneqv, s.tauss, fage);
+    if (c.O.alb == 1) {                                 // SNOWALB_BATS lsm:2599-2649
+      float sl = 2.0f, sl1 = 1.f / sl, sl2 = 2.f * sl;
+      float cf1 = ((1.f + sl1) / (1.f + sl2 * s.cosz) - sl1);
+      float fzen = fmaxf(cf1, 0.f);
+      albsni[0] = 0.95f * (1.f - 0.2f * fage);
+      albsni[1] = 0.65f * (1.f - 0.5f * fage);
+      albsnd[0] = albsni[0] + 0.4f * fzen * (1.f - albsni[0]);
+      albsnd[1] = albsni[1] + 0.4f * fzen * (1.f - albsni[1]);
+    } else {                                            // SNOWALB_CLASS lsm:2652-2700
+      float alb = 0.55f + (s.albold - 0.55f) * expf(-0.01f * c.dt / 3600.f);
+      if (s.qsnow > 0.f) alb = alb + fminf(s.qsnow * c.dt, SWEMX) * (0.84f - alb) / (SWEMX);
+      albsni[0] = albsni[1] = albsnd[0] = albsnd[1] = alb;
+      s.albold = alb;
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ib++) {                    // GROUNDALB lsm:2703-2765 (IST=1 branch)
+      float inc = fmaxf(0.11f - 0.40f * smc1, 0.f);
+      float albsod = fminf(T->albsat[ib][s.isc - 1] + inc, T->albdry[ib][s.isc - 1]);
+      float albsoi = albsod;
+      if (s.isc == 9) { albsod += 0.10f; albsoi += 0.10f; }
+      albgrd[ib] = albsod * (1.f - s.fsno) + albsnd[ib] * s.fsno;
+      albgri[ib] = albsoi * (1.f - s.fsno) + albsni[ib] * s.fsno;
+    }
+    float gdir = 0.f;
+#pragma unroll 1
+    for (int ib = 0; ib < 2; ib++) {
+#pragma unroll 1
+      for (int ic = 0; ic < 2; ic++) {
+        TwoStreamOut o = twostream(c, ic, v, s.cosz, vai, s.fwet, s.tv, albgrd[ib], albgri[ib],
+                                   rho[ib], tau[ib], T->omegas[ib], s.fveg, gdir, s.bgap, s.wgap);
+        if (ic == 0) { fabd[ib] = o.fab; albd[ib] = o.fre; ftdd[ib] = o.ftd; ftid[ib] = o.fti;
+                       frevd[ib] = o.frev; fregd[ib] = o.freg; }
+        else { fabi[ib] = o.fab; albi[ib] = o.fre; ftii[ib] = o.fti; frevi[ib] = o.frev;
+               fregi[ib] = o.freg; }
+      }
+    }
+    float ext = gdir / s.cosz * sqrtf(1.f - rho[0] - tau[0]);
+    fsun = (1.f - expf(-ext * vai)) / fmaxf(ext * vai, MPE);
+    if (fsun < 0.01f) fsun = 0.f;
+  }
+  RadOut r;
+  r.fsun = fsun;
+  float fsha = 1.f - fsun;
+  r.laisun = s.elai * fsun;
+  r.laisha = s.elai * fsha;
+  const float solad[2] = {s.solad0, s.solad1}, solai[2] = {s.solai0, s.solai1};
+  float cad[2], cai[2];
+  s.sag = 0.f; s.sav = 0.f; s.fsa = 0.f;
+#pragma unroll
+  for (int ib = 0; ib < 2; ib++) {
+    cad[ib] = solad[ib] * fabd[ib];
+    cai[ib] = solai[ib] * fabi[ib];
+    s.sav = s.sav + cad[ib] + cai[ib];
+    s.fsa = s.fsa + cad[ib] + cai[ib];
+    float trd = solad[ib] * ftdd[ib];
+    float tri = solad[ib] * ftid[ib] + solai[ib] * ftii[ib];
+    float abs_ = trd * (1.f - albgrd[ib]) + tri * (1.f - albgri[ib]);
+    s.sag = s.sag + abs_;
+    s.fsa = s.fsa + abs_;
+  }
+  float laifra = s.elai / fmaxf(vai, MPE);
+  if (fsun > 0.f) {
+    r.parsun = (cad[0] + fsun * cai[0]) * laifra / fmaxf(r.laisun, MPE);
+    r.parsha = (fsha * cai[0]) * laifra / fmaxf(r.laisha, MPE);
+  } else {
+    r.parsun = 0.f;
+    r.parsha = (cad[0] + cai[0]) * laifra / fmaxf(r.laisha, MPE);
+  }
+  float rvis = albd[0] * solad[0] + albi[0] * solai[0];
+  float rnir = albd[1] * solad[1] + albi[1] * solai[1];
+  s.fsr = rvis + rnir;
+  s.fsrv = frevd[0] * solad[0] + frevi[0] * solai[0] + frevd[1] * solad[1] + frevi[1] * solai[1];
+  s.fsrg = fregd[0] * solad[0] + fregi[0] * solai[0] + fregd[1] * solad[1] + fregi[1] * solai[1];
+  return r;
+}
+
+struct MoState { float moz, fm, fh, fm2, fh2, fv; int mozsgn; };
+
+// SFCDIF1 lsm:4061-4220
+NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, float qair, float zlvl,
+                     float zpd, float z0m, float z0h, float ur, float mpe, MoState& m, float& cm,
+                     float& ch) {
+  float mozold = m.moz;
+  float moz2, fmnew, fhnew, fm2new, fh2new;
+  if (zlvl <= zpd) { raise(s, NOAHMP_ERR_STABILITY_STOP); }
+  float tmpcm = logf((zlvl - zpd) / z0m);
+  float tmpch = logf((zlvl - zpd) / z0h);
+  float tmpcm2 = logf((2.0f + z0m) / z0m);
+  float tmpch2 = logf((2.0f + z0h) / z0h);
+  if (iter == 1) {
+    m.fv = 0.0f; m.moz = 0.0f; moz2 = 0.0f;
+  } else {
+    float tvir = (1.f + 0.61f * qair) * sfctmp;
+    float tmp1 = VKC * (GRAV / tvir) * h / (rhoair * CPAIR);
+    if (fabsf(tmp1) <= mpe) tmp1 = mpe;
+    float mol = -1.f * powi3(m.fv) / tmp1;
+    m.moz = fminf((zlvl - zpd) / mol, 1.f);
+    moz2 = fminf((2.0f + z0h) / mol, 1.f);
+  }
+  if (mozold * m.moz < 0.f) m.mozsgn = m.mozsgn + 1;
+  if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
+  if (m.moz < 0.f) {
+    float tmp1 = powf(1.f - 16.f * m.moz, 0.25f);
+    float tmp2 = logf((1.f + tmp1 * tmp1) / 2.f);
+    float tmp3 = logf((1.f + tmp1) / 2.f);
+    fmnew = 2.f * tmp3 + tmp2 - 2.f * atanf(tmp1) + 1.5707963f;
+    fhnew = 2 * tmp2;
+    float tmp12 = powf(1.f - 16.f * moz2, 0.25f);
+    float tmp22 = logf((1.f + tmp12 * tmp12) / 2.f);
+    float tmp32 = logf((1.f + tmp12) / 2.f);
+    fm2new = 2.f * tmp32 + tmp22 - 2.f * atanf(tmp12) + 1.5707963f;
+    fh2new = 2 * tmp22;
+  } else {
+    fmnew = -5.f * m.moz; fhnew = fmnew;
+    fm2new = -5.f * moz2; fh2new = fm2new;
+  }
+  if (iter == 1) {
+    m.fm = fmnew; m.fh = fhnew; m.fm2 = fm2new; m.fh2 = fh2new;
+  } else {
+    m.fm = 0.5f * (m.fm + fmnew);
+    m.fh = 0.5f * (m.fh + fhnew);
+    m.fm2 = 0.5f * (m.fm2 + fm2new);
+    m.fh2 = 0.5f * (m.fh2 + fh2new);
+  }
+  m.fh = fminf(m.fh, 0.9f * tmpch);
+  m.fm = fminf(m.fm, 0.9f * tmpcm);
+  m.fh2 = fminf(m.fh2, 0.9f * tmpch2);
+  m.fm2 = fminf(m.fm2, 0.9f * tmpcm2);
+  float cmfm = tmpcm - m.fm, chfh = tmpch - m.fh;
+  if (fabsf(cmfm) <= mpe) cmfm = mpe;
+  if (fabsf(chfh) <= mpe) chfh = mpe;
+  cm = VKC * VKC / (cmfm * cmfm);
+  ch = VKC * VKC / (cmfm * chfh);
+  m.fv = ur * sqrtf(cm);
+}
+
+// SFCDIF2 lsm:4224-4422
+NMP_DEV float pspmu(float xx) {
+  return -2.f * logf((xx + 1.f) * 0.5f) - logf((xx * xx + 1.f) * 0.5f) + 2.f * atanf(xx) -
+         (3.14159265f / 2.f);
+}
+NMP_DEV float psphu(float xx) { return -2.f * logf((xx * xx + 1.f) * 0.5f); }
+
+NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, float czil, float zlm,
+                     float& akms, float& akhs, float& rlmo, float& wstar2, float& ustar) {
+  const float WWST2 = 1.2f * 1.2f, VKRM = 0.40f, EXCM = 0.001f, BTG = (1.0f / 270.0f) * GRAV,
+              ELFC = VKRM * BTG, WOLD = 0.15f, WNEW = 1.0f - WOLD, EPSU2 = 1.E-4f, EPSUST = 0.07f,
+              ZTMIN = -5.0f, ZTMAX = 1.0f, HPBL = 1000.0f, SQVISC = 258.2f;
+  float zilfc = -czil * VKRM * SQVISC;
+  float zu = z0;
+  float rdz = 1.f / zlm;
+  float cxch = EXCM * rdz;
+  float dthv = thlm - thz0;
+  float du2 = fmaxf(sfcspd * sfcspd, EPSU2);
+  float btgh = BTG * HPBL;
+  if (iter == 1) {
+    if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
+    else wstar2 = 0.0f;
+    ustar = fmaxf(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
+    rlmo = ELFC * akhs * dthv / powi3(ustar);
+  }
+  float zt = fmaxf(1.E-6f, expf(zilfc * sqrtf(ustar * z0)) * z0);
+  float zslu = zlm + zu;
+  float zslt = zlm + zt;
+  float rlogu = logf(zslu / zu);
+  float rlogt = logf(zslt / zt);
+  float zetalt = fmaxf(zslt * rlmo, ZTMIN);
+  rlmo = zetalt / zslt;
+  float zetalu = zslu * rlmo;
+  float zetau = zu * rlmo;
+  float zetat = zt * rlmo;
+  float psmz, simm, pshz, simh;
+  if (rlmo < 0.f) {
+    float xlu = sqrtf(sqrtf(1.f - 16.f * zetalu)), xlt = sqrtf(sqrtf(1.f - 16.f * zetalt)),
+          xu = sqrtf(sqrtf(1.f - 16.f * zetau)), xt = sqrtf(sqrtf(1.f - 16.f * zetat));
+    psmz = pspmu(xu);
+    simm = pspmu(xlu) - psmz + rlogu;
+    pshz = psphu(xt);
+    simh = psphu(xlt) - pshz + rlogt;
+  } else {
+    zetalu = fminf(zetalu, ZTMAX);
+    zetalt = fminf(zetalt, ZTMAX);
+    psmz = 5.f * zetau;
+    simm = 5.f * zetalu - psmz + rlogu;
+    pshz = 5.f * zetat;
+    simh = 5.f * zetalt - pshz + rlogt;
+  }
+  ustar = fmaxf(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
+  float ustark = ustar * VKRM;
+  akms = fmaxf(ustark / simm, cxch);
+  akhs = fmaxf(ustark / simh, cxch);
+  if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
+  else wstar2 = 0.0f;
+  float rlmn = ELFC * akhs * dthv / powi3(ustar);
+  rlmo = rlmo * WOLD + rlmn * WNEW;
+}
+
+// STOMATA + CI2CI lsm:5323-5464 (bisection on Ci, <= 20 iterations)
+NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, float tv, float ei,
+                     float ea, float sfctmp, float sfcprs, float o2, float co2, float igs,
+                     float btran, float rb, float& rs, float& psn) {
+  const noahmp_tables* T = c.T;
+  const float bpv = T->bp[v];
+  float cf = sfcprs / (8.314f * sfctmp) * 1.0e06f;
+  rs = 1.0f / bpv * cf;
+  psn = 0.0f;
+  if (apar <= 0.0f) return;
+  const float c3 = T->c3psn[v], mpv = T->mp[v];
+  float fnf = fminf(foln / fmaxf(mpe, T->folnmx[v]), 1.0f);
+  float tc = tv - TFRZ;
+  float ppf = 4.6f * apar;
+  float j = ppf * T->qe25[v];
+  float kc = T->kc25[v] * powf(T->akc[v], (tc - 25.0f) / 10.0f);
+  float ko = T->ko25[v] * powf(T->ako[v], (tc - 25.0f) / 10.0f);
+  float awc = kc * (1.0f + o2 / ko);
+  float cp = 0.5f * kc / ko * o2 * 0.21f;
+  float vcmx = T->vcmx25[v] / (1.0f + expf((-2.2E05f + 710.0f * (tc + TFRZ)) / (8.314f * (tc + TFRZ)))) *
+               fnf * btran * powf(T->avcmx[v], (tc - 25.0f) / 10.0f);
+  float rlb = rb / cf;
+  float cihi = 1.5f * co2, cilow = 0.0f;
+#pragma unroll 1
+  for (int iter = 1; iter <= 20; iter++) {
+    float ci = 0.5f * (cihi + cilow);
+    float wj = fmaxf(ci - cp, 0.0f) * j / (ci + 2.0f * cp) * c3 + j * (1.f - c3);
+    float wc = fmaxf(ci - cp, 0.0f) * vcmx / (ci + awc) * c3 + vcmx * (1.f - c3);
+    float we = 0.5f * vcmx * c3 + 4000.0f * vcmx * ci / sfcprs * (1.f - c3);
+    psn = fminf(fminf(wj, wc), we) * igs;
+    float cs = fmaxf(co2 - 1.37f * rlb * sfcprs * psn, mpe);
+    float a = mpv * psn * sfcprs * ea / (cs * ei) + bpv;
+    float b = (mpv * psn * sfcprs / cs + bpv) * rlb - 1.f;
+    float cq = -rlb;
+    float q;
+    if (b >= 0.0f) q = -0.5f * (b + sqrtf(b * b - 4.0f * a * cq));
+    else q = -0.5f * (b - sqrtf(b * b - 4.0f * a * cq));
+    float r1 = q / a, r2 = cq / q;
+    rs = fmaxf(r1, r2);
+    float fci = fmaxf(cs - psn * sfcprs * 1.65f * rs, 0.0f);
+    if (((cihi - cilow) <= 5e-2f) || fabsf(fci - ci) <= mpe) break;
+    else if (fci > ci) cilow = ci;
+    else cihi = ci;
+  }
+  rs = rs * cf;
+}
+
+// CANRES lsm:5598-5677 (+ CALHUM lsm:5679-5705)
+NMP_DEV void canres(const Parm& P, float par, float sfctmp, float rcsoil, float eah, float sfcprs,
+                    float& rc, float& psn) {
+  float q2 = 0.622f * eah / (sfcprs - 0.378f * eah);
+  q2 = q2 / (1.0f + q2);
+  float es = 0.611f * expf(2.501E6f / 461.0f * (1.f / 273.15f - 1.f / sfctmp));
+  float sfcprsx = sfcprs * 1.E-3f;
+  float q2sat = 0.622f * es / (sfcprsx - es);
+  q2sat = q2sat * 1.E3f;
+  q2sat = q2sat / 1.E3f;
+  float ff = 2.0f * par / P.rgl;
+  float rcs = (ff + P.rsmin / P.rsmax) / (1.0f + ff);
+  rcs = fmaxf(rcs, 0.0001f);
+  float dt_ = P.topt - sfctmp;
+  float rct = 1.0f - 0.0016f * (dt_ * dt_);
+  rct = fmaxf(rct, 0.0001f);
+  float rcq = 1.0f / (1.0f + P.hs * fmaxf(0.f, q2sat - q2));
+  rcq = fmaxf(rcq, 0.01f);
+  rc = P.rsmin / (rcs * rct * rcq * rcsoil);
+  psn = -999.99f;
+}
+
+// VEGE_FLUX lsm:3018-3589.  `top` quantities are those of layer ISNOW+1.
+struct VegIn {
+  float ur, vai, gammav, gammag, laisun, laisha, cwp, zlvl, zpd, z0m, z0mg, emv, emg, rsurf, rhsur,
+        parsun, parsha, df_top, dz_top, stc_top;
+};
+
+NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float& cmv, float& psnsun,
+                       float& psnsha) {
+  const noahmp_tables* T = c.T;
+  const int v = s.vegtyp - 1;
+  const float MPE = 1E-6f;
+  const float fveg = s.fveg, rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur;
+  int liter = 0;
+  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0};
+  float dtv = 0.f, hg = 0.f, h = 0.f, wstar = 0.f;
+  float t, esatw, esati, dsatw, dsati, estg, destg, estv = 0.f, destv = 0.f;
+  float rahc = 0.f, rawc, rahg = 0.f, rawg = 0.f, rb = 0.f, fhg = 0.f;
+  float cah = 0.f, cvh = 0.f, cgh, cond, ata, bta, csh, caw, cew, ctw, cgw, aea, bea, cev, ctr;
+  float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah; float& ch = s.chv;
+  float& cm = cmv;
+  const float z0h = q.z0m, z0hg = q.z0mg;
+  float vaie = fminf(6.f, q.vai / fveg);
+  float laisune = fminf(6.f, q.laisun / fveg);
+  float laishae = fminf(6.f, q.laisha / fveg);
+  t = tdc(tg);
+  esat(t, esatw, esati, dsatw, dsati);
+  estg = (t > 0.f) ? esatw : esati;
+  s.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
+  const float hcan = s.htop;
+  float uc = ur * logf(hcan / q.z0m) / logf(q.zlvl / q.z0m);
+  if ((hcan - q.zpd) <= 0.f) raise(s, NOAHMP_ERR_HCAN_LE_ZPD);
+  float air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(tg);
+  float cir = (2.f - q.emv * (1.f - q.emg)) * q.emv * SB;
+  const float dleaf = T->dleaf[v];
+#pragma unroll 1
+  for (int iter = 1; iter <= 20; iter++) {              // loop1, NITERC = 20 (lsm:3234)
+    if (c.O.sfc == 1) {
+      sfcdif1(s, iter, sfctmp, rhoair, h, s.qair, q.zlvl, q.zpd, q.z0m, z0h, ur, MPE, mo, cm, ch);
+    } else {
+      sfcdif2(iter, q.z0m, tah, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
+      ch = ch / ur;
+      cm = cm / ur;
+    }
+    rahc = fmaxf(1.f, 1.f / (ch * ur));
+    rawc = rahc;
+    {                                                   // RAGRB lsm:3960-4057
+      float mozg = 0.f, fhgnew;
+      if (iter > 1) {
+        float tmp1 = VKC * (GRAV / tah) * hg / (rhoair * CPAIR);
+        if (fabsf(tmp1) <= MPE) tmp1 = MPE;
+        float molg = -1.f * powi3(mo.fv) / tmp1;
+        mozg = fminf((q.zpd - q.z0mg) / molg, 1.f);
+      }
+      if (mozg < 0.f) fhgnew = powf(1.f - 15.f * mozg, -0.25f);
+      else fhgnew = 1.f + 4.7f * mozg;
+      if (iter == 1) fhg = fhgnew;
+      else fhg = 0.5f * (fhg + fhgnew);
+      float cwpc = powf(q.cwp * vaie * hcan * fhg, 0.5f);
+      float tmp1 = expf(-cwpc * z0hg / hcan);
+      float tmp2 = expf(-cwpc * (z0h + q.zpd) / hcan);
+      float tmprah2 = hcan * expf(cwpc) / cwpc * (tmp1 - tmp2);
+      float kh = fmaxf(VKC * mo.fv * (hcan - q.zpd), MPE);
+      rahg = tmprah2 / kh;
+      rawg = rahg;
+      float tmprb = cwpc * 50.f / (1.f - expf(-cwpc / 2.f));
+      rb = tmprb * sqrtf(dleaf / uc);
+    }
+    t = tdc(tv);
+    esat(t, esatw, esati, dsatw, dsati);
+    if (t > 0.f) { estv = esatw; destv = dsatw; } else { estv = esati; destv = dsati; }
+    if (iter == 1) {
+#pragma unroll 1
+      for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
+        float par = leaf ? q.parsha : q.parsun, rs_, psn_;
+        if (c.O.crs == 1)
+          stomata(c, v, MPE, par, s.foln, tv, estv, eah, sfctmp, s.sfcprs, s.o2air, s.co2air, s.igs,
+                  s.btran, rb, rs_, psn_);
+        else
+          canres(P, par, tv, s.btran, eah, s.sfcprs, rs_, psn_);
+        if (leaf) { s.rssha = rs_; psnsha = psn_; } else { s.rssun = rs_; psnsun = psn_; }
+      }
+    }
+    cah = 1.f / rahc;
+    cvh = 2.f * vaie / rb;
+    cgh = 1.f / rahg;
+    cond = cah + cvh + cgh;
+    ata = (sfctmp * cah + tg * cgh) / cond;
+    bta = cvh / cond;
+    csh = (1.f - bta) * rhoair * CPAIR * cvh;
+    caw = 1.f / rawc;
+    cew = s.fwet * vaie / rb;
+    ctw = (1.f - s.fwet) * (laisune / (rb + s.rssun) + laishae / (rb + s.rssha));
+    cgw = 1.f / (rawg + q.rsurf);
+    cond = caw + cew + ctw + cgw;
+    aea = (s.eair * caw + estg * cgw) / cond;
+    bea = (cew + ctw) / cond;
+    cev = (1.f - bea) * cew * rhoair * CPAIR / q.gammav;
+    ctr = (1.f - bea) * ctw * rhoair * CPAIR / q.gammav;
+    tah = ata + bta * tv;
+    eah = aea + bea * estv;
+    s.irc = fveg * (air + cir * powi4(tv));
+    s.shc = fveg * rhoair * CPAIR * cvh * (tv - tah);
+    s.evc = fveg * rhoair * CPAIR * cew * (estv - eah) / q.gammav;
+    s.tr = fveg * rhoair * CPAIR * ctw * (estv - eah) / q.gammav;
+    if (tv > TFRZ) s.evc = fminf(s.canliq * s.latheav / c.dt, s.evc);
+    else s.evc = fminf(s.canice * s.latheav / c.dt, s.evc);
+    float b = s.sav - s.irc - s.shc - s.evc - s.tr;
+    float a = fveg * (4.f * cir * powi3(tv) + csh + (cev + ctr) * destv);
+    dtv = b / a;
+    s.irc = s.irc + fveg * 4.f * cir * powi3(tv) * dtv;
+    s.shc = s.shc + fveg * csh * dtv;
+    s.evc = s.evc + fveg * cev * destv * dtv;
+    s.tr = s.tr + fveg * ctr * destv * dtv;
+    tv = tv + dtv;
+    h = rhoair * CPAIR * (tah - sfctmp) / rahc;
+    hg = rhoair * CPAIR * (tg - tah) / rahg;
+    s.qsfc = (0.622f * eah) / (s.sfcprs - 0.378f * eah);
+    if (liter == 1) break;
+    if (iter >= 5 && fabsf(dtv) <= 0.01f && liter == 0) liter = 1;
+  }
+  // under-canopy ground, lsm:3495-3542
+  air = -q.emg * (1.f - q.emv) * s.lwdn - q.emg * q.emv * SB * powi4(tv);
+  cir = q.emg * SB;
+  csh = rhoair * CPAIR / rahg;
+  cev = rhoair * CPAIR / (q.gammag * (rawg + q.rsurf));
+  cgh = 2.f * q.df_top / q.dz_top;
+#pragma unroll 1
+  for (int iter = 1; iter <= 5; iter++) {               // loop2, NITERG = 5
+    t = tdc(tg);
+    esat(t, esatw, esati, dsatw, dsati);
+    if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
+    s.irg = cir * powi4(tg) + air;
+    s.shg = csh * (tg - tah);
+    s.evg = cev * (estg * q.rhsur - eah);
+    s.ghv = cgh * (tg - q.stc_top);
+    float b = s.sag - s.irg - s.shg - s.evg - s.ghv;
+    float a = 4.f * cir * powi3(tg) + csh + cev * destg + cgh;
+    float dtg = b / a;
+    s.irg = s.irg + 4.f * cir * powi3(tg) * dtg;
+    s.shg = s.shg + csh * dtg;
+    s.evg = s.evg + cev * destg * dtg;
+    s.ghv = s.ghv + cgh * dtg;
+    tg = tg + dtg;
+  }
+  if (c.O.stc == 1) {
+    if (s.snowh > 0.05f && tg > TFRZ) {
+      tg = TFRZ;
+      s.irg = cir * powi4(tg) - q.emg * (1.f - q.emv) * s.lwdn - q.emg * q.emv * SB * powi4(tv);
+      s.shg = csh * (tg - tah);
+      s.evg = cev * (estg * q.rhsur - eah);
+      s.ghv = s.sag - (s.irg + s.shg + s.evg);
+    }
+  }
+  // 2-m diagnostics lsm:3557-3571 (OPT_SFC 1/2; FH2 is 0 under OPT_SFC=2)
+  float cah2 = mo.fv * VKC / (logf((2.f + z0h) / z0h) - mo.fh2);
+  s.chv2 = cah2;
+  if (cah2 < 1.E-5f) {
+    s.t2mv = tah;
+    s.q2v = s.qsfc;
+  } else {
+    s.t2mv = tah - (s.shg + s.shc / fveg) / (rhoair * CPAIR) * 1.f / cah2;
+    s.q2v = s.qsfc - ((s.evc + s.tr) / fveg + s.evg) / (s.latheav * rhoair) * 1.f / cah2;
+  }
+  ch = cah;
+  s.chleaf = cvh;
+  s.chuc = 1.f / rahg;
+}
+
+// BARE_FLUX lsm:3591-3958
+NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float zpdg, float& cmb) {
+  const float MPE = 1E-6f;
+  const float rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur, z0m = q.z0mg;
+  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0};
+  float h = 0.f, wstar = 0.f;
+  float t, esatw, esati, dsatw, dsati, estg = 0.f, destg, csh = 0.f, cev = 0.f, ehb = 0.f;
+  float& tgb = s.tgb; float& ch = s.chb; float& cm = cmb;
+  const float z0h = z0m;
+  const float cir = q.emg * SB;
+  const float cgh = 2.f * q.df_top / q.dz_top;
+  const float gamma = q.gammag, lathea = s.latheag;
+#pragma unroll 1
+  for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
+    if (c.O.sfc == 1) {
+      sfcdif1(s, iter, sfctmp, rhoair, h, s.qair, q.zlvl, zpdg, z0m, z0h, ur, MPE, mo, cm, ch);
+    } else {
+      sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
+      ch = ch / ur;
+      cm = cm / ur;
+      if (s.snowh > 0.f) { cm = fminf(0.01f, cm); ch = fminf(0.01f, ch); }
+    }
+    float rahb = fmaxf(1.f, 1.f / (ch * ur));
+    float rawb = rahb;
+    ehb = 1.f / rahb;
+    t = tdc(tgb);
+    esat(t, esatw, esati, dsatw, dsati);
+    if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
+    csh = rhoair * CPAIR / rahb;
+    cev = rhoair * CPAIR / gamma / (q.rsurf + rawb);
+    s.irb = cir * powi4(tgb) - q.emg * s.lwdn;
+    s.shb = csh * (tgb - sfctmp);
+    s.evb = cev * (estg * q.rhsur - s.eair);
+    s.ghb = cgh * (tgb - q.stc_top);
+    float b = s.sag - s.irb - s.shb - s.evb - s.ghb;
+    float a = 4.f * cir * powi3(tgb) + csh + cev * destg + cgh;
+    float dtg = b / a;
+    s.irb = s.irb + 4.f * cir * powi3(tgb) * dtg;
+    s.shb = s.shb + csh * dtg;
+    s.evb = s.evb + cev * destg * dtg;
+    s.ghb = s.ghb + cgh * dtg;
+    tgb = tgb + dtg;
+    h = csh * (tgb - sfctmp);
+    t = tdc(tgb);
+    esat(t, esatw, esati, dsatw, dsati);
+    estg = (t > 0.f) ? esatw : esati;
+    s.qsfc = 0.622f * (estg * q.rhsur) / (s.psfc - 0.378f * (estg * q.rhsur));
+  }
+  if (c.O.stc == 1) {
+    if (s.snowh > 0.05f && tgb > TFRZ) {
+      tgb = TFRZ;
+      s.irb = cir * powi4(tgb) - q.emg * s.lwdn;
+      s.shb = csh * (tgb - sfctmp);
+      s.evb = cev * (estg * q.rhsur - s.eair);
+      s.ghb = s.sag - (s.irb + s.shb + s.evb);
+    }
+  }
+  float ehb2 = mo.fv * VKC / (logf((2.f + z0h) / z0h) - mo.fh2);
+  s.chb2 = ehb2;
+  if (ehb2 < 1.E-5f) {
+    s.t2mb = tgb;
+    s.q2b = s.qsfc;
+  } else {
+    s.t2mb = tgb - s.shb / (rhoair * CPAIR) * 1.f / ehb2;
+    s.q2b = s.qsfc - s.evb / (lathea * rhoair) * (1.f / ehb2 + q.rsurf);
+  }
+  if (s.vegtyp == c.isurban) s.q2b = s.qsfc;
+  ch = ehb;
+}
+
+// TSNOSOI lsm:5707-5822 = HRT (5825-5922) + HSTEP (5925-5977) + ROSR12 (5979-6036).
+// Rows ISNOW+1..4 of the 7 fixed slots; inactive slots are predicated off.
+template <class A>
+NMP_DEV void tsnosoi(const Ctx& c, const Parm& P, const Col& s, const Lay<A>& y, const float* df,
+                     const float* hcpct) {
+  const int isnow = s.isnow, ntop = isnow + 1;
+  const float dt = c.dt;
+  const float zbotsno = P.zbot - s.snowh;
+  float ai[NL], bi[NL], ci[NL], rhsts[NL], ddz[NL], dtsdz[NL], zs[NL], tt[NL];
+#pragma unroll
+  for (int k = -2; k <= NSOIL; k++) { zs[L(k)] = y.zsnso[L(k)]; tt[L(k)] = y.stc[L(k)]; }
+#pragma unroll
+  for (int k = -2; k <= NSOIL; k++) {
+    const int km = (k > -2) ? k - 1 : -2;          // clamped neighbours keep every unrolled index
+    const int kp = (k < NSOIL) ? k + 1 : NSOIL;    // in range; clamped values are never consumed
+    ai[L(k)] = 0.f; bi[L(k)] = 1.f; ci[L(k)] = 0.f; rhsts[L(k)] = 0.f; ddz[L(k)] = 0.f; dtsdz[L(k)] = 0.f;
+    if (k >= ntop) {
+      float denom, eflux;
+      if (k == ntop) {
+        denom = -zs[L(k)] * hcpct[L(k)];
+        float temp1 = -zs[L(kp)];
+        ddz[L(k)] = 2.0f / temp1;
+        dtsdz[L(k)] = 2.0f * (tt[L(k)] - tt[L(kp)]) / temp1;
+        eflux = df[L(k)] * dtsdz[L(k)] - s.ssoil - 0.f;
+      } else if (k < NSOIL) {
+        denom = (zs[L(km)] - zs[L(k)]) * hcpct[L(k)];
+        float temp1 = zs[L(km)] - zs[L(kp)];
+        ddz[L(k)] = 2.0f / temp1;
+        dtsdz[L(k)] = 2.0f * (tt[L(k)] - tt[L(kp)]) / temp1;
+        eflux = (df[L(k)] * dtsdz[L(k)] - df[L(km)] * dtsdz[L(km)]) - 0.f;
+      } else {
+        denom = (zs[L(km)] - zs[L(k)]) * hcpct[L(k)];
+        float botflx = 0.f;
+        if (c.O.tbot == 2) {
+          dtsdz[L(k)] = (tt[L(k)] - s.tbot) / (0.5f * (zs[L(km)] + zs[L(k)]) - zbotsno);
+          botflx = -df[L(k)] * dtsdz[L(k)];
+        }
+        eflux = (-botflx - df[L(km)] * dtsdz[L(km)]) - 0.f;
+      }
+      if (k == ntop) {
+        ai[L(k)] = 0.0f;
+        ci[L(k)] = -df[L(k)] * ddz[L(k)] / denom;
+        if (c.O.stc == 1) bi[L(k)] = -ci[L(k)];
+        else bi[L(k)] = -ci[L(k)] + df[L(k)] / (0.5f * zs[L(k)] * zs[L(k)] * hcpct[L(k)]);
+      } else if (k < NSOIL) {
+        ai[L(k)] = -df[L(km)] * ddz[L(km)] / denom;
+        ci[L(k)] = -df[L(k)] * ddz[L(k)] / denom;
+        bi[L(k)] = -(ai[L(k)] + ci[L(k)]);
+      } else {
+        ai[L(k)] = -df[L(km)] * ddz[L(km)] / denom;
+        ci[L(k)] = 0.0f;
+        bi[L(k)] = -(ai[L(k)] + ci[L(k)]);
+      }
+      rhsts[L(k)] = eflux / (-denom);
+      // HSTEP scaling
+      rhsts[L(k)] = rhsts[L(k)] * dt;
+      ai[L(k)] = ai[L(k)] * dt;
+      bi[L(k)] = 1.f + bi[L(k)] * dt;
+      ci[L(k)] = ci[L(k)] * dt;
+    }
+  }
+  // ROSR12: forward sweep then back substitution (P -> p[], DELTA -> dl[])
+  float p[NL], dl[NL];
+  ci[L(NSOIL)] = 0.0f;
+#pragma unroll
+  for (int k = -2; k <= NSOIL; k++) {
+    p[L(k)] = 0.f; dl[L(k)] = 0.f;
+    if (k == ntop) {
+      p[L(k)] = -ci[L(k)] / bi[L(k)];
+      dl[L(k)] = rhsts[L(k)] / bi[L(k)];
+    } else if (k > ntop) {
+      const int km = (k > -2) ? k - 1 : -2;
+      float inv = 1.0f / (bi[L(k)] + ai[L(k)] * p[L(km)]);
+      p[L(k)] = -ci[L(k)] * inv;
+      dl[L(k)] = (rhsts[L(k)] - ai[L(k)] * dl[L(km)]) * inv;
+    }
+  }
+  p[L(NSOIL)] = dl[L(NSOIL)];
+#pragma unroll
+  for (int kk = NSOIL - 1; kk >= -2; kk--)
+    if (kk >= ntop) p[L(kk)] = p[L(kk)] * p[L(kk + 1)] + dl[L(kk)];
+#pragma unroll
+  for (int k = -2; k <= NSOIL; k++)
+    if (k >= ntop) y.stc[L(k)] = tt[L(k)] + p[L(k)];
+}
+
+// FRH2O lsm:6247-6377
+NMP_DEV float frh2o(const Parm& P, float tkelv, float smc, float sh2o) {
+  const float CK = 8.0f, BLIM = 5.5f, ERROR = 0.005f;
+  float bx = P.bexp, free_;
+  if (P.bexp > BLIM) bx = BLIM;
+  int nlog = 0, kcount = 0;
+  if (tkelv > (TFRZ - 1.E-3f)) return smc;
+  float swl = smc - sh2o;
+  if (swl > (smc - 0.02f)) swl = smc - 0.02f;
+  if (swl < 0.f) swl = 0.f;
+#pragma unroll 1
+  while ((nlog < 10) && (kcount == 0)) {
+    nlog = nlog + 1;
+    float t1 = 1.f + CK * swl;
+    float df = logf((P.psisat * GRAV / HFUS) * (t1 * t1) * powf(P.smcmax / (smc - swl), bx)) -
+               logf(-(tkelv - TFRZ) / tkelv);
+    float denom = 2.f * CK / (1.f + CK * swl) + bx / (smc - swl);
+    float swlk = swl - df / denom;
+    if (swlk > (smc - 0.02f)) swlk = smc - 0.02f;
+    if (swlk < 0.f) swlk = 0.f;
+    float dswl = fabsf(swlk - swl);
+    swl = swlk;
+    if (dswl <= ERROR) kcount = kcount + 1;
+  }
+  free_ = smc - swl;
+  if (kcount == 0) {
+    float fk = powf((HFUS / (GRAV * (-P.psisat))) * ((tkelv - TFRZ) / tkelv), -1 / bx) * P.smcmax;
+    if (fk < 0.02f) fk = 0.02f;
+    free_ = fminf(fk, smc);
+  }
+  return free_;
+}
+
+// PHASECHANGE lsm:6039-6245
+template <class A>
+NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const float* fact) {
+  const int isnow = s.isnow;
+  const float dt = c.dt;
+  float qmelt = 0.f, ponding = 0.f;
+  float hm1 = 0.f, xm1 = 0.f;
+  // layer 1 first pass values are needed by the no-layer snow melt (lsm:6177); compute all layers
+  float hm[NL], xm[NL], wmass0[NL], wice0[NL], mice[NL], mliq[NL], supercool[NL], stc[NL];
+  int imelt[NL];
+#pragma unroll
+  for (int j = -2; j <= NSOIL; j++) {
+    supercool[L(j)] = 0.f; imelt[L(j)] = 0; hm[L(j)] = 0.f; xm[L(j)] = 0.f; mice[L(j)] = 0.f;
+    mliq[L(j)] = 0.f; wice0[L(j)] = 0.f; wmass0[L(j)] = 0.f; stc[L(j)] = y.stc[L(j)];
+  }
+#pragma unroll
+  for (int j = -2; j <= 0; j++)
+    if (j > isnow) { mice[L(j)] = y.snice[L(j)]; mliq[L(j)] = y.snliq[L(j)]; }
+#pragma unroll
+  for (int j = 1; j <= NSOIL; j++) {
+    float dz = y.dzsnso[L(j)];
+    mliq[L(j)] = y.sh2o[L(j)] * dz * 1000.f;
+    mice[L(j)] = (y.smc[L(j)] - y.sh2o[L(j)]) * dz * 1000.f;
+  }
+#pragma unroll
+  for (int j = -2; j <= NSOIL; j++)
+    if (j > isnow) { wice0[L(j)] = mice[L(j)]; wmass0[L(j)] = mice[L(j)] + mliq[L(j)]; }
+#pragma unroll
+  for (int j = 1; j <= NSOIL; j++) {
+    if (c.O.frz == 1) {
+      if (stc[L(j)] < TFRZ) {
+        float smp = HFUS * (TFRZ - stc[L(j)]) / (GRAV * stc[L(j)]);
+        supercool[L(j)] = P.smcmax * powf(smp / P.psisat, -1.f / P.bexp);
+        supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;
+      }
+    } else {
+      supercool[L(j)] = frh2o(P, stc[L(j)], y.smc[L(j)], y.sh2o[L(j)]);
+      supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;
+    }
+  }
+#pragma unroll
+  for (int j = -2; j <= NSOIL; j++) {
+    if (j > isnow) {
+      if (mice[L(j)] > 0.f && stc[L(j)] >= TFRZ) imelt[L(j)] = 1;
+      if (mliq[L(j)] > supercool[L(j)] && stc[L(j)] < TFRZ) imelt[L(j)] = 2;
+      if (isnow == 0 && s.sneqv > 0.f && j == 1) {
+        if (stc[L(j)] >= TFRZ) imelt[L(j)] = 1;
+      }
+      if (imelt[L(j)] > 0) {
+        hm[L(j)] = (stc[L(j)] - TFRZ) / fact[L(j)];
+        stc[L(j)] = TFRZ;
+      }
+      if (imelt[L(j)] == 1 && hm[L(j)] < 0.f) { hm[L(j)] = 0.f; imelt[L(j)] = 0; }
+      if (imelt[L(j)] == 2 && hm[L(j)] > 0.f) { hm[L(j)] = 0.f; imelt[L(j)] = 0; }
+      xm[L(j)] = hm[L(j)] * dt / HFUS;
+    }
+  }
+  (void)hm1; (void)xm1;
+  if (isnow == 0 && s.sneqv > 0.f && xm[L(1)] > 0.f) {
+    float temp1 = s.sneqv;
+    s.sneqv = fmaxf(0.f, temp1 - xm[L(1)]);
+    float propor = s.sneqv / temp1;
+    s.snowh = fmaxf(0.f, propor * s.snowh);
+    float heatr = hm[L(1)] - HFUS * (temp1 - s.sneqv) / dt;
+    if (heatr > 0.f) { xm[L(1)] = heatr * dt / HFUS; hm[L(1)] = heatr; }
+    else { xm[L(1)] = 0.f; hm[L(1)] = 0.f; }
+    qmelt = fmaxf(0.f, (temp1 - s.sneqv)) / dt;
+    ponding = temp1 - s.sneqv;
+  }
+#pragma unroll
+  for (int j = -2; j <= NSOIL; j++) {
+    if (j > isnow) {
+      if (imelt[L(j)] > 0 && fabsf(hm[L(j)]) > 0.f) {
+        float heatr = 0.f;
+        if (xm[L(j)] > 0.f) {
+          mice[L(j)] = fmaxf(0.f, wice0[L(j)] - xm[L(j)]);
+          heatr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
+        } else if (xm[L(j)] < 0.f) {
+          if (j <= 0) {
+            mice[L(j)] = fminf(wmass0[L(j)], wice0[L(j)] - xm[L(j)]);
+          } else {
+            if (wmass0[L(j)] < supercool[L(j)]) {
+              mice[L(j)] = 0.f;
+            } else {
+              mice[L(j)] = fminf(wmass0[L(j)] - supercool[L(j)], wice0[L(j)] - xm[L(j)]);
+              mice[L(j)] = fmaxf(mice[L(j)], 0.0f);
+            }
+          }
+          heatr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
+        }
+        mliq[L(j)] = fmaxf(0.f, wmass0[L(j)] - mice[L(j)]);
+        if (fabsf(heatr) > 0.f) {
+          stc[L(j)] = stc[L(j)] + fact[L(j)] * heatr;
+          if (j <= 0) {
+            if (mliq[L(j)] * mice[L(j)] > 0.f) stc[L(j)] = TFRZ;
+          }
+        }
+        if (j < 1) qmelt = qmelt + fmaxf(0.f, (wice0[L(j)] - mice[L(j)])) / dt;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = -2; j <= NSOIL; j++) {
+    if (j > isnow) { y.stc[L(j)] = stc[L(j)]; }
+    y.imelt[L(j)] = (float)imelt[L(j)];
+  }
+#pragma unroll
+  for (int j = -2; j <= 0; j++)
+    if (j > isnow) { y.snliq[L(j)] = mliq[L(j)]; y.snice[L(j)] = mice[L(j)]; }
+#pragma unroll
+  for (int j = 1; j <= NSOIL; j++) {
+    float dz = y.dzsnso[L(j)];
+    y.sh2o[L(j)] = mliq[L(j)] / (1000.f * dz);
+    y.smc[L(j)] = (mliq[L(j)] + mice[L(j)]) / (1000.f * dz);
+  }
+  s.qmelt = qmelt;
+  s.ponding = ponding;
+}
+
+// dynamic-top accessor: value of a 7-slot array at layer ISNOW+1 without run-time indexing
+NMP_DEV float at_top(const float* a, int isnow) {
+  return (isnow == 0) ? a[L(1)] : (isnow == -1) ? a[L(0)] : (isnow == -2) ? a[L(-1)] : a[L(-2)];
+}
+
+// ENERGY lsm:1231-1843
+template <class A>
+NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
+  const noahmp_tables* T = c.T;
+  const int v = s.vegtyp - 1;
+  const float MPE = 1.E-6f, PSIWLT = -150.f, Z0 = 0.01f;
+  float psnsun = 0.f, psnsha = 0.f;
+  s.irc = 0.f; s.shc = 0.f; s.irg = 0.f; s.shg = 0.f; s.evg = 0.f; s.evc = 0.f; s.tr = 0.f;
+  s.ghv = 0.f; s.t2mv = 0.f; s.q2v = 0.f; s.chv = 0.f; s.chleaf = 0.f; s.chuc = 0.f; s.chv2 = 0.f;
+  VegIn q;
+  q.ur = fmaxf(sqrtf(s.uu * s.uu + s.vv * s.vv), 1.f);          // UU**2.+VV**2. (lsm:1536)
+  q.vai = s.elai + s.esai;
+  const bool veg = (q.vai > 0.f);
+  s.fsno = 0.f;
+  if (s.snowh > 0.f) {
+    float bdsno = s.sneqv / s.snowh;
+    float fmelt = powf(bdsno / 100.f, M_MELT);
+    s.fsno = tanhf(s.snowh / (2.5f * Z0 * fmelt));
+  }
+  q.z0mg = Z0 * (1.0f - s.fsno) + s.fsno * Z0SNO;
+  const float zpdg = s.snowh;
+  if (veg) {
+    q.z0m = T->z0mvt[v];
+    q.zpd = 0.65f * s.htop;
+    if (s.snowh > q.zpd) q.zpd = s.snowh;
+  } else {
+    q.z0m = q.z0mg;
+    q.zpd = zpdg;
+  }
+  q.zlvl = fmaxf(q.zpd, s.htop) + s.zlvl;
+  if (zpdg >= q.zlvl) q.zlvl = zpdg + s.zlvl;
+  q.cwp = T->cwpvt[v];
+  float df[NL], hcpct[NL], fact[NL];
+#pragma unroll
+  for (int k = 0; k < NL; k++) { df[k] = 0.f; hcpct[k] = 0.f; fact[k] = 0.f; }
+  thermoprop(c, P, s, y, df, hcpct, fact);
+  RadOut r = radiation(c, s, y.smc[L(1)]);
+  q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
+  q.emv = 1.f - expf(-(s.elai + s.esai) / 1.0f);
+  q.emg = T->eg[s.ist - 1] * (1.f - s.fsno) + 1.0f * s.fsno;    // ICE is 0 on this path (drv:549)
+  // BTRAN lsm:1617-1640
+  s.btran = 0.f;
+  const float zroot = -c.zsoil[L(P.nroot)];
+#pragma unroll
+  for (int iz = 1; iz <= NSOIL; iz++) {
+    if (iz <= P.nroot) {
+      float gx, sh = y.sh2o[L(iz)];
+      if (c.O.btr == 1) {
+        gx = (sh - P.smcwlt) / (P.smcref - P.smcwlt);
+      } else {
+        float psi = fmaxf(PSIWLT, -P.psisat * powf(fmaxf(0.01f, sh) / P.smcmax, -P.bexp));
+        if (c.O.btr == 2) gx = (1.f - psi / PSIWLT) / (1.f + P.psisat / PSIWLT);
+        else gx = 1.f - expf(-5.8f * (logf(PSIWLT / psi)));
+      }
+      gx = fminf(1.f, fmaxf(0.f, gx));
+      float bt = fmaxf(MPE, y.dzsnso[L(iz)] / zroot * gx);
+      y.btrani[L(iz)] = bt;
+      s.btran = s.btran + bt;
+    }
+  }
+  s.btran = fmaxf(MPE, s.btran);
+#pragma unroll
+  for (int iz = 1; iz <= NSOIL; iz++)
+    if (iz <= P.nroot) y.btrani[L(iz)] = y.btrani[L(iz)] / s.btran;
+  // soil surface resistance lsm:1644-1669
+  {
+    float sh1 = y.sh2o[L(1)];
+    float l_rsurf = (-c.zsoil[L(1)]) * (expf(powi5(1.0f - fminf(1.0f, sh1 / P.smcmax))) - 1.0f) /
+                    (2.71828f - 1.0f);
+    float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * powf(1.0f - P.smcwlt / P.smcmax, 2.0f + 3.0f / P.bexp);
+    q.rsurf = l_rsurf / d_rsurf;
+    if (sh1 < 0.01f && s.snowh == 0.f) q.rsurf = 1.E6f;
+    float psi = -P.psisat * powf(fmaxf(0.01f, sh1) / P.smcmax, -P.bexp);
+    q.rhsur = s.fsno + (1.f - s.fsno) * expf(psi * GRAV / (RW * s.tg));
+  }
+  if (s.vegtyp == c.isurban && s.snowh == 0.f) q.rsurf = 1.E6f;
+  if (s.tv > TFRZ) { s.latheav = HVAP; s.frozen_canopy = 0; } else { s.latheav = HSUB; s.frozen_canopy = 1; }
+  q.gammav = CPAIR * s.sfcprs / (0.622f * s.latheav);
+  if (s.tg > TFRZ) { s.latheag = HVAP; s.frozen_ground = 0; } else { s.latheag = HSUB; s.frozen_ground = 1; }
+  q.gammag = CPAIR * s.sfcprs / (0.622f * s.latheag);
+  q.df_top = at_top(df, s.isnow);
+  q.dz_top = y.dzsnso[L(s.isnow + 1)];
+  q.stc_top = y.stc[L(s.isnow + 1)];
+
+  float cmv = 0.f, cmb;
+  const bool canopy = veg && s.fveg > 0;
+  if (canopy) {
+    s.tgv = s.tg;
+    cmv = s.cm;
+    s.chv = s.ch;
+    vege_flux(c, P, s, q, cmv, psnsun, psnsha);
+  }
+  s.tgb = s.tg;
+  cmb = s.cm;
+  s.chb = s.ch;
+  bare_flux(c, P, s, q, zpdg, cmb);
+  if (canopy) {
+    s.fira = s.fveg * s.irg + (1.0f - s.fveg) * s.irb + s.irc;
+    s.fsh = s.fveg * s.shg + (1.0f - s.fveg) * s.shb + s.shc;
+    s.fgev = s.fveg * s.evg + (1.0f - s.fveg) * s.evb;
+    s.ssoil = s.fveg * s.ghv + (1.0f - s.fveg) * s.ghb;
+    s.fcev = s.evc;
+    s.fctr = s.tr;
+    s.tg = s.fveg * s.tgv + (1.0f - s.fveg) * s.tgb;
+    s.cm = s.fveg * cmv + (1.0f - s.fveg) * cmb;
+    s.ch = s.fveg * s.chv + (1.0f - s.fveg) * s.chb;
+  } else {
+    s.fira = s.irb; s.fsh = s.shb; s.fgev = s.evb; s.ssoil = s.ghb; s.tg = s.tgb;
+    s.fcev = 0.f; s.fctr = 0.f;
+    s.cm = cmb; s.ch = s.chb;
+    s.rssun = 0.0f; s.rssha = 0.0f;
+    s.tgv = s.tgb; s.chv = s.chb;
+  }
+  float fire = s.lwdn + s.fira;
+  if (fire <= 0.f) raise(s, NOAHMP_ERR_FIRE_NONPOSITIVE);
+  s.emissi = s.fveg * (q.emg * (1 - q.emv) + q.emv + q.emv * (1 - q.emv) * (1 - q.emg)) +
+             (1 - s.fveg) * q.emg;
+  s.trad = powf((fire - (1 - s.emissi) * s.lwdn) / (s.emissi * SB), 0.25f);
+  s.apar = r.parsun * r.laisun + r.parsha * r.laisha;
+  s.psn = psnsun * r.laisun + psnsha * r.laisha;
+  tsnosoi(c, P, s, y, df, hcpct);
+  if (c.O.stc == 2) {
+    if (s.snowh > 0.05f && s.tg > TFRZ) {
+      s.tgv = TFRZ; s.tgb = TFRZ;
+      if (canopy) s.tg = s.fveg * s.tgv + (1.0f - s.fveg) * s.tgb;
+      else s.tg = s.tgb;
+    }
+  }
+  phasechange(c, P, s, y, fact);
+}
+
+}  // namespace nmp

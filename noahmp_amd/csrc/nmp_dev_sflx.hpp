@@ -1,0 +1,246 @@
+// Noah-MP column engine for MI355X -- NOAHMP_SFLX orchestration, REDPRM, PHENOLOGY, CARBON, ERROR.
+// Reference: lsm:518-1228, lsm:8723-9104, lsm:9202-9349.
+#pragma once
+#include "nmp_dev_energy.hpp"
+#include "nmp_dev_water.hpp"
+
+namespace nmp {
+
+// REDPRM lsm:9202-9349: table gather into per-thread registers (the reference writes module globals)
+NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
+  const noahmp_tables* T = c.T;
+  if (soiltyp > T->slcats || soiltyp < 1) { raise(s, NOAHMP_ERR_SOILTYP_RANGE); soiltyp = 1; }
+  if (vegtyp > T->lucats || vegtyp < 1) { raise(s, NOAHMP_ERR_VEGTYP_RANGE); vegtyp = 1; }
+  const int st = soiltyp - 1, vt = vegtyp - 1;
+  P.csoil = T->csoil_data;
+  P.bexp = T->bb[st];
+  P.dksat = T->satdk[st];
+  P.dwsat = T->satdw[st];
+  P.psisat = T->satpsi[st];
+  P.quartz = T->qtz[st];
+  P.smcmax = T->maxsmc[st];
+  P.smcref = T->refsmc[st];
+  P.smcwlt = T->wltsmc[st];
+  if (vegtyp == c.isurban) { P.smcmax = 0.45f; P.smcref = 0.42f; P.smcwlt = 0.40f; P.csoil = 3.E6f; }
+  P.zbot = T->zbot_data;
+  P.czil = T->czil_data;
+  P.kdt = T->refkdt_data * P.dksat / T->refdk_data;
+  P.slope = T->slope_data[0];                         // SLOPETYP = 1 (drv:525)
+  P.frzx = T->frzk_data * ((P.smcmax / P.smcref) * (0.412f / 0.468f));
+  P.topt = T->topt_data;
+  P.rgl = T->rgltbl[vt];
+  P.rsmax = T->rsmax_data;
+  P.rsmin = T->rstbl[vt];
+  P.hs = T->hstbl[vt];
+  P.nroot = T->nrotbl[vt];
+  if (vegtyp == c.isurban) P.rsmin = 400.0f;
+  if (P.nroot > NSOIL) { raise(s, NOAHMP_ERR_NROOT_GT_NSOIL); P.nroot = NSOIL; }
+}
+
+// PHENOLOGY lsm:1010-1104
+NMP_DEV void phenology(const Ctx& c, Col& s) {
+  const noahmp_tables* T = c.T;
+  const int v = s.vegtyp - 1;
+  if (c.O.dveg == 1 || c.O.dveg == 3 || c.O.dveg == 4) {
+    float day;
+    if (s.lat >= 0.f) day = s.julian;
+    else day = fmodf(s.julian + (0.5f * s.yearlen), (float)s.yearlen);
+    float t = 12.f * day / (float)s.yearlen;
+    int it1 = (int)(t + 0.5f);                        // REAL -> INTEGER truncation (lsm:1063)
+    int it2 = it1 + 1;
+    float wt1 = (it1 + 0.5f) - t;
+    float wt2 = 1.f - wt1;
+    if (it1 < 1) it1 = 12;
+    if (it2 > 12) it2 = 1;
+    s.lai = wt1 * T->laim[it1 - 1][v] + wt2 * T->laim[it2 - 1][v];
+    s.sai = wt1 * T->saim[it1 - 1][v] + wt2 * T->saim[it2 - 1][v];
+  }
+  if (s.sai < 0.01f) s.sai = 0.0f;
+  if (s.lai < 0.05f || s.sai == 0.0f) s.lai = 0.0f;
+  if ((s.vegtyp == T->iswater) || (s.vegtyp == T->isbarren) || (s.vegtyp == T->issnow) ||
+      (s.vegtyp == c.isurban)) {
+    s.lai = 0.f; s.sai = 0.f;
+  }
+  const float hvt = T->hvt[v], hvb = T->hvb[v];
+  float db = fminf(fmaxf(s.snowh - hvb, 0.f), hvt - hvb);
+  float fb = db / fmaxf(1.E-06f, hvt - hvb);
+  if (hvt > 0.f && hvt <= 1.0f) {
+    float snowhc = hvt * expf(-s.snowh / 0.2f);
+    fb = fminf(s.snowh, snowhc) / snowhc;
+  }
+  s.elai = s.lai * (1.f - fb);
+  s.esai = s.sai * (1.f - fb);
+  if (s.esai < 0.01f) s.esai = 0.0f;
+  if (s.elai < 0.05f || s.esai == 0.0f) s.elai = 0.0f;
+  s.igs = (s.tv > T->tmin[v]) ? 1.f : 0.f;
+  s.htop = hvt;
+}
+
+// CARBON lsm:8723-8835 + CO2FLUX lsm:8837-9104 (DVEG 2 / 5 only)
+template <class A>
+NMP_DEV void carbon(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
+  const noahmp_tables* T = c.T;
+  const int v = s.vegtyp - 1;
+  const float dt = c.dt;
+  if ((s.vegtyp == T->iswater) || (s.vegtyp == T->isbarren) || (s.vegtyp == T->issnow) ||
+      (s.vegtyp == c.isurban)) {
+    s.lai = 0.f; s.sai = 0.f; s.gpp = 0.f; s.npp = 0.f; s.nee = 0.f;
+    s.lfmass = 0.f; s.rtmass = 0.f; s.stmass = 0.f; s.wood = 0.f; s.stblcp = 0.f; s.fastcp = 0.f;
+    return;
+  }
+  float lapm = T->sla[v] / 1000.f;
+  float wstres = 1.f - s.btran;
+  float wroot = 0.f;
+  const float zroot = -c.zsoil[L(P.nroot)];
+#pragma unroll
+  for (int j = 1; j <= NSOIL; j++)
+    if (j <= P.nroot) wroot = wroot + y.smc[L(j)] / P.smcmax * y.dzsnso[L(j)] / zroot;
+  const float rtovrc = 2.0E-8f, rswoodc = 3.0E-10f, bf = 0.90f, wstrc = 100.0f, laimin = 0.05f,
+              xsamin = 0.01f;
+  float sapm = 3.f * 0.001f;
+  float lfmsmn = laimin / lapm, stmsmn = xsamin / sapm;
+  float rf = (s.igs == 0.f) ? 0.5f : 1.0f;
+  float tv = s.tv;
+  float fnf = fminf(s.foln / fmaxf(1.E-06f, T->folnmx[v]), 1.0f);
+  float tf = powf(T->arm[v], (tv - 298.16f) / 10.f);
+  float resp = T->rmf25[v] * tf * fnf * s.lai * rf * (1.f - wstres);
+  float rsleaf = fminf(s.lfmass / dt, resp * 12.e-6f);
+  float rsroot = T->rmr25[v] * (s.rtmass * 1E-3f) * tf * rf * 12.e-6f;
+  float rsstem = T->rms25[v] * (s.stmass * 1E-3f) * tf * rf * 12.e-6f;
+  float rswood = rswoodc * expf(0.08f * (tv - 298.16f)) * s.wood * T->wdpool[v];
+  float carbfx = s.psn * 12.e-6f;
+  float leafpt = expf(0.01f * (1.f - expf(0.75f * s.lai)) * s.lai);
+  if (s.vegtyp == T->eblforest) leafpt = expf(0.01f * (1.f - expf(0.50f * s.lai)) * s.lai);
+  float nonlef = 1.0f - leafpt;
+  float stempt = s.lai / 10.0f;
+  leafpt = leafpt - stempt;
+  float woodf;
+  if (s.wood > 0) woodf = (1.f - expf(-bf * (T->wrrat[v] * s.rtmass / s.wood)) / bf) * T->wdpool[v];
+  else woodf = 0.f;
+  float rootpt = nonlef * (1.f - woodf);
+  float woodpt = nonlef * woodf;
+  float lftovr = T->ltovrc[v] * 1.E-6f * s.lfmass;
+  float sttovr = T->ltovrc[v] * 1.E-6f * s.stmass;
+  float rttovr = rtovrc * s.rtmass;
+  float wdtovr = 9.5E-10f * s.wood;
+  float sc = expf(-0.3f * fmaxf(0.f, tv - T->tdlef[v])) * (s.lfmass / 120.f);
+  float sd = expf((wstres - 1.f) * wstrc);
+  float dielf = s.lfmass * 1.E-6f * (T->dilefw[v] * sd + T->dilefc[v] * sc);
+  float diest = s.stmass * 1.E-6f * (T->dilefw[v] * sd + T->dilefc[v] * sc);
+  float grleaf = fmaxf(0.0f, T->fragr[v] * (leafpt * carbfx - rsleaf));
+  float grstem = fmaxf(0.0f, T->fragr[v] * (stempt * carbfx - rsstem));
+  float grroot = fmaxf(0.0f, T->fragr[v] * (rootpt * carbfx - rsroot));
+  float grwood = fmaxf(0.0f, T->fragr[v] * (woodpt * carbfx - rswood));
+  float addnpplf = fmaxf(0.f, leafpt * carbfx - grleaf - rsleaf);
+  float addnppst = fmaxf(0.f, stempt * carbfx - grstem - rsstem);
+  if (tv < T->tmin[v]) { addnpplf = 0.f; addnppst = 0.f; }
+  float lfdel = (s.lfmass - lfmsmn) / dt;
+  float stdel = (s.stmass - stmsmn) / dt;
+  dielf = fminf(dielf, lfdel + addnpplf - lftovr);
+  diest = fminf(diest, stdel + addnppst - sttovr);
+  float nppl = fmaxf(addnpplf, -lfdel);
+  float npps = fmaxf(addnppst, -stdel);
+  float nppr = rootpt * carbfx - rsroot - grroot;
+  float nppw = woodpt * carbfx - rswood - grwood;
+  s.lfmass = s.lfmass + (nppl - lftovr - dielf) * dt;
+  s.stmass = s.stmass + (npps - sttovr - diest) * dt;
+  s.rtmass = s.rtmass + (nppr - rttovr) * dt;
+  if (s.rtmass < 0.0f) { rttovr = nppr; s.rtmass = 0.0f; }
+  s.wood = (s.wood + (nppw - wdtovr) * dt) * T->wdpool[v];
+  s.fastcp = s.fastcp + (rttovr + lftovr + sttovr + wdtovr + dielf) * dt;
+  float fst = powf(2.0f, (y.stc[L(1)] - 283.16f) / 10.f);
+  float fsw = wroot / (0.20f + wroot) * 0.23f / (0.23f + wroot);
+  float rssoil = fsw * fst * T->mrp[v] * fmaxf(0.f, s.fastcp * 1.E-3f) * 12.E-6f;
+  float stablc = 0.1f * rssoil;
+  s.fastcp = s.fastcp - (rssoil + stablc) * dt;
+  s.stblcp = s.stblcp + stablc * dt;
+  s.gpp = carbfx;
+  s.npp = nppl + nppw + nppr;
+  float autors = rsroot + rswood + rsleaf + grleaf + grroot + grwood;
+  s.nee = (autors + rssoil - s.gpp) * 44.f / 12.f;
+  s.lai = fmaxf(s.lfmass * lapm, laimin);
+  s.sai = fmaxf(s.stmass * sapm, xsamin);
+}
+
+// NOAHMP_SFLX lsm:518-947 (with ATM lsm:949-1007 and ERROR lsm:1106-1228)
+template <class A>
+NMP_DEV void sflx(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
+  const noahmp_tables* T = c.T;
+  s.nee = 0.f; s.npp = 0.f; s.gpp = 0.f;
+  // ATM
+  s.thair = s.sfctmp;                                  // SFCTMP*(SFCPRS/PAIR)**(RAIR/CPAIR), PAIR==SFCPRS
+  s.qair = s.q2;
+  s.eair = s.qair * s.sfcprs / (0.622f + 0.378f * s.qair);
+  s.rhoair = (s.sfcprs - 0.378f * s.eair) / (RAIR * s.sfctmp);
+  s.qprecc = 0.10f * s.prcp;
+  s.qprecl = 0.90f * s.prcp;
+  s.swdown = (s.cosz <= 0.f) ? 0.f : s.soldn;
+  s.solad0 = s.swdown * 0.7f * 0.5f; s.solad1 = s.swdown * 0.7f * 0.5f;
+  s.solai0 = s.swdown * 0.3f * 0.5f; s.solai1 = s.swdown * 0.3f * 0.5f;
+  // layer thicknesses (lsm:788-794)
+  {
+    float prev = 0.f;
+#pragma unroll
+    for (int iz = -2; iz <= NSOIL; iz++) {
+      if (iz > s.isnow) {
+        float z = y.zsnso[L(iz)];
+        y.dzsnso[L(iz)] = (iz == s.isnow + 1) ? -z : (prev - z);
+        prev = z;
+      }
+    }
+  }
+  float beg_wb = s.canliq + s.canice + s.sneqv + s.wa;
+#pragma unroll
+  for (int iz = 1; iz <= NSOIL; iz++) beg_wb = beg_wb + y.smc[L(iz)] * y.dzsnso[L(iz)] * 1000.f;
+  phenology(c, s);
+  if (c.O.dveg == 1) {
+    s.fveg = s.shdfac;
+    if (s.fveg <= 0.01f) s.fveg = 0.01f;
+  } else if (c.O.dveg == 2 || c.O.dveg == 3) {
+    s.fveg = 1.f - expf(-0.52f * (s.lai + s.sai));
+    if (s.fveg <= 0.01f) s.fveg = 0.01f;
+  } else if (c.O.dveg == 4 || c.O.dveg == 5) {
+    s.fveg = s.shdmax;
+    if (s.fveg <= 0.01f) s.fveg = 0.01f;
+  } else {
+    raise(s, NOAHMP_ERR_DVEG_UNKNOWN);
+    s.fveg = 0.01f;
+  }
+  if (s.vegtyp == c.isurban || s.vegtyp == T->isbarren) s.fveg = 0.0f;
+  if (s.elai + s.esai == 0.0f) s.fveg = 0.0f;
+
+  energy(c, P, s, y);
+
+#pragma unroll
+  for (int iz = 1; iz <= NSOIL; iz++) y.sice[L(iz)] = fmaxf(0.0f, y.smc[L(iz)] - y.sh2o[L(iz)]);
+  s.sneqvo = s.sneqv;
+  float qvap = fmaxf(s.fgev / s.latheag, 0.f);
+  float qdew = fabsf(fminf(s.fgev / s.latheag, 0.f));
+  s.edir = qvap - qdew;
+
+  water(c, P, s, y, qvap, qdew);
+
+  if (c.O.dveg == 2 || c.O.dveg == 5) carbon(c, P, s, y);
+
+  // ERROR: the reference STOPs; here the column raises its status word and finishes the step
+  {
+    float errsw = s.swdown - (s.fsa + s.fsr);
+    if (fabsf(errsw) > 0.01f) raise(s, NOAHMP_ERR_SW_BALANCE);
+    float erreng = s.sav + s.sag - (s.fira + s.fsh + s.fcev + s.fgev + s.fctr + s.ssoil);
+    if (fabsf(erreng) > 0.01f) raise(s, NOAHMP_ERR_ENERGY_BALANCE);
+    float end_wb = s.canliq + s.canice + s.sneqv + s.wa;
+#pragma unroll
+    for (int iz = 1; iz <= NSOIL; iz++) end_wb = end_wb + y.smc[L(iz)] * y.dzsnso[L(iz)] * 1000.f;
+    float errwat = end_wb - beg_wb - (s.prcp - s.ecan - s.etran - s.edir - s.runsrf - s.runsub) * c.dt;
+    if (fabsf(errwat) > 0.1f) raise(s, NOAHMP_ERR_WATER_BALANCE);
+  }
+  float qfx = s.etran + s.ecan + s.edir;
+  if (s.vegtyp == c.isurban) {
+    s.qsfc = (qfx / s.rhoair * s.ch) + s.qair;
+    s.q2b = s.qsfc;
+  }
+  if (s.snowh <= 1.E-6f || s.sneqv <= 1.E-3f) { s.snowh = 0.0f; s.sneqv = 0.0f; }
+  s.albedo = (s.swdown != 0.f) ? (s.fsr / s.swdown) : -999.9f;
+}
+
+}  // namespace nmp

@@ -1,0 +1,464 @@
+// Noah-MP column engine for MI355X (gfx950): kernels + the C-ABI of include/noahmp_hip.h.
+//
+// Drop-in boundary: noahmp_hip_step() replaces the body of module_sf_noahmpdrv::noahmplsm
+// (reference phys/module_sf_noahmpdrv.F90:11-844).  The JLOOP/ILOOP gather -> NOAHMP_SFLX ->
+// scatter of drv:397-840 becomes one kernel launch: thread t owns column (i,j); every field is
+// read / written in the caller's own Fortran layout, whose i-contiguous rows are already the
+// coalesced structure-of-arrays the GPU wants.  No CPU fallback exists in this library.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "noahmp_hip.h"
+#include "nmp_dev_sflx.hpp"
+#include "nmp_dev_glacier.hpp"
+
+using namespace nmp;
+
+namespace {
+
+struct KArgs {
+  noahmp_step_args a;     // array members hold DEVICE pointers here
+  Ctx c;
+  int ni, nka;            // memory extents: ni = ime-ims+1, nka = kme-kms+1
+  int nti, ntj;           // tile extents
+  int k1;                 // 0-based slot of atmospheric level 1 inside (kms:kme)
+  int kp_lo, kp_hi;       // slots of P8W3D(kts), P8W3D(kts+1)
+  int yearlen;
+  unsigned long long* err;   // min over columns of ((linear index + 1) << 8 | code)
+  int* counts;               // [0]=land [1]=glacier [2]=skipped
+};
+
+constexpr int LAY_SLOTS = 4 * 7 + 5 * 4 + 3 * 3;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold
+
+template <int STRIDE>
+__device__ __forceinline__ Lay<LArr<STRIDE>> make_lay(float* base) {
+  Lay<LArr<STRIDE>> y;
+  int o = 0;
+  y.stc.p = base + o * STRIDE; o += 7;
+  y.zsnso.p = base + o * STRIDE; o += 7;
+  y.dzsnso.p = base + o * STRIDE; o += 7;
+  y.imelt.p = base + o * STRIDE; o += 7;
+  // soil-only arrays keep slots L(1)..L(4): bias the base pointer by -L(1) slots
+  y.smc.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.sh2o.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.sice.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.smceq.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.btrani.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.snice.p = base + o * STRIDE; o += 3;
+  y.snliq.p = base + o * STRIDE; o += 3;
+  y.ficeold.p = base + o * STRIDE; o += 3;
+  return y;
+}
+
+#define G2(f) k.a.f[ij]
+#define G3(f, lev, nk) k.a.f[((size_t)jj * (nk) + (lev)) * k.ni + ii]
+
+// One thread = one column-step (the ILOOP body, drv:424-837).
+template <int BLOCK, bool USE_LDS>
+__global__ void __launch_bounds__(BLOCK) noahmp_column_kernel(const KArgs k) {
+  constexpr int STRIDE = USE_LDS ? BLOCK : 1;
+  __shared__ float lds[USE_LDS ? LAY_SLOTS * BLOCK : 1];
+  float priv[USE_LDS ? 1 : LAY_SLOTS];
+  float* base = USE_LDS ? (lds + threadIdx.x) : priv;
+  Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
+
+  const long t = (long)blockIdx.x * BLOCK + threadIdx.x;
+  const bool inside = t < (long)k.nti * k.ntj;
+  int cls = 3;   // 0 land, 1 glacier, 2 skipped, 3 outside
+  int ii = 0, jj = 0;
+  size_t ij = 0;
+  if (inside) {
+    const int tj = (int)(t / k.nti), ti = (int)(t - (long)tj * k.nti);
+    ii = k.a.its - k.a.ims + ti;
+    jj = k.a.jts - k.a.jms + tj;
+    ij = (size_t)jj * k.ni + ii;
+    const float xland = G2(xland), xice = G2(xice);
+    const int ivg = G2(ivgtyp);
+    int ice = (xice >= k.a.xice_thres) ? 1 : ((ivg == k.a.isice) ? -1 : 0);      // drv:426-432
+    const bool water = (xland - 1.5f) >= 0.f;
+    if (k.a.itimestep == 1) {                                                      // drv:399-419
+      if (water) {
+        G2(smstav) = 1.0f; G2(smstot) = 1.0f;
+        for (int l = 0; l < NSOIL; l++) { G3(smois, l, NSOIL) = 1.0f; G3(tslb, l, NSOIL) = 273.16f; }
+      } else if (xice == 1.f) {
+        G2(smstav) = 1.0f; G2(smstot) = 1.0f;
+        for (int l = 0; l < NSOIL; l++) G3(smois, l, NSOIL) = 1.0f;
+      }
+    }
+    if (water) cls = 2;
+    else if (ice == 1) {                                                           // drv:436-441
+      for (int l = 0; l < NSOIL; l++) G3(sh2o, l, NSOIL) = 1.0f;
+      G2(xlaixy) = 0.01f;
+      cls = 2;
+    } else cls = (ice == -1) ? 1 : 0;
+  }
+  // per-wave tallies (64-wide wavefront)
+  {
+    unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+    if ((threadIdx.x & 63) == 0) {
+      if (m0) atomicAdd(&k.counts[0], __popcll(m0));
+      if (m1) atomicAdd(&k.counts[1], __popcll(m1));
+      if (m2) atomicAdd(&k.counts[2], __popcll(m2));
+    }
+  }
+  if (cls > 1) return;
+
+  Col s;
+  memset(&s, 0, sizeof(s));
+  // ---- gather, drv:449-545
+  s.cosz = G2(coszin); s.lat = G2(xlatin);
+  s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
+  int vegtyp = G2(ivgtyp), soiltyp = G2(isltyp);
+  s.shdfac = G2(vegfra) / 100.f;
+  s.shdmax = G2(vegmax) / 100.f;
+  s.tbot = G2(tmn);
+  s.sfctmp = G3(t3d, k.k1, k.nka);
+  { float qv = G3(qv3d, k.k1, k.nka); s.q2 = qv / (1.0f + qv); }
+  s.uu = G3(u_phy, k.k1, k.nka); s.vv = G3(v_phy, k.k1, k.nka);
+  s.soldn = G2(swdown); s.lwdn = G2(glw);
+  s.sfcprs = (G3(p8w3d, k.kp_hi, k.nka) + G3(p8w3d, k.kp_lo, k.nka)) * 0.5f;
+  s.psfc = G3(p8w3d, k.k1, k.nka);
+  s.prcp = G2(rainbl) / k.a.dt;
+  s.isnow = G2(isnowxy);
+#pragma unroll
+  for (int l = 1; l <= NSOIL; l++) {
+    y.smc[L(l)] = G3(smois, l - 1, NSOIL); y.sh2o[L(l)] = G3(sh2o, l - 1, NSOIL);
+    y.stc[L(l)] = G3(tslb, l - 1, NSOIL); y.smceq[L(l)] = G3(smoiseq, l - 1, NSOIL);
+    y.sice[L(l)] = 0.f; y.btrani[L(l)] = 0.f;
+  }
+#pragma unroll
+  for (int l = -2; l <= 0; l++) {
+    float si = G3(snicexy, l + 2, 3), sl = G3(snliqxy, l + 2, 3);
+    y.stc[L(l)] = G3(tsnoxy, l + 2, 3); y.snice[L(l)] = si; y.snliq[L(l)] = sl;
+    y.ficeold[L(l)] = (l > s.isnow) ? si / (si + sl) : 0.f;                        // drv:516-518
+  }
+#pragma unroll
+  for (int l = -2; l <= NSOIL; l++) {
+    y.zsnso[L(l)] = G3(zsnsoxy, l + 2, NSOIL + 3); y.dzsnso[L(l)] = 0.f; y.imelt[L(l)] = 0.f;
+  }
+  s.sneqv = G2(snow); s.snowh = G2(snowh); s.qsfc = G2(qsfc);
+  s.tv = G2(tvxy); s.tg = G2(tgxy); s.canliq = G2(canliqxy); s.canice = G2(canicexy);
+  s.eah = G2(eahxy); s.tah = G2(tahxy); s.cm = G2(cmxy); s.ch = G2(chxy); s.fwet = G2(fwetxy);
+  s.sneqvo = G2(sneqvoxy); s.albold = G2(alboldxy); s.qsnow = G2(qsnowxy);
+  s.wslake = G2(wslakexy); s.zwt = G2(zwtxy); s.wa = G2(waxy); s.wt = G2(wtxy);
+  s.lfmass = G2(lfmassxy); s.rtmass = G2(rtmassxy); s.stmass = G2(stmassxy); s.wood = G2(woodxy);
+  s.stblcp = G2(stblcpxy); s.fastcp = G2(fastcpxy); s.lai = G2(xlaixy); s.sai = G2(xsaixy);
+  s.tauss = G2(taussxy); s.smcwtd = G2(smcwtdxy);
+  s.rech = 0.f; s.deeprech = 0.f;
+  s.co2air = 395.e-06f * s.sfcprs;
+  s.o2air = 0.209f * s.sfcprs;
+  s.foln = 1.0f;
+  s.ist = 1; s.isc = 4; s.ice = (cls == 1) ? -1 : 0;
+  s.yearlen = k.yearlen; s.julian = k.a.julian;
+  if (soiltyp == 14 && G2(xice) == 0.f) soiltyp = 7;
+  if (vegtyp == k.a.isurban || vegtyp == 31 || vegtyp == 32 || vegtyp == 33) vegtyp = k.a.isurban;
+  if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }
+  Parm P;
+  redprm(k.c, s, P, vegtyp, soiltyp);
+  s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
+
+  float qfx_out, lh_out;
+  if (cls == 1) {
+    s.tbot = fminf(s.tbot, 263.15f);                                               // drv:555
+    glacier(k.c, s, y);
+    glacier_fill_undefined(s);                                                     // drv:571-625
+    qfx_out = s.edir; lh_out = s.fgev;                                             // drv:627-628
+  } else {
+    sflx(k.c, P, s, y);
+    qfx_out = s.ecan + s.edir + s.etran;                                           // drv:713-714
+    lh_out = s.fcev + s.fgev + s.fctr;
+  }
+
+  if (s.err) {
+    unsigned long long key = ((unsigned long long)(t + 1) << 8) | (unsigned)s.err;
+    atomicMin(k.err, key);
+    return;                                   // the reference STOPs at this column: leave it untouched
+  }
+  // ---- scatter, drv:728-835
+  G2(qfx) = qfx_out; G2(lh) = lh_out;
+  G2(tsk) = s.trad; G2(hfx) = s.fsh; G2(grdflx) = s.ssoil;
+  G2(smstav) = 0.0f; G2(smstot) = 0.0f;
+  G2(sfcrunoff) = G2(sfcrunoff) + s.runsrf * k.a.dt;
+  G2(udrunoff) = G2(udrunoff) + s.runsub * k.a.dt;
+  if (s.albedo > -999) G2(albedo) = s.albedo;
+  G2(snowc) = s.fsno;
+#pragma unroll
+  for (int l = 1; l <= NSOIL; l++) {
+    G3(smois, l - 1, NSOIL) = y.smc[L(l)]; G3(sh2o, l - 1, NSOIL) = y.sh2o[L(l)];
+    G3(tslb, l - 1, NSOIL) = y.stc[L(l)];
+  }
+  G2(snow) = s.sneqv; G2(snowh) = s.snowh;
+  G2(canwat) = s.canliq + s.canice;
+  G2(acsnow) = G2(acsnow) + s.prcp * s.fpice;                                      // no *DT (drv:751)
+  G2(acsnom) = G2(acsnom) + s.qsnbot * k.a.dt + s.ponding + s.ponding1 + s.ponding2;
+  G2(emiss) = s.emissi; G2(qsfc) = s.qsfc;
+  G2(isnowxy) = s.isnow; G2(tvxy) = s.tv; G2(tgxy) = s.tg; G2(canliqxy) = s.canliq;
+  G2(canicexy) = s.canice; G2(eahxy) = s.eah; G2(tahxy) = s.tah; G2(cmxy) = s.cm; G2(chxy) = s.ch;
+  G2(fwetxy) = s.fwet; G2(sneqvoxy) = s.sneqvo; G2(alboldxy) = s.albold; G2(qsnowxy) = s.qsnow;
+  G2(wslakexy) = s.wslake; G2(zwtxy) = s.zwt; G2(waxy) = s.wa; G2(wtxy) = s.wt;
+#pragma unroll
+  for (int l = -2; l <= 0; l++) {
+    G3(tsnoxy, l + 2, 3) = y.stc[L(l)]; G3(snicexy, l + 2, 3) = y.snice[L(l)];
+    G3(snliqxy, l + 2, 3) = y.snliq[L(l)];
+  }
+#pragma unroll
+  for (int l = -2; l <= NSOIL; l++) G3(zsnsoxy, l + 2, NSOIL + 3) = y.zsnso[L(l)];
+  G2(lfmassxy) = s.lfmass; G2(rtmassxy) = s.rtmass; G2(stmassxy) = s.stmass; G2(woodxy) = s.wood;
+  G2(stblcpxy) = s.stblcp; G2(fastcpxy) = s.fastcp; G2(xlaixy) = s.lai; G2(xsaixy) = s.sai;
+  G2(taussxy) = s.tauss;
+  G2(t2mvxy) = s.t2mv; G2(t2mbxy) = s.t2mb;
+  G2(q2mvxy) = s.q2v / (1.0f - s.q2v); G2(q2mbxy) = s.q2b / (1.0f - s.q2b);
+  G2(tradxy) = s.trad; G2(neexy) = s.nee; G2(gppxy) = s.gpp; G2(nppxy) = s.npp;
+  G2(fvegxy) = s.fveg; G2(runsfxy) = s.runsrf; G2(runsbxy) = s.runsub; G2(ecanxy) = s.ecan;
+  G2(edirxy) = s.edir; G2(etranxy) = s.etran; G2(fsaxy) = s.fsa; G2(firaxy) = s.fira;
+  G2(aparxy) = s.apar; G2(psnxy) = s.psn; G2(savxy) = s.sav; G2(sagxy) = s.sag;
+  G2(rssunxy) = s.rssun; G2(rsshaxy) = s.rssha; G2(bgapxy) = s.bgap; G2(wgapxy) = s.wgap;
+  G2(tgvxy) = s.tgv; G2(tgbxy) = s.tgb; G2(chvxy) = s.chv; G2(chbxy) = s.chb;
+  G2(ircxy) = s.irc; G2(irgxy) = s.irg; G2(shcxy) = s.shc; G2(shgxy) = s.shg; G2(evgxy) = s.evg;
+  G2(ghvxy) = s.ghv; G2(irbxy) = s.irb; G2(shbxy) = s.shb; G2(evbxy) = s.evb; G2(ghbxy) = s.ghb;
+  G2(trxy) = s.tr; G2(evcxy) = s.evc; G2(chleafxy) = s.chleaf; G2(chucxy) = s.chuc;
+  G2(chv2xy) = s.chv2; G2(chb2xy) = s.chb2;
+  G2(rechxy) = G2(rechxy) + s.rech * 1.E3f;
+  G2(deeprechxy) = G2(deeprechxy) + s.deeprech;
+  G2(smcwtdxy) = s.smcwtd;
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+struct FieldDesc { const char* name; size_t off; int kind; int lev; int io; };   // kind 0 float*, 1 int*
+// lev: 0 2-D, 1 atm, 2 soil, 3 snow, 4 snso ; io: 0 in, 1 inout, 2 out
+#define FD(n, kind, lev, io) {#n, offsetof(noahmp_step_args, n), kind, lev, io}
+const FieldDesc kFields[] = {
+#include "nmp_fields.inc"
+};
+constexpr int kNumFields = sizeof(kFields) / sizeof(kFields[0]);
+
+struct Engine {
+  int device = -1;
+  bool have_tables = false;
+  noahmp_tables* d_tables = nullptr;
+  unsigned long long* d_err = nullptr;
+  int* d_counts = nullptr;
+  unsigned long long* h_err = nullptr;   // pinned
+  int* h_counts = nullptr;               // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t own_stream = nullptr;
+  // host-mode mirrors
+  std::vector<void*> mirror = std::vector<void*>(kNumFields, nullptr);
+  std::vector<size_t> mirror_bytes = std::vector<size_t>(kNumFields, 0);
+  int block = 64;
+  int use_lds = 1;
+  std::string last_error;
+};
+Engine g;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  g.last_error = b_; return -100; } } while (0)
+
+int ensure_init() {
+  if (g.d_err) return 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    g.last_error = "no HIP device visible: the Noah-MP HIP engine has no CPU fallback";
+    return -101;
+  }
+  if (g.device < 0) { HIPCHK(hipGetDevice(&g.device)); }
+  HIPCHK(hipMalloc(&g.d_err, sizeof(unsigned long long)));
+  HIPCHK(hipMalloc(&g.d_counts, 4 * sizeof(int)));
+  HIPCHK(hipHostMalloc((void**)&g.h_err, sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&g.h_counts, 4 * sizeof(int), hipHostMallocDefault));
+  HIPCHK(hipEventCreate(&g.ev0));
+  HIPCHK(hipEventCreate(&g.ev1));
+  HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
+  return 0;
+}
+
+size_t field_elems(const FieldDesc& f, const noahmp_step_args* a) {
+  size_t ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1;
+  size_t nk = 1;
+  switch (f.lev) {
+    case 1: nk = a->kme - a->kms + 1; break;
+    case 2: nk = a->nsoil; break;
+    case 3: nk = 3; break;
+    case 4: nk = a->nsoil + 3; break;
+  }
+  return ni * nk * nj;
+}
+
+template <int BLOCK>
+void launch(const KArgs& k, long ncol, bool lds, hipStream_t st) {
+  dim3 grid((unsigned)((ncol + BLOCK - 1) / BLOCK)), block(BLOCK);
+  if (lds) hipLaunchKernelGGL((noahmp_column_kernel<BLOCK, true>), grid, block, 0, st, k);
+  else hipLaunchKernelGGL((noahmp_column_kernel<BLOCK, false>), grid, block, 0, st, k);
+}
+
+}  // namespace
+
+extern "C" {
+
+int noahmp_hip_abi_version(void) { return NOAHMP_HIP_ABI_VERSION; }
+size_t noahmp_hip_sizeof_step_args(void) { return sizeof(noahmp_step_args); }
+size_t noahmp_hip_sizeof_tables(void) { return sizeof(noahmp_tables); }
+
+int noahmp_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int noahmp_hip_set_device(int device) {
+  HIPCHK(hipSetDevice(device));
+  g.device = device;
+  return 0;
+}
+
+int noahmp_hip_set_tables(const noahmp_tables* t) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!g.d_tables) HIPCHK(hipMalloc(&g.d_tables, sizeof(noahmp_tables)));
+  HIPCHK(hipMemcpy(g.d_tables, t, sizeof(noahmp_tables), hipMemcpyHostToDevice));
+  g.have_tables = true;
+  return 0;
+}
+
+int noahmp_hip_set_option(const char* key, int value) {
+  int prev = -1;
+  if (!strcmp(key, "block")) { prev = g.block; if (value == 64 || value == 128 || value == 256) g.block = value; }
+  else if (!strcmp(key, "lds")) { prev = g.use_lds; g.use_lds = value ? 1 : 0; }
+  return prev;
+}
+
+int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
+  if (st) memset(st, 0, sizeof(*st));
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!g.have_tables) { g.last_error = "noahmp_hip_set_tables() has not been called"; return -102; }
+  if (a->nsoil != NOAHMP_NSOIL) { if (st) st->code = NOAHMP_ERR_NSOIL_UNSUPPORTED; return NOAHMP_ERR_NSOIL_UNSUPPORTED; }
+  if (a->iopt_sfc != 1 && a->iopt_sfc != 2) {
+    if (st) st->code = NOAHMP_ERR_OPT_SFC_UNSUPPORTED;
+    return NOAHMP_ERR_OPT_SFC_UNSUPPORTED;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+
+  KArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.ni = a->ime - a->ims + 1;
+  k.nka = a->kme - a->kms + 1;
+  k.nti = a->ite - a->its + 1;
+  k.ntj = a->jte - a->jts + 1;
+  k.k1 = 1 - a->kms;
+  k.kp_lo = a->kts - a->kms;
+  k.kp_hi = a->kts + 1 - a->kms;
+  k.yearlen = 365;                                                                 // drv:381-390
+  if (a->yr % 4 == 0) { k.yearlen = 366; if (a->yr % 100 == 0) { k.yearlen = 365; if (a->yr % 400 == 0) k.yearlen = 366; } }
+  k.c.T = g.d_tables;
+  k.c.O = Opt{a->idveg, a->iopt_crs, a->iopt_btr, a->iopt_run, a->iopt_sfc, a->iopt_frz, a->iopt_inf,
+              a->iopt_rad, a->iopt_alb, a->iopt_snf, a->iopt_tbot, a->iopt_stc};
+  k.c.dt = a->dt;
+  k.c.isurban = a->isurban;
+  k.c.zsoil[L(1)] = -a->dzs[0];                                                    // drv:392-395
+  for (int l = 2; l <= NOAHMP_NSOIL; l++) k.c.zsoil[L(l)] = -a->dzs[l - 1] + k.c.zsoil[L(l - 1)];
+  k.err = g.d_err;
+  k.counts = g.d_counts;
+  k.a.dzs = nullptr;
+
+  if (mem == NOAHMP_MEM_HOST) {
+    // stage every array H2D into persistent device mirrors (caller's arrays stay the source of truth)
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      size_t bytes = field_elems(fd, a) * 4;
+      if (g.mirror_bytes[f] < bytes) {
+        if (g.mirror[f]) HIPCHK(hipFree(g.mirror[f]));
+        HIPCHK(hipMalloc(&g.mirror[f], bytes));
+        g.mirror_bytes[f] = bytes;
+      }
+      void* host = *(void* const*)((const char*)a + fd.off);
+      if (fd.io != 2) HIPCHK(hipMemcpyAsync(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      else HIPCHK(hipMemsetAsync(g.mirror[f], 0, bytes, s));
+      *(void**)((char*)&k.a + fd.off) = g.mirror[f];
+    }
+  }
+
+  *g.h_err = ~0ULL;
+  HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(g.d_counts, 0, 4 * sizeof(int), s));
+  const long ncol = (long)k.nti * k.ntj;
+  HIPCHK(hipEventRecord(g.ev0, s));
+  if (ncol > 0) {
+    if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
+    else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
+    else launch<64>(k, ncol, g.use_lds, s);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+
+  if (mem == NOAHMP_MEM_HOST) {
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      if (fd.io == 0) continue;
+      void* host = *(void* const*)((const char*)a + fd.off);
+      HIPCHK(hipMemcpyAsync(host, g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, g.ev0, g.ev1);
+  int code = 0;
+  if (st) {
+    st->kernel_ms = ms;
+    st->n_land = g.h_counts[0]; st->n_glacier = g.h_counts[1]; st->n_skipped = g.h_counts[2];
+  }
+  if (*g.h_err != ~0ULL) {
+    code = (int)(*g.h_err & 0xFF);
+    long t = (long)(*g.h_err >> 8) - 1;
+    if (st) { st->code = code; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
+  }
+  return code;
+}
+
+const char* noahmp_hip_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case NOAHMP_ERR_SOILTYP_RANGE: return "REDPRM: too many input soil types (lsm:9266)";
+    case NOAHMP_ERR_VEGTYP_RANGE: return "REDPRM: too many input landuse types (lsm:9272)";
+    case NOAHMP_ERR_NROOT_GT_NSOIL: return "REDPRM: too many root layers (lsm:9340)";
+    case NOAHMP_ERR_DVEG_UNKNOWN: return "Namelist parameter DVEG unknown (lsm:842)";
+    case NOAHMP_ERR_SW_BALANCE: return "Stop in Noah-MP: ERRSW (lsm:1185)";
+    case NOAHMP_ERR_ENERGY_BALANCE: return "Energy budget problem in NOAHMP LSM (lsm:1196)";
+    case NOAHMP_ERR_WATER_BALANCE: return "Water budget problem in NOAHMP LSM (lsm:1221)";
+    case NOAHMP_ERR_FIRE_NONPOSITIVE: return "STOP in Noah-MP: emitted longwave <0 (lsm:1786)";
+    case NOAHMP_ERR_HCAN_LE_ZPD: return "CRITICAL PROBLEM: HCAN <= ZPD (lsm:3289)";
+    case NOAHMP_ERR_STABILITY_STOP: return "STOP in Noah-MP: ZLVL <= ZPD (lsm:4124)";
+    case NOAHMP_ERR_OPT_SFC_UNSUPPORTED: return "OPT_SFC 3/4 unsupported: MYJ/YSU tables are never initialised offline";
+    case NOAHMP_ERR_GLACIER_SW_BALANCE: return "glacier: ERRSW (gla:2939)";
+    case NOAHMP_ERR_GLACIER_ENERGY_BALANCE: return "glacier: energy budget (gla:2948)";
+    case NOAHMP_ERR_GLACIER_WATER_BALANCE: return "glacier: water budget (gla:2968)";
+    case NOAHMP_ERR_GLACIER_FIRE_NONPOSITIVE: return "glacier: emitted longwave <0 (gla:541)";
+    case NOAHMP_ERR_NSOIL_UNSUPPORTED: return "engine is compiled for NSOIL=4, NSNOW=3";
+  }
+  return "unknown";
+}
+
+const char* noahmp_hip_last_error(void) { return g.last_error.c_str(); }
+
+void noahmp_hip_finalize(void) {
+  for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
+  for (auto& b : g.mirror_bytes) b = 0;
+  if (g.d_tables) hipFree(g.d_tables);
+  if (g.d_err) hipFree(g.d_err);
+  if (g.d_counts) hipFree(g.d_counts);
+  if (g.h_err) hipHostFree(g.h_err);
+  if (g.h_counts) hipHostFree(g.h_counts);
+  if (g.ev0) hipEventDestroy(g.ev0);
+  if (g.ev1) hipEventDestroy(g.ev1);
+  if (g.own_stream) hipStreamDestroy(g.own_stream);
+  g = Engine();
+}
+
+}  // extern "C"

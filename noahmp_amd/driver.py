@@ -1,0 +1,54 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+``noahmplsm(store, itimestep, yr, julian)`` has the meaning of
+``module_sf_noahmpdrv :: noahmplsm`` (reference drv:11): one call advances every land column
+of the tile by one timestep.  It packs the caller's arrays into the C-ABI block and calls the
+HIP engine -- nothing else.  A fatal column raises :class:`NoahMPFatal` (the reference STOPs via
+wrf_error_fatal, util/module_wrf_utilities.F:12-24).
+"""
+import ctypes as C
+
+from . import abi
+from .state import DeviceColumnStore
+
+
+class NoahMPFatal(RuntimeError):
+    def __init__(self, code, i, j, msg):
+        super().__init__("Noah-MP fatal %d (%s) at I=%d J=%d: %s" % (code, abi.error_name(code), i, j, msg))
+        self.code, self.i, self.j = code, i, j
+
+
+class Engine:
+    """Thin handle on libnoahmp_hip.so (one per process == one per GPU/MPI rank)."""
+
+    def __init__(self, tables, device=None, lib_path=None):
+        self.lib = abi.load_library(lib_path)
+        if self.lib.noahmp_hip_device_count() < 1:
+            raise RuntimeError("Noah-MP HIP engine: no GPU visible and there is no CPU fallback")
+        if device is not None:
+            rc = self.lib.noahmp_hip_set_device(int(device))
+            if rc:
+                raise RuntimeError(self.lib.noahmp_hip_last_error().decode())
+        self.tables = tables
+        rc = self.lib.noahmp_hip_set_tables(C.byref(tables))
+        if rc:
+            raise RuntimeError("noahmp_hip_set_tables: " + self.lib.noahmp_hip_last_error().decode())
+        self.last_status = abi.Status()
+
+    def set_option(self, key, value):
+        return self.lib.noahmp_hip_set_option(key.encode(), int(value))
+
+    def noahmplsm(self, store, itimestep, yr, julian, stream=None, check=True):
+        a = store.step_args(itimestep, yr, julian)
+        mem = abi.MEM_DEVICE if isinstance(store, DeviceColumnStore) else abi.MEM_HOST
+        st = abi.Status()
+        rc = self.lib.noahmp_hip_step(C.byref(a), mem, stream, C.byref(st))
+        self.last_status = st
+        if rc < 0:
+            raise RuntimeError("noahmp_hip_step: " + self.lib.noahmp_hip_last_error().decode())
+        if rc > 0 and check:
+            raise NoahMPFatal(rc, st.i, st.j, self.lib.noahmp_hip_error_string(rc).decode())
+        return st
+
+    def finalize(self):
+        self.lib.noahmp_hip_finalize()

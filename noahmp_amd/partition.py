@@ -1,0 +1,44 @@
+"""Tile decomposition: one MPI rank (here: one process) per GPU, the reference's block rule.
+
+Mirrors mpp/module_mpp_land.F90: ``mpp_land_get_nprocsxy`` (:124-141, most-square factorisation,
+first best wins) and ``mpp_land_partition_calc`` (:227-288: base = n/np, the first mod(n,np) ranks
+along each axis get one extra cell, contiguous blocks, rank = iprocy*nprocx + iprocx).
+Columns are independent for every option except opt_run=5, so no data-path collective exists;
+the only exchange the physics can need is the 1-cell ZWTXY ring of LATERALFLOW.
+"""
+
+
+def nprocs_xy(nproc):
+    best = nproc
+    nx, ny = nproc, 1
+    for j in range(1, nproc + 1):
+        if nproc % j == 0:
+            i = nproc // j
+            if abs(i - j) < best:
+                best = abs(i - j)
+                nx, ny = i, j
+    return nx, ny
+
+
+def partition(global_nx, global_ny, nproc):
+    """-> list over ranks of dict(startx, starty, nx, ny) with 1-based Fortran starts."""
+    npx, npy = nprocs_xy(nproc)
+    base_nx, base_ny = global_nx // npx, global_ny // npy
+    out = []
+    for rank in range(nproc):
+        ipx, ipy = rank % npx, rank // npx
+        nx = base_nx + 1 if ipx <= (global_nx % npx) - 1 else base_nx
+        ny = base_ny + 1 if ipy <= (global_ny % npy) - 1 else base_ny
+        out.append(dict(nx=nx, ny=ny, ipx=ipx, ipy=ipy))
+    for r in out:
+        r["startx"] = 1 + sum(o["nx"] for o in out if o["ipy"] == 0 and o["ipx"] < r["ipx"])
+        r["starty"] = 1 + sum(o["ny"] for o in out if o["ipx"] == 0 and o["ipy"] < r["ipy"])
+    return out
+
+
+def neighbours(rank, nproc):
+    """left/right/down/up rank ids (or -1), mpp:93-107."""
+    npx, npy = nprocs_xy(nproc)
+    ipx, ipy = rank % npx, rank // npx
+    return dict(left=rank - 1 if ipx > 0 else -1, right=rank + 1 if ipx < npx - 1 else -1,
+                down=rank - npx if ipy > 0 else -1, up=rank + npx if ipy < npy - 1 else -1)

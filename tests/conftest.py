@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tables():
+    from noahmp_amd.tables import load_tables
+    return load_tables("usgs")          # (ctypes struct, dict)
+
+
+@pytest.fixture(scope="session")
+def port(tables):
+    """The C restatement (oracle/_build), built on demand with gcc."""
+    from oracle.portlib import PortLib
+    p = PortLib(autobuild=True)
+    p.set_tables(tables[0])
+    return p
+
+
+@pytest.fixture(scope="session")
+def reflib():
+    """The compiled reference (oracle/_ref); present only where `make -C oracle ref` has run."""
+    from oracle import reflib as r
+    if not r.available("O0"):
+        pytest.skip("oracle/_ref/libnoahmp_ref.so not built (needs /root/reference)")
+    return r.RefLib("O0")
+
+
+@pytest.fixture(scope="session")
+def engine(tables):
+    from noahmp_amd.driver import Engine
+    return Engine(tables[0], device=0)
+
+
+def load_store(npz, prefix, ni, nj, cfg=None):
+    """Rebuild a ColumnStore from a golden npz group."""
+    from noahmp_amd.state import ColumnStore, ModelConfig
+    s = ColumnStore(ni, nj, cfg or ModelConfig())
+    for k in s.a:
+        key = "%s/%s" % (prefix, k)
+        if key in npz:
+            s.a[k][...] = npz[key]
+    return s

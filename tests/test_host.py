@@ -1,0 +1,127 @@
+"""CPU tests of the host side: ABI layout, exported symbols, cold-start init, partition rule."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from noahmp_amd import abi, synth
+from noahmp_amd.abi_spec import STEP_FIELDS, TABLE_FIELDS
+from noahmp_amd.state import ColumnStore, ModelConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_is_in_sync_with_spec():
+    """include/noahmp_hip.h is generated from abi_spec.py; every field appears in order."""
+    txt = open(os.path.join(ROOT, "include", "noahmp_hip.h")).read()
+    pos = -1
+    body = txt[txt.index("typedef struct noahmp_step_args"):txt.index("} noahmp_step_args;")]
+    for n, k, lev, io, ln in STEP_FIELDS:
+        p = body.find(" %s;" % n)
+        assert p > pos, n
+        pos = p
+    body = txt[txt.index("typedef struct noahmp_tables"):txt.index("} noahmp_tables;")]
+    for n, k, s, src in TABLE_FIELDS:
+        assert (" %s;" % n in body) or (" %s[" % n in body), n
+
+
+def test_ctypes_layout_matches_compiled_header(tmp_path):
+    """sizeof/offsetof of the ctypes mirrors == what gcc makes of the C header."""
+    src = tmp_path / "sz.c"
+    probes = ["coszin", "dzs", "isnowxy", "chb2xy", "kte"]
+    tprobes = ["saim", "nrotbl", "albsat", "eg"]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "noahmp_hip.h"\nint main(){'
+                   'printf("%zu %zu", sizeof(noahmp_step_args), sizeof(noahmp_tables));'
+                   + "".join('printf(" %%zu", offsetof(noahmp_step_args,%s));' % p for p in probes)
+                   + "".join('printf(" %%zu", offsetof(noahmp_tables,%s));' % p for p in tprobes)
+                   + 'return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(abi.StepArgs) and out[1] == C.sizeof(abi.Tables)
+    for p, o in zip(probes, out[2:]):
+        assert getattr(abi.StepArgs, p).offset == o, p
+    for p, o in zip(tprobes, out[2 + len(probes):]):
+        assert getattr(abi.Tables, p).offset == o, p
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every entry point of include/noahmp_hip.h (no compute)."""
+    if not os.path.exists(abi.LIB_PATH):
+        from noahmp_amd import build
+        build.build()
+    hdr = open(os.path.join(ROOT, "include", "noahmp_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\b(noahmp_hip_\w+)\s*\(", hdr))
+    assert declared == set(abi.EXPORTED_SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", abi.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported, declared - exported
+    lib = abi.load_library()
+    assert lib.noahmp_hip_abi_version() == 1
+    assert lib.noahmp_hip_sizeof_step_args() == C.sizeof(abi.StepArgs)
+    assert lib.noahmp_hip_error_string(7).decode().startswith("Water budget")
+
+
+def test_engine_fails_loudly_without_gpu(tables):
+    """No CPU fallback: without a device the engine refuses to run."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from noahmp_amd.driver import Engine
+    with pytest.raises(RuntimeError):
+        Engine(tables[0])
+
+
+def test_tables_roundtrip(tables):
+    T, d = tables
+    d2 = abi.tables_to_dict(T)
+    for k, v in d.items():
+        np.testing.assert_array_equal(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else None),
+                                      np.asarray(d2[k]))
+    assert d["laim"].shape == (27, 12) and d["nrotbl"].shape == (50,)
+    assert T.laim[6][6] == d["laim"][6, 6]          # Fortran LAIM(7,7) == C laim[6][6]
+
+
+def test_cold_start_matches_reference_init(reflib, tables):
+    """noahmp_amd.init (NOAHMP_INIT + SNOW_INIT mirror) vs the reference's own NOAHMP_INIT."""
+    import noahmp_amd.init as ini
+    captured = []
+    orig = ini.noahmp_init
+
+    def spy(store, tb, fndsnowh=True):
+        captured.append(store.copy())
+        return orig(store, tb, fndsnowh)
+    synth.noahmp_init = spy
+    try:
+        mine = synth.mixed_small(tables[1], ni=64, nj=8, seed=5)
+    finally:
+        synth.noahmp_init = orig
+    theirs = captured[0]
+    reflib.noahmp_init(theirs)
+    for k in mine.a:
+        if k == "sh2o":     # powf differs by <= 1 ulp between numpy and the Fortran runtime
+            np.testing.assert_allclose(mine.a[k], theirs.a[k], rtol=3e-7, atol=0)
+        else:
+            np.testing.assert_array_equal(mine.a[k], theirs.a[k], err_msg=k)
+    assert set(np.unique(mine["isnowxy"])) == {0, -1, -2, -3}
+
+
+def test_synth_is_seeded(tables):
+    a = synth.mixed_small(tables[1], ni=16, nj=2, seed=3)
+    b = synth.mixed_small(tables[1], ni=16, nj=2, seed=3)
+    for k in a.a:
+        np.testing.assert_array_equal(a.a[k], b.a[k])
+
+
+def test_store_layout_is_fortran_image():
+    s = ColumnStore(5, 3, ModelConfig())
+    assert s["tslb"].shape == (3, 4, 5) and s["zsnsoxy"].shape == (3, 7, 5) and s["tsk"].shape == (3, 5)
+    a = s.step_args(1, 2000, 1.0)
+    assert a.ime - a.ims + 1 == 5 and a.jme - a.jms + 1 == 3 and a.kme == 2
+    # element (i=2,k=3,j=1) (Fortran, 1-based) sits at ((j-1)*nk + (k-1))*ni + (i-1)
+    s["tslb"][0, 2, 1] = 42.0
+    flat = s["tslb"].ravel()
+    assert flat[((1 - 1) * 4 + (3 - 1)) * 5 + (2 - 1)] == 42.0

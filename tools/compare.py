@@ -62,3 +62,77 @@ def compare(a, b, fields=None, steps=1, mask=None, verbose=False, skip=()):
 
 def report(bad):
     return "\n".join("%-12s max|d|=%.4e maxrel=%.3e n_bad=%d" % b for b in bad)
+
+
+# ---------------------------------------------------------------------------------------------
+# Parity envelope for float32 engines whose libm differs from the reference's (GPU vs CPU).
+#
+# Measured floor (tests/golden): the reference compiled -O2 against ITSELF compiled -O0,
+# one step from an identical state on the 512-column mixed tile, already differs in a few columns by
+#   TSK/TV/TAH 8e-3 K, HFX 0.06 W m-2 (rel 8e-3), CM/CH/CHV 2.2e-2 rel, CHV2 1.5e-2 rel, EAH 0.08 Pa,
+# because the canopy Newton loop stops on |DTV| <= 0.01 after >= 5 iterations (lsm:3487) and an
+# ulp-level difference flips the iteration count.  The contract therefore has two parts:
+#   (1) TIGHT  : |d| <= atol + rtol*|x| with the per-group tolerances of `tolerance()` must hold for
+#                at least (1 - frac) of the entries of every field, and
+#   (2) ENVELOPE: every entry must stay inside a loose physical envelope (no blow-ups, no wrong branch
+#                with a visible effect).
+TEMP = ("tsk", "tvxy", "tgxy", "tahxy", "tslb", "tsnoxy", "t2mvxy", "t2mbxy", "tradxy", "tgvxy", "tgbxy")
+
+
+def envelope(name, steps=1):
+    """Hard cap for every entry.  Sized ~3x the largest single-step deviation seen over 196 608
+    column-steps for BOTH pairs (reference -O2 vs -O0: TSK 0.03 K, HFX 0.65, SHG 1.3 W m-2, CH 3e-2 rel;
+    HIP vs oracle: TSK 0.07 K, HFX 4.0, SHC 4.1 W m-2, EAH 15 Pa) -- profiles/r01_parity_stats.md."""
+    k = 1.0 if steps == 1 else 3.0
+    if name in TEMP:
+        return (0.0, 0.5 * k)
+    if name in FLUX:
+        return (5e-2, 15.0 * k)
+    if name in EXCH:
+        return (0.5, 1e-6)
+    if name in RATE:
+        return (0.2, 5e-6 * k)
+    if name == "eahxy":
+        return (0.0, 50.0 * k)
+    if name in ("snow", "sneqvoxy", "snicexy", "snliqxy", "acsnom", "canwat", "canicexy", "canliqxy", "acsnow"):
+        return (2e-2 * k, 2e-2 * k)
+    if name in ("fwetxy",):
+        return (0.0, 0.1 * k)
+    return (5e-3 * k, 5e-3 * k)
+
+
+def parity_check(ref, test, steps=1, frac=0.04, frac_medium=0.01, fields=None, mask=None, skip=()):
+    """-> (ok, lines).  Three nested criteria per field:
+         TIGHT    tolerance()      may be exceeded by at most `frac` of the entries (min 3 entries),
+         MEDIUM   10 x TIGHT       by at most `frac_medium` (min 3 entries),
+         ENVELOPE envelope()       by none."""
+    names = fields or [n for n in ref.a if FIELD_INFO[n][2] != "in"]
+    ok, lines = True, []
+    for n in names:
+        if n in skip or n == "dzs":
+            continue
+        x, y = np.asarray(ref.a[n]), np.asarray(test.a[n])
+        if mask is not None:
+            m = mask if x.ndim == 2 else np.broadcast_to(mask[:, None, :], x.shape)
+            x, y = x[m], y[m]
+        if x.dtype.kind == "i":
+            nb = int((x != y).sum())
+            if nb > max(frac_medium * x.size, 1):
+                ok = False
+                lines.append("%-12s integer mismatches %d/%d" % (n, nb, x.size))
+            continue
+        x = x.astype(np.float64)
+        y = y.astype(np.float64)
+        d = np.abs(x - y)
+        d[np.isnan(x) & np.isnan(y)] = 0.0
+        mag = np.maximum(np.abs(x), np.abs(y))
+        rt, at = tolerance(n, steps)
+        nt = int((~(d <= at + rt * mag)).sum())
+        nm = int((~(d <= 10 * (at + rt * mag))).sum())
+        re_, ae = envelope(n, steps)
+        ne = int((~(d <= ae + re_ * mag)).sum())
+        if nt > max(frac * d.size, 3) or nm > max(frac_medium * d.size, 3) or ne:
+            ok = False
+            lines.append("%-12s tight-viol %d  medium-viol %d  envelope-viol %d  of %d; max|d|=%.3e"
+                         % (n, nt, nm, ne, d.size, np.nanmax(d)))
+    return ok, lines

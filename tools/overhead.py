@@ -1,0 +1,21 @@
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from noahmp_amd import synth
+from noahmp_amd.driver import Engine
+from noahmp_amd.tables import load_tables
+import torch
+T, tb = load_tables("usgs")
+eng = Engine(T, device=0)
+for ni, nj in ((8, 1), (1024, 64), (1024, 1024)):
+    s = synth.config2(tb, ni=ni, nj=nj)
+    synth.first_step_fixups(s); synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+    d = s.to_device("cuda:0")
+    for it in range(3): eng.noahmplsm(d, it + 1, 2000, 180.0)
+    torch.cuda.synchronize()
+    t = time.perf_counter(); km = 0
+    n = 50
+    for it in range(n):
+        st = eng.noahmplsm(d, it + 4, 2000, 180.0); km += st.kernel_ms
+    torch.cuda.synchronize()
+    w = (time.perf_counter() - t) / n * 1e3
+    print("tile %dx%d: wall %.3f ms/step, kernel %.3f ms, overhead %.3f ms" % (ni, nj, w, km / n, w - km / n))
