@@ -6,8 +6,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libnoahmp_hip.so")
 SOURCES = ["noahmp_engine.hip"]
-HEADERS = ["nmp_dev_common.hpp", "nmp_dev_energy.hpp", "nmp_dev_water.hpp", "nmp_dev_sflx.hpp",
-           "nmp_dev_glacier.hpp", "nmp_fields.inc", "../../include/noahmp_hip.h"]
+def _headers():
+    return [f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + ["../../include/noahmp_hip.h"]
 # -ffp-contract=off: keep the reference's a*b+c rounding (no FMA contraction); no fast-math.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
          "-Wno-unused-value", "-I" + os.path.join(_HERE, "..", "include")]
@@ -17,7 +17,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + _headers())
 
 
 def build(force=False, verbose=False):

@@ -1,0 +1,202 @@
+// Noah-MP column engine for MI355X -- one column-step: the ILOOP body of noahmplsm (drv:424-837).
+// Shared by the GPU kernel (noahmp_engine.hip) and by the host-compiled emulation used only by
+// tests/ (tests/host_emul) to debug the device source without a GPU.
+#pragma once
+#include <string.h>
+#include "nmp_dev_sflx.hpp"
+#include "nmp_dev_glacier.hpp"
+
+namespace nmp {
+
+struct KArgs {
+  noahmp_step_args a;     // array members hold DEVICE pointers here
+  Ctx c;
+  int ni, nka;            // memory extents: ni = ime-ims+1, nka = kme-kms+1
+  int nti, ntj;           // tile extents
+  int k1;                 // 0-based slot of atmospheric level 1 inside (kms:kme)
+  int kp_lo, kp_hi;       // slots of P8W3D(kts), P8W3D(kts+1)
+  int yearlen;
+  unsigned long long* err;   // min over columns of ((linear index + 1) << 8 | code)
+  int* counts;               // [0]=land [1]=glacier [2]=skipped
+};
+
+constexpr int LAY_SLOTS = 4 * 7 + 5 * 4 + 3 * 3;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold
+
+template <int STRIDE>
+NMP_DEV Lay<LArr<STRIDE>> make_lay(float* base) {
+  Lay<LArr<STRIDE>> y;
+  int o = 0;
+  y.stc.p = base + o * STRIDE; o += 7;
+  y.zsnso.p = base + o * STRIDE; o += 7;
+  y.dzsnso.p = base + o * STRIDE; o += 7;
+  y.imelt.p = base + o * STRIDE; o += 7;
+  // soil-only arrays keep slots L(1)..L(4): bias the base pointer by -L(1) slots
+  y.smc.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.sh2o.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.sice.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.smceq.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.btrani.p = base + (o - L(1)) * STRIDE; o += 4;
+  y.snice.p = base + o * STRIDE; o += 3;
+  y.snliq.p = base + o * STRIDE; o += 3;
+  y.ficeold.p = base + o * STRIDE; o += 3;
+  return y;
+}
+
+#define G2(f) k.a.f[ij]
+#define G3(f, lev, nk) k.a.f[((size_t)jj * (nk) + (lev)) * k.ni + ii]
+
+
+// Classify column t and apply the water / sea-ice shortcuts (drv:399-441).
+// returns 0 land, 1 glacier, 2 skipped, 3 outside the tile
+NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij) {
+  if (t >= (long)k.nti * k.ntj) return 3;
+  const int tj = (int)(t / k.nti), ti = (int)(t - (long)tj * k.nti);
+  ii = k.a.its - k.a.ims + ti;
+  jj = k.a.jts - k.a.jms + tj;
+  ij = (size_t)jj * k.ni + ii;
+  const float xland = G2(xland), xice = G2(xice);
+  const int ivg = G2(ivgtyp);
+  int ice = (xice >= k.a.xice_thres) ? 1 : ((ivg == k.a.isice) ? -1 : 0);      // drv:426-432
+  const bool water = (xland - 1.5f) >= 0.f;
+  if (k.a.itimestep == 1) {                                                      // drv:399-419
+    if (water) {
+      G2(smstav) = 1.0f; G2(smstot) = 1.0f;
+      for (int l = 0; l < NSOIL; l++) { G3(smois, l, NSOIL) = 1.0f; G3(tslb, l, NSOIL) = 273.16f; }
+    } else if (xice == 1.f) {
+      G2(smstav) = 1.0f; G2(smstot) = 1.0f;
+      for (int l = 0; l < NSOIL; l++) G3(smois, l, NSOIL) = 1.0f;
+    }
+  }
+  if (water) return 2;
+  if (ice == 1) {                                                                // drv:436-441
+    for (int l = 0; l < NSOIL; l++) G3(sh2o, l, NSOIL) = 1.0f;
+    G2(xlaixy) = 0.01f;
+    return 2;
+  }
+  return (ice == -1) ? 1 : 0;
+}
+
+// Gather -> REDPRM -> NOAHMP_SFLX | NOAHMP_GLACIER -> scatter for one land / glacier column.
+// returns the column's status word (0 = ok); a failing column is left untouched (the reference STOPs).
+template <int STRIDE>
+NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base) {
+  Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
+  // value-initialise (NOT memset(): HIP's device memset is a byte loop through a pointer PHI, which
+  // pins the whole struct in scratch and defeats scalar replacement -- 556 B/lane of scratch traffic)
+  Col s = {};
+  // ---- gather, drv:449-545
+  s.cosz = G2(coszin); s.lat = G2(xlatin);
+  s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
+  int vegtyp = G2(ivgtyp), soiltyp = G2(isltyp);
+  s.shdfac = G2(vegfra) / 100.f;
+  s.shdmax = G2(vegmax) / 100.f;
+  s.tbot = G2(tmn);
+  s.sfctmp = G3(t3d, k.k1, k.nka);
+  { float qv = G3(qv3d, k.k1, k.nka); s.q2 = qv / (1.0f + qv); }
+  s.uu = G3(u_phy, k.k1, k.nka); s.vv = G3(v_phy, k.k1, k.nka);
+  s.soldn = G2(swdown); s.lwdn = G2(glw);
+  s.sfcprs = (G3(p8w3d, k.kp_hi, k.nka) + G3(p8w3d, k.kp_lo, k.nka)) * 0.5f;
+  s.psfc = G3(p8w3d, k.k1, k.nka);
+  s.prcp = G2(rainbl) / k.a.dt;
+  s.isnow = G2(isnowxy);
+#pragma unroll
+  for (int l = 1; l <= NSOIL; l++) {
+    y.smc[L(l)] = G3(smois, l - 1, NSOIL); y.sh2o[L(l)] = G3(sh2o, l - 1, NSOIL);
+    y.stc[L(l)] = G3(tslb, l - 1, NSOIL); y.smceq[L(l)] = G3(smoiseq, l - 1, NSOIL);
+    y.sice[L(l)] = 0.f; y.btrani[L(l)] = 0.f;
+  }
+#pragma unroll
+  for (int l = -2; l <= 0; l++) {
+    float si = G3(snicexy, l + 2, 3), sl = G3(snliqxy, l + 2, 3);
+    y.stc[L(l)] = G3(tsnoxy, l + 2, 3); y.snice[L(l)] = si; y.snliq[L(l)] = sl;
+    y.ficeold[L(l)] = (l > s.isnow) ? si / (si + sl) : 0.f;                        // drv:516-518
+  }
+#pragma unroll
+  for (int l = -2; l <= NSOIL; l++) {
+    y.zsnso[L(l)] = G3(zsnsoxy, l + 2, NSOIL + 3); y.dzsnso[L(l)] = 0.f; y.imelt[L(l)] = 0.f;
+  }
+  s.sneqv = G2(snow); s.snowh = G2(snowh); s.qsfc = G2(qsfc);
+  s.tv = G2(tvxy); s.tg = G2(tgxy); s.canliq = G2(canliqxy); s.canice = G2(canicexy);
+  s.eah = G2(eahxy); s.tah = G2(tahxy); s.cm = G2(cmxy); s.ch = G2(chxy); s.fwet = G2(fwetxy);
+  s.sneqvo = G2(sneqvoxy); s.albold = G2(alboldxy); s.qsnow = G2(qsnowxy);
+  s.wslake = G2(wslakexy); s.zwt = G2(zwtxy); s.wa = G2(waxy); s.wt = G2(wtxy);
+  s.lfmass = G2(lfmassxy); s.rtmass = G2(rtmassxy); s.stmass = G2(stmassxy); s.wood = G2(woodxy);
+  s.stblcp = G2(stblcpxy); s.fastcp = G2(fastcpxy); s.lai = G2(xlaixy); s.sai = G2(xsaixy);
+  s.tauss = G2(taussxy); s.smcwtd = G2(smcwtdxy);
+  s.rech = 0.f; s.deeprech = 0.f;
+  s.co2air = 395.e-06f * s.sfcprs;
+  s.o2air = 0.209f * s.sfcprs;
+  s.foln = 1.0f;
+  s.ist = 1; s.isc = 4; s.ice = (cls == 1) ? -1 : 0;
+  s.yearlen = k.yearlen; s.julian = k.a.julian;
+  if (soiltyp == 14 && G2(xice) == 0.f) soiltyp = 7;
+  if (vegtyp == k.a.isurban || vegtyp == 31 || vegtyp == 32 || vegtyp == 33) vegtyp = k.a.isurban;
+  if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }
+  Parm P;
+  redprm(k.c, s, P, vegtyp, soiltyp);
+  s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
+
+  float qfx_out, lh_out;
+  if (cls == 1) {
+    s.tbot = fminf(s.tbot, 263.15f);                                               // drv:555
+    glacier(k.c, s, y);
+    glacier_fill_undefined(s);                                                     // drv:571-625
+    qfx_out = s.edir; lh_out = s.fgev;                                             // drv:627-628
+  } else {
+    sflx(k.c, P, s, y);
+    qfx_out = s.ecan + s.edir + s.etran;                                           // drv:713-714
+    lh_out = s.fcev + s.fgev + s.fctr;
+  }
+
+  if (s.err) return s.err;
+  // ---- scatter, drv:728-835
+  G2(qfx) = qfx_out; G2(lh) = lh_out;
+  G2(tsk) = s.trad; G2(hfx) = s.fsh; G2(grdflx) = s.ssoil;
+  G2(smstav) = 0.0f; G2(smstot) = 0.0f;
+  G2(sfcrunoff) = G2(sfcrunoff) + s.runsrf * k.a.dt;
+  G2(udrunoff) = G2(udrunoff) + s.runsub * k.a.dt;
+  if (s.albedo > -999) G2(albedo) = s.albedo;
+  G2(snowc) = s.fsno;
+#pragma unroll
+  for (int l = 1; l <= NSOIL; l++) {
+    G3(smois, l - 1, NSOIL) = y.smc[L(l)]; G3(sh2o, l - 1, NSOIL) = y.sh2o[L(l)];
+    G3(tslb, l - 1, NSOIL) = y.stc[L(l)];
+  }
+  G2(snow) = s.sneqv; G2(snowh) = s.snowh;
+  G2(canwat) = s.canliq + s.canice;
+  G2(acsnow) = G2(acsnow) + s.prcp * s.fpice;                                      // no *DT (drv:751)
+  G2(acsnom) = G2(acsnom) + s.qsnbot * k.a.dt + s.ponding + s.ponding1 + s.ponding2;
+  G2(emiss) = s.emissi; G2(qsfc) = s.qsfc;
+  G2(isnowxy) = s.isnow; G2(tvxy) = s.tv; G2(tgxy) = s.tg; G2(canliqxy) = s.canliq;
+  G2(canicexy) = s.canice; G2(eahxy) = s.eah; G2(tahxy) = s.tah; G2(cmxy) = s.cm; G2(chxy) = s.ch;
+  G2(fwetxy) = s.fwet; G2(sneqvoxy) = s.sneqvo; G2(alboldxy) = s.albold; G2(qsnowxy) = s.qsnow;
+  G2(wslakexy) = s.wslake; G2(zwtxy) = s.zwt; G2(waxy) = s.wa; G2(wtxy) = s.wt;
+#pragma unroll
+  for (int l = -2; l <= 0; l++) {
+    G3(tsnoxy, l + 2, 3) = y.stc[L(l)]; G3(snicexy, l + 2, 3) = y.snice[L(l)];
+    G3(snliqxy, l + 2, 3) = y.snliq[L(l)];
+  }
+#pragma unroll
+  for (int l = -2; l <= NSOIL; l++) G3(zsnsoxy, l + 2, NSOIL + 3) = y.zsnso[L(l)];
+  G2(lfmassxy) = s.lfmass; G2(rtmassxy) = s.rtmass; G2(stmassxy) = s.stmass; G2(woodxy) = s.wood;
+  G2(stblcpxy) = s.stblcp; G2(fastcpxy) = s.fastcp; G2(xlaixy) = s.lai; G2(xsaixy) = s.sai;
+  G2(taussxy) = s.tauss;
+  G2(t2mvxy) = s.t2mv; G2(t2mbxy) = s.t2mb;
+  G2(q2mvxy) = s.q2v / (1.0f - s.q2v); G2(q2mbxy) = s.q2b / (1.0f - s.q2b);
+  G2(tradxy) = s.trad; G2(neexy) = s.nee; G2(gppxy) = s.gpp; G2(nppxy) = s.npp;
+  G2(fvegxy) = s.fveg; G2(runsfxy) = s.runsrf; G2(runsbxy) = s.runsub; G2(ecanxy) = s.ecan;
+  G2(edirxy) = s.edir; G2(etranxy) = s.etran; G2(fsaxy) = s.fsa; G2(firaxy) = s.fira;
+  G2(aparxy) = s.apar; G2(psnxy) = s.psn; G2(savxy) = s.sav; G2(sagxy) = s.sag;
+  G2(rssunxy) = s.rssun; G2(rsshaxy) = s.rssha; G2(bgapxy) = s.bgap; G2(wgapxy) = s.wgap;
+  G2(tgvxy) = s.tgv; G2(tgbxy) = s.tgb; G2(chvxy) = s.chv; G2(chbxy) = s.chb;
+  G2(ircxy) = s.irc; G2(irgxy) = s.irg; G2(shcxy) = s.shc; G2(shgxy) = s.shg; G2(evgxy) = s.evg;
+  G2(ghvxy) = s.ghv; G2(irbxy) = s.irb; G2(shbxy) = s.shb; G2(evbxy) = s.evb; G2(ghbxy) = s.ghb;
+  G2(trxy) = s.tr; G2(evcxy) = s.evc; G2(chleafxy) = s.chleaf; G2(chucxy) = s.chuc;
+  G2(chv2xy) = s.chv2; G2(chb2xy) = s.chb2;
+  G2(rechxy) = G2(rechxy) + s.rech * 1.E3f;
+  G2(deeprechxy) = G2(deeprechxy) + s.deeprech;
+  G2(smcwtdxy) = s.smcwtd;
+  return 0;
+}
+
+}  // namespace nmp

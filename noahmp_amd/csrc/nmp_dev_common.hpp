@@ -13,7 +13,8 @@
 
 namespace nmp {
 
-#define NMP_DEV __device__ __forceinline__
+// __host__ too: tests/host_emul compiles the same source for the CPU to debug it without a GPU
+#define NMP_DEV __host__ __device__ __forceinline__
 #define L(i) ((i) + 2)   // layer -2..4 -> slot 0..6
 constexpr int NL = 7;
 constexpr int NSOIL = NOAHMP_NSOIL;

@@ -78,16 +78,26 @@ NMP_DEV void phenology(const Ctx& c, Col& s) {
 
 // CARBON lsm:8723-8835 + CO2FLUX lsm:8837-9104 (DVEG 2 / 5 only)
 template <class A>
+NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y);
+
+template <class A>
 NMP_DEV void carbon(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
+  const noahmp_tables* T = c.T;
+  const bool novegc = (s.vegtyp == T->iswater) || (s.vegtyp == T->isbarren) || (s.vegtyp == T->issnow) ||
+                      (s.vegtyp == c.isurban);
+  if (novegc) {                                       // lsm:8792-8810
+    s.lai = 0.f; s.sai = 0.f; s.gpp = 0.f; s.npp = 0.f; s.nee = 0.f;
+    s.lfmass = 0.f; s.rtmass = 0.f; s.stmass = 0.f; s.wood = 0.f; s.stblcp = 0.f; s.fastcp = 0.f;
+  } else {
+    carbon_veg(c, P, s, y);
+  }
+}
+
+template <class A>
+NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   const noahmp_tables* T = c.T;
   const int v = s.vegtyp - 1;
   const float dt = c.dt;
-  if ((s.vegtyp == T->iswater) || (s.vegtyp == T->isbarren) || (s.vegtyp == T->issnow) ||
-      (s.vegtyp == c.isurban)) {
-    s.lai = 0.f; s.sai = 0.f; s.gpp = 0.f; s.npp = 0.f; s.nee = 0.f;
-    s.lfmass = 0.f; s.rtmass = 0.f; s.stmass = 0.f; s.wood = 0.f; s.stblcp = 0.f; s.fastcp = 0.f;
-    return;
-  }
   float lapm = T->sla[v] / 1000.f;
   float wstres = 1.f - s.btran;
   float wroot = 0.f;

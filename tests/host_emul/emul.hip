@@ -1,0 +1,52 @@
+// TEST INFRASTRUCTURE -- host-compiled emulation of the device source.
+// The column physics in noahmp_amd/csrc/*.hpp is __host__ __device__; this harness runs the very
+// same column_step() on the CPU (host libm) so that the restructured GPU source can be checked
+// bit-for-bit against the oracle in a container that has no GPU.  Never shipped, never a fallback:
+// the product library (libnoahmp_hip.so) contains no host path.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+#include "noahmp_hip.h"
+#include "nmp_dev_column.hpp"
+
+using namespace nmp;
+
+static noahmp_tables g_t;
+
+extern "C" int emul_set_tables(const noahmp_tables* t) { g_t = *t; return 0; }
+
+extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
+  memset(st, 0, sizeof(*st));
+  KArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.ni = a->ime - a->ims + 1;
+  k.nka = a->kme - a->kms + 1;
+  k.nti = a->ite - a->its + 1;
+  k.ntj = a->jte - a->jts + 1;
+  k.k1 = 1 - a->kms;
+  k.kp_lo = a->kts - a->kms;
+  k.kp_hi = a->kts + 1 - a->kms;
+  k.yearlen = 365;
+  if (a->yr % 4 == 0) { k.yearlen = 366; if (a->yr % 100 == 0) { k.yearlen = 365; if (a->yr % 400 == 0) k.yearlen = 366; } }
+  k.c.T = &g_t;
+  k.c.O = Opt{a->idveg, a->iopt_crs, a->iopt_btr, a->iopt_run, a->iopt_sfc, a->iopt_frz, a->iopt_inf,
+              a->iopt_rad, a->iopt_alb, a->iopt_snf, a->iopt_tbot, a->iopt_stc};
+  k.c.dt = a->dt;
+  k.c.isurban = a->isurban;
+  k.c.zsoil[L(1)] = -a->dzs[0];
+  for (int l = 2; l <= NOAHMP_NSOIL; l++) k.c.zsoil[L(l)] = -a->dzs[l - 1] + k.c.zsoil[L(l - 1)];
+  const long n = (long)k.nti * k.ntj;
+  for (long t = 0; t < n; t++) {
+    float base[LAY_SLOTS];
+    int ii = 0, jj = 0;
+    size_t ij = 0;
+    int cls = column_classify(k, t, ii, jj, ij);
+    if (cls == 2) st->n_skipped++;
+    if (cls > 1) continue;
+    if (cls == 0) st->n_land++; else st->n_glacier++;
+    int err = column_step<1>(k, cls, ii, jj, ij, base);
+    if (err && !st->code) { st->code = err; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
+  }
+  return st->code;
+}

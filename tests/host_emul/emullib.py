@@ -1,0 +1,38 @@
+"""TEST INFRASTRUCTURE: loader for the host-compiled emulation of the device source."""
+import ctypes as C
+import os
+import subprocess
+
+from noahmp_amd.abi import StepArgs, Tables, Status
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(_HERE))
+LIB = os.path.join(_HERE, "libnmp_emul.so")
+
+
+def build():
+    src = os.path.join(_HERE, "emul.hip")
+    csrc = os.path.join(ROOT, "noahmp_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
+        return
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-fPIC", "-shared", "-std=c++17",
+                           "-ffp-contract=off", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + csrc, src, "-o", LIB])
+
+
+class EmulLib:
+    def __init__(self):
+        build()
+        self.lib = C.CDLL(LIB)
+        self.lib.emul_set_tables.argtypes = [C.POINTER(Tables)]
+        self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
+
+    def set_tables(self, t):
+        self.lib.emul_set_tables(C.byref(t))
+
+    def noahmplsm(self, store, itimestep, yr, julian):
+        a = store.step_args(itimestep, yr, julian)
+        st = Status()
+        self.lib.emul_step(C.byref(a), C.byref(st))
+        return st
