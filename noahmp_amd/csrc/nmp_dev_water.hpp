@@ -107,8 +107,9 @@ NMP_DEV void combo(float& dz, float& wliq, float& wice, float& t, float dz2, flo
   dz = dzc; wice = wicec; wliq = wliqc; t = tc;
 }
 
-// COMBINE lsm:7065-7246
-template <class A>
+// COMBINE lsm:7065-7246.  GLAC selects COMBINE_GLACIER (gla:2403-2571): DZMIN /0.045,0.05,0.2/,
+// collapse below 0.05 m, PONDING1/2 accumulate, no negative-ice branch.
+template <bool GLAC, class A>
 NMP_DEV void combine(Col& s, const Lay<A>& y) {
   int& isnow = s.isnow;
   int isnow_old = isnow;
@@ -123,7 +124,11 @@ NMP_DEV void combine(Col& s, const Lay<A>& y) {
           y.snliq[L(j - 1)] = y.snliq[L(j - 1)] + y.snliq[L(j)];
           y.snice[L(j - 1)] = y.snice[L(j - 1)] + y.snice[L(j)];
         } else {
-          if (y.snice[L(j)] >= 0.f) {
+          if (GLAC) {
+            s.ponding1 = s.ponding1 + y.snliq[L(j)];
+            s.sneqv = y.snice[L(j)];
+            s.snowh = y.dzsnso[L(j)];
+          } else if (y.snice[L(j)] >= 0.f) {
             s.ponding1 = y.snliq[L(j)];
             s.sneqv = y.snice[L(j)];
             s.snowh = y.dzsnso[L(j)];
@@ -162,10 +167,10 @@ NMP_DEV void combine(Col& s, const Lay<A>& y) {
     zwice = zwice + y.snice[L(j)];
     zwliq = zwliq + y.snliq[L(j)];
   }
-  if (s.snowh < 0.025f && isnow < 0) {
+  if (s.snowh < (GLAC ? 0.05f : 0.025f) && isnow < 0) {
     isnow = 0;
     s.sneqv = zwice;
-    s.ponding2 = zwliq;
+    s.ponding2 = GLAC ? (s.ponding2 + zwliq) : zwliq;
     if (s.sneqv <= 0.f) s.snowh = 0.f;
   }
   if (isnow < -1) {
@@ -173,7 +178,8 @@ NMP_DEV void combine(Col& s, const Lay<A>& y) {
     int mssi = 1;
 #pragma unroll 1
     for (int i = isnow_old + 1; i <= 0; i++) {
-      float dzmin = (mssi == 3) ? 0.1f : 0.025f;          // DZMIN /0.025, 0.025, 0.1/ (lsm:7104)
+      float dzmin = GLAC ? ((mssi == 1) ? 0.045f : (mssi == 2) ? 0.05f : 0.2f)    // gla:2438
+                         : ((mssi == 3) ? 0.1f : 0.025f);                        // lsm:7104
       if (y.dzsnso[L(i)] < dzmin) {
         int neibor, j, l;
         if (i == isnow + 1) neibor = i + 1;
@@ -205,7 +211,7 @@ NMP_DEV void combine(Col& s, const Lay<A>& y) {
 }
 
 // DIVIDE lsm:7248-7371 (working copies held as scalars: at most 3 snow layers)
-template <class A>
+template <bool GLAC, class A>
 NMP_DEV void divide(Col& s, const Lay<A>& y) {
   const int isnow = s.isnow;
   int msno = -isnow;
@@ -232,7 +238,7 @@ NMP_DEV void divide(Col& s, const Lay<A>& y) {
       wl1 = propor * wl1;
       dz1 = 0.05f;
       combo(dz2, wl2, wi2, t2, drr, zwliq, zwice, t1);
-      if (msno <= 2 && dz2 > 0.20f) {
+      if (msno <= 2 && dz2 > (GLAC ? 0.10f : 0.20f)) {     // lsm:7321 / DIVIDE_GLACIER
         msno = 3;
         float dtdz = (t1 - t2) / ((dz1 + dz2) / 2.f);
         dz2 = dz2 / 2.f; wi2 = wi2 / 2.f; wl2 = wl2 / 2.f;
@@ -300,12 +306,12 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
 }
 
 // SNOWH2O lsm:7530-7678
-template <class A>
+template <bool GLAC, class A>
 NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float qsnsub, float qrain) {
   const float dt = c.dt;
   if (s.sneqv == 0.f) {
     y.sice[L(1)] = y.sice[L(1)] + (qsnfro - qsnsub) * dt / (y.dzsnso[L(1)] * 1000.f);
-    if (y.sice[L(1)] < 0.f) { y.sh2o[L(1)] = y.sh2o[L(1)] + y.sice[L(1)]; y.sice[L(1)] = 0.f; }
+    if (!GLAC && y.sice[L(1)] < 0.f) { y.sh2o[L(1)] = y.sh2o[L(1)] + y.sice[L(1)]; y.sice[L(1)] = 0.f; }
   }
   if (s.isnow == 0 && s.sneqv > 0.f) {
     float temp = s.sneqv;
@@ -322,7 +328,7 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
   if (s.isnow < 0) {
     float wgdif = y.snice[L(s.isnow + 1)] - qsnsub * dt + qsnfro * dt;
     y.snice[L(s.isnow + 1)] = wgdif;
-    if (wgdif < 1.e-6f && s.isnow < 0) combine(s, y);
+    if (wgdif < 1.e-6f && s.isnow < 0) combine<GLAC>(s, y);
     if (s.isnow < 0) {
       float v = y.snliq[L(s.isnow + 1)] + qrain * dt;
       y.snliq[L(s.isnow + 1)] = fmaxf(0.f, v);
@@ -364,6 +370,25 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
   s.qsnbot = qout / dt;
 }
 
+// Rebuild ZSNSO / DZSNSO after the snow-layer bookkeeping (lsm:6978-6994, gla:2219-2235);
+// DZSNSO ends up as positive thickness.
+template <class A>
+NMP_DEV void rebuild_layers(const Ctx& c, const Col& s, const Lay<A>& y) {
+  float run = 0.f;
+#pragma unroll
+  for (int iz = -2; iz <= NSOIL; iz++) {
+    if (iz > s.isnow) {
+      float d;
+      if (iz <= 0) d = -y.dzsnso[L(iz)];
+      else if (iz == 1) d = c.zsoil[L(1)];
+      else d = (c.zsoil[L(iz)] - c.zsoil[L(iz > 1 ? iz - 1 : 1)]);
+      run = (iz == s.isnow + 1) ? d : (run + d);
+      y.zsnso[L(iz)] = run;
+      y.dzsnso[L(iz)] = -d;
+    }
+  }
+}
+
 // SNOWWATER lsm:6868-6996 (SNOWFALL lsm:6998-7063 inlined)
 template <class A>
 NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, float qsnfro,
@@ -391,9 +416,9 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
     }
   }
   if (s.isnow < 0) compact(c, s, y);
-  if (s.isnow < 0) combine(s, y);
-  if (s.isnow < 0) divide(s, y);
-  snowh2o(c, s, y, qsnfro, qsnsub, qrain);
+  if (s.isnow < 0) combine<false>(s, y);
+  if (s.isnow < 0) divide<false>(s, y);
+  snowh2o<false>(c, s, y, qsnfro, qsnsub, qrain);
 #pragma unroll
   for (int iz = -2; iz <= 0; iz++) {
     if (iz <= s.isnow) {
@@ -415,20 +440,7 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
       if (iz > s.isnow) sw = sw + y.snice[L(iz)] + y.snliq[L(iz)];
     s.sneqv = sw;
   }
-  // rebuild ZSNSO / DZSNSO (lsm:6978-6994); DZSNSO ends up positive thickness
-  float run = 0.f;
-#pragma unroll
-  for (int iz = -2; iz <= NSOIL; iz++) {
-    if (iz > s.isnow) {
-      float d;
-      if (iz <= 0) d = -y.dzsnso[L(iz)];
-      else if (iz == 1) d = c.zsoil[L(1)];
-      else d = (c.zsoil[L(iz)] - c.zsoil[L(iz > 1 ? iz - 1 : 1)]);
-      run = (iz == s.isnow + 1) ? d : (run + d);
-      y.zsnso[L(iz)] = run;
-      y.dzsnso[L(iz)] = -d;
-    }
-  }
+  rebuild_layers(c, s, y);
 }
 
 // WDFCND1 lsm:8329-8362 / WDFCND2 lsm:8364-8400

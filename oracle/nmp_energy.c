@@ -20,7 +20,7 @@ void nmp_esat(real t, real* esw, real* esi, real* desw, real* desi) {
 }
 
 /* statement function TDC, lsm:3247 / 3752 */
-static real tdc(real t) { return MINF(50.f, MAXF(-50.f, (t - TFRZ))); }
+real nmp_tdc(real t) { return MINF(50.f, MAXF(-50.f, (t - TFRZ))); }
 
 /* TDFCND, lsm:2014-2118 (Peters-Lidard soil thermal conductivity) */
 static real tdfcnd(const nmp_ctx* c, real smc, real sh2o) {
@@ -82,7 +82,7 @@ static void thermoprop(const nmp_ctx* c, int isnow, int ist, const real* dzsnso,
 }
 
 /* SNOW_AGE lsm:2547-2596 */
-static void snow_age(real dt, real tg, real sneqvo, real sneqv, real* tauss, real* fage) {
+void nmp_snow_age(real dt, real tg, real sneqvo, real sneqv, real* tauss, real* fage) {
   if (sneqv <= 0.0f) *tauss = 0.f;
   else if (sneqv > 800.f) *tauss = 0.f;
   else {
@@ -238,7 +238,7 @@ static void radiation(const nmp_ctx* c, int ist, int isc, int ice, real sneqvo, 
       rho[ib] = MAXF(T->rhol[ib][v] * wl + T->rhos[ib][v] * ws, MPE);
       tau[ib] = MAXF(T->taul[ib][v] * wl + T->taus[ib][v] * ws, MPE);
     }
-    snow_age(dt, tg, sneqvo, sneqv, tauss, &fage);
+    nmp_snow_age(dt, tg, sneqvo, sneqv, tauss, &fage);
     if (c->O.opt_alb == 1) {                                   /* SNOWALB_BATS lsm:2599-2649 */
       const real C1 = 0.2f, C2 = 0.5f;
       real sl = 2.0f, sl1 = 1.f / sl, sl2 = 2.f * sl;
@@ -319,9 +319,8 @@ static void radiation(const nmp_ctx* c, int ist, int isc, int ice, real sneqvo, 
 }
 
 /* SFCDIF1 lsm:4061-4220 (Monin-Obukhov) */
-typedef struct { real moz, fm, fh, fm2, fh2, fv; int mozsgn; } mo_state;
 
-static void sfcdif1(nmp_ctx* c, int iter, real sfctmp, real rhoair, real h, real qair, real zlvl,
+void nmp_sfcdif1(nmp_ctx* c, int iter, real sfctmp, real rhoair, real h, real qair, real zlvl,
                     real zpd, real z0m, real z0h, real ur, real mpe, mo_state* s, real* cm, real* ch,
                     real* ch2) {
   real mozold = s->moz;
@@ -605,7 +604,7 @@ static void vege_flux(nmp_ctx* c, int isnow, real dt, real sav, real sag, real l
   real vaie = MINF(6.f, vai / fveg);
   real laisune = MINF(6.f, laisun / fveg);
   real laishae = MINF(6.f, laisha / fveg);
-  t = tdc(*tg);
+  t = nmp_tdc(*tg);
   nmp_esat(t, &esatw, &esati, &dsatw, &dsati);
   estg = (t > 0.f) ? esatw : esati;
   *qsfc = 0.622f * eair / (psfc - 0.378f * eair);
@@ -617,7 +616,7 @@ static void vege_flux(nmp_ctx* c, int isnow, real dt, real sav, real sag, real l
   for (int iter = 1; iter <= 20; iter++) {           /* loop1, NITERC=20 (lsm:3234) */
     z0h = z0m; z0hg = z0mg;
     if (c->O.opt_sfc == 1) {
-      sfcdif1(c, iter, sfctmp, rhoair, h, qair, zlvl, zpd, z0m, z0h, ur, MPE, &mo, cm, ch, &ch2);
+      nmp_sfcdif1(c, iter, sfctmp, rhoair, h, qair, zlvl, zpd, z0m, z0h, ur, MPE, &mo, cm, ch, &ch2);
       if (c->err) return;
     }
     if (c->O.opt_sfc == 2) {
@@ -631,7 +630,7 @@ static void vege_flux(nmp_ctx* c, int isnow, real dt, real sav, real sag, real l
     rawc = rahc;
     ragrb(c, iter, vaie, rhoair, hg, *tah, zpd, z0mg, z0hg, hcan, uc, z0h, mo.fv, cwp, MPE, &fhg,
           &rahg, &rawg, &rb);
-    t = tdc(*tv);
+    t = nmp_tdc(*tv);
     nmp_esat(t, &esatw, &esati, &dsatw, &dsati);
     if (t > 0.f) { estv = esatw; destv = dsatw; } else { estv = esati; destv = dsati; }
     if (iter == 1) {
@@ -691,7 +690,7 @@ static void vege_flux(nmp_ctx* c, int isnow, real dt, real sav, real sag, real l
   cev = rhoair * CPAIR / (gammag * (rawg + rsurf));
   cgh = 2.f * df[L(isnow + 1)] / dzsnso[L(isnow + 1)];
   for (int iter = 1; iter <= 5; iter++) {            /* loop2, NITERG=5 */
-    t = tdc(*tg);
+    t = nmp_tdc(*tg);
     nmp_esat(t, &esatw, &esati, &dsatw, &dsati);
     if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
     *irg = cir * powi(*tg, 4) + air;
@@ -751,7 +750,7 @@ static void bare_flux(nmp_ctx* c, int isnow, real sag, real lwdn, real ur, real 
   for (int iter = 1; iter <= 5; iter++) {            /* loop3, NITERB=5 (lsm:3749) */
     z0h = z0m;
     if (c->O.opt_sfc == 1) {
-      sfcdif1(c, iter, sfctmp, rhoair, h, qair, zlvl, zpd, z0m, z0h, ur, MPE, &mo, cm, ch, &ch2);
+      nmp_sfcdif1(c, iter, sfctmp, rhoair, h, qair, zlvl, zpd, z0m, z0h, ur, MPE, &mo, cm, ch, &ch2);
       if (c->err) return;
     }
     if (c->O.opt_sfc == 2) {
@@ -763,7 +762,7 @@ static void bare_flux(nmp_ctx* c, int isnow, real sag, real lwdn, real ur, real 
     real rahb = MAXF(1.f, 1.f / (*ch * ur));
     real rawb = rahb;
     ehb = 1.f / rahb;
-    t = tdc(*tgb);
+    t = nmp_tdc(*tgb);
     nmp_esat(t, &esatw, &esati, &dsatw, &dsati);
     if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
     csh = rhoair * CPAIR / rahb;
@@ -781,7 +780,7 @@ static void bare_flux(nmp_ctx* c, int isnow, real sag, real lwdn, real ur, real 
     *ghb = *ghb + cgh * dtg;
     *tgb = *tgb + dtg;
     h = csh * (*tgb - sfctmp);
-    t = tdc(*tgb);
+    t = nmp_tdc(*tgb);
     nmp_esat(t, &esatw, &esati, &dsatw, &dsati);
     estg = (t > 0.f) ? esatw : esati;
     *qsfc = 0.622f * (estg * rhsur) / (psfc - 0.378f * (estg * rhsur));
@@ -828,7 +827,7 @@ void nmp_rosr12(real* p, const real* a, const real* b, real* cc, const real* d, 
 }
 
 /* TSNOSOI lsm:5707-5822 = HRT (5825-5922) + HSTEP (5925-5977); returns before its energy check */
-static void tsnosoi(const nmp_ctx* c, int isnow, real tbot, const real* zsnso, real ssoil,
+void nmp_tsnosoi(const nmp_ctx* c, int isnow, real tbot, const real* zsnso, real ssoil,
                     const real* df, const real* hcpct, real zbot, real dt, real snowh, real* stc) {
   int ns = c->nsoil;
   real zbotsno = zbot - snowh;
@@ -1169,7 +1168,7 @@ void nmp_energy(nmp_ctx* c, nmp_column* s, nmp_work* w) {
   s->trad = powf((fire - (1 - s->emissi) * s->lwdn) / (s->emissi * SB), 0.25f);
   s->apar = parsun * laisun + parsha * laisha;
   s->psn = psnsun * laisun + psnsha * laisha;
-  tsnosoi(c, s->isnow, s->tbot, s->zsnso, s->ssoil, df, hcpct, P->zbot, c->dt, s->snowh, s->stc);
+  nmp_tsnosoi(c, s->isnow, s->tbot, s->zsnso, s->ssoil, df, hcpct, P->zbot, c->dt, s->snowh, s->stc);
   if (c->O.opt_stc == 2) {
     if (s->snowh > 0.05f && s->tg > TFRZ) {
       s->tgv = TFRZ; s->tgb = TFRZ;

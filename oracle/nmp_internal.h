@@ -31,6 +31,21 @@ typedef struct {
   real sice[NL];
 } nmp_work;
 
+typedef struct { real moz, fm, fh, fm2, fh2, fv; int mozsgn; } mo_state;
+real nmp_tdc(real t);
+void nmp_snow_age(real dt, real tg, real sneqvo, real sneqv, real* tauss, real* fage);
+void nmp_sfcdif1(nmp_ctx* c, int iter, real sfctmp, real rhoair, real h, real qair, real zlvl, real zpd,
+                 real z0m, real z0h, real ur, real mpe, mo_state* s, real* cm, real* ch, real* ch2);
+void nmp_tsnosoi(const nmp_ctx* c, int isnow, real tbot, const real* zsnso, real ssoil, const real* df,
+                 const real* hcpct, real zbot, real dt, real snowh, real* stc);
+void nmp_combine(int glacier, int* isnow, real* sh2o, real* stc, real* snice, real* snliq, real* dzsnso,
+                 real* sice, real* snowh, real* sneqv, real* ponding1, real* ponding2);
+void nmp_divide(int nsnow, real dz2max, int* isnow, real* stc, real* snice, real* snliq, real* dzsnso);
+void nmp_compact(real dt, const real* stc, const real* snice, const real* snliq, const int* imelt,
+                 const real* ficeold, int isnow, real* dzsnso);
+void nmp_snowh2o(const nmp_ctx* c, int glacier, real dt, real qsnfro, real qsnsub, real qrain, int* isnow,
+                 real* dzsnso, real* snowh, real* sneqv, real* snice, real* snliq, real* sh2o, real* sice,
+                 real* stc, real* qsnbot, real* ponding1, real* ponding2);
 void nmp_esat(real t, real* esw, real* esi, real* desw, real* desi);
 void nmp_rosr12(real* p, const real* a, const real* b, real* cc, const real* d, real* delta, int ntop,
                 int nsoil);

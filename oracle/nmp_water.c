@@ -105,9 +105,13 @@ static void combo(real* dz, real* wliq, real* wice, real* t, real dz2, real wliq
 }
 
 /* COMBINE lsm:7065-7246 */
-static void combine(int* isnow, real* sh2o, real* stc, real* snice, real* snliq, real* dzsnso,
-                    real* sice, real* snowh, real* sneqv, real* ponding1, real* ponding2) {
-  const real DZMIN[3] = {0.025f, 0.025f, 0.1f};
+/* glacier != 0 selects COMBINE_GLACIER (gla:2403-2571): DZMIN /0.045,0.05,0.2/, collapse below
+ * 0.05 m, PONDING1/2 accumulate, no negative-ice branch */
+void nmp_combine(int glacier, int* isnow, real* sh2o, real* stc, real* snice, real* snliq, real* dzsnso,
+                 real* sice, real* snowh, real* sneqv, real* ponding1, real* ponding2) {
+  const real DZMIN_L[3] = {0.025f, 0.025f, 0.1f}, DZMIN_G[3] = {0.045f, 0.05f, 0.2f};
+  const real* DZMIN = glacier ? DZMIN_G : DZMIN_L;
+  const real hmin = glacier ? 0.05f : 0.025f;
   int isnow_old = *isnow;
   for (int j = isnow_old + 1; j <= 0; j++) {
     if (snice[L(j)] <= .1f) {
@@ -119,7 +123,11 @@ static void combine(int* isnow, real* sh2o, real* stc, real* snice, real* snliq,
           snliq[L(j - 1)] = snliq[L(j - 1)] + snliq[L(j)];
           snice[L(j - 1)] = snice[L(j - 1)] + snice[L(j)];
         } else {
-          if (snice[L(j)] >= 0.f) {
+          if (glacier) {
+            *ponding1 = *ponding1 + snliq[L(j)];
+            *sneqv = snice[L(j)];
+            *snowh = dzsnso[L(j)];
+          } else if (snice[L(j)] >= 0.f) {
             *ponding1 = snliq[L(j)];
             *sneqv = snice[L(j)];
             *snowh = dzsnso[L(j)];
@@ -156,10 +164,10 @@ static void combine(int* isnow, real* sh2o, real* stc, real* snice, real* snliq,
     zwice = zwice + snice[L(j)];
     zwliq = zwliq + snliq[L(j)];
   }
-  if (*snowh < 0.025f && *isnow < 0) {
+  if (*snowh < hmin && *isnow < 0) {
     *isnow = 0;
     *sneqv = zwice;
-    *ponding2 = zwliq;
+    *ponding2 = glacier ? (*ponding2 + zwliq) : zwliq;
     if (*sneqv <= 0.f) *snowh = 0.f;
   }
   if (*isnow < -1) {
@@ -195,7 +203,8 @@ static void combine(int* isnow, real* sh2o, real* stc, real* snice, real* snliq,
 }
 
 /* DIVIDE lsm:7248-7371 */
-static void divide(int nsnow, int* isnow, real* stc, real* snice, real* snliq, real* dzsnso) {
+/* dz2max: third-layer trigger, 0.20 m on land (lsm:7321), 0.10 m on glaciers (gla DIVIDE_GLACIER) */
+void nmp_divide(int nsnow, real dz2max, int* isnow, real* stc, real* snice, real* snliq, real* dzsnso) {
   real dz[4] = {0, 0, 0, 0}, swice[4] = {0, 0, 0, 0}, swliq[4] = {0, 0, 0, 0}, tsno[4] = {0, 0, 0, 0};
   for (int j = 1; j <= nsnow; j++) {
     if (j <= abs(*isnow)) {
@@ -224,7 +233,7 @@ static void divide(int nsnow, int* isnow, real* stc, real* snice, real* snliq, r
       swliq[1] = propor * swliq[1];
       dz[1] = 0.05f;
       combo(&dz[2], &swliq[2], &swice[2], &tsno[2], drr, zwliq, zwice, tsno[1]);
-      if (msno <= 2 && dz[2] > 0.20f) {
+      if (msno <= 2 && dz[2] > dz2max) {
         msno = 3;
         real dtdz = (tsno[1] - tsno[2]) / ((dz[1] + dz[2]) / 2.f);
         dz[2] = dz[2] / 2.f; swice[2] = swice[2] / 2.f; swliq[2] = swliq[2] / 2.f;
@@ -258,7 +267,7 @@ static void divide(int nsnow, int* isnow, real* stc, real* snice, real* snliq, r
 }
 
 /* COMPACT lsm:7427-7528 */
-static void compact(real dt, const real* stc, const real* snice, const real* snliq, const int* imelt,
+void nmp_compact(real dt, const real* stc, const real* snice, const real* snliq, const int* imelt,
                     const real* ficeold, int isnow, real* dzsnso) {
   const real C2 = 21.e-3f, C3 = 2.5e-6f, C4 = 0.04f, C5 = 2.0f, DM = 100.0f, ETA0 = 0.8e+6f;
   real burden = 0.0f;
@@ -289,13 +298,14 @@ static void compact(real dt, const real* stc, const real* snice, const real* snl
 }
 
 /* SNOWH2O lsm:7530-7678 */
-static void snowh2o(const nmp_ctx* c, real dt, real qsnfro, real qsnsub, real qrain, int* isnow,
+/* glacier != 0 selects SNOWH2O_GLACIER (gla:2751-2895): no SICE<0 repair in the bare-ground branch */
+void nmp_snowh2o(const nmp_ctx* c, int glacier, real dt, real qsnfro, real qsnsub, real qrain, int* isnow,
                     real* dzsnso, real* snowh, real* sneqv, real* snice, real* snliq, real* sh2o,
                     real* sice, real* stc, real* qsnbot, real* ponding1, real* ponding2) {
   real vol_liq[NL], vol_ice[NL], epore[NL];
   if (*sneqv == 0.f) {
     sice[L(1)] = sice[L(1)] + (qsnfro - qsnsub) * dt / (dzsnso[L(1)] * 1000.f);
-    if (sice[L(1)] < 0.f) { sh2o[L(1)] = sh2o[L(1)] + sice[L(1)]; sice[L(1)] = 0.f; }
+    if (!glacier && sice[L(1)] < 0.f) { sh2o[L(1)] = sh2o[L(1)] + sice[L(1)]; sice[L(1)] = 0.f; }
   }
   if (*isnow == 0 && *sneqv > 0.f) {
     real temp = *sneqv;
@@ -313,7 +323,7 @@ static void snowh2o(const nmp_ctx* c, real dt, real qsnfro, real qsnsub, real qr
     real wgdif = snice[L(*isnow + 1)] - qsnsub * dt + qsnfro * dt;
     snice[L(*isnow + 1)] = wgdif;
     if (wgdif < 1.e-6f && *isnow < 0)
-      combine(isnow, sh2o, stc, snice, snliq, dzsnso, sice, snowh, sneqv, ponding1, ponding2);
+      nmp_combine(glacier, isnow, sh2o, stc, snice, snliq, dzsnso, sice, snowh, sneqv, ponding1, ponding2);
     if (*isnow < 0) {
       snliq[L(*isnow + 1)] = snliq[L(*isnow + 1)] + qrain * dt;
       snliq[L(*isnow + 1)] = MAXF(0.f, snliq[L(*isnow + 1)]);
@@ -376,11 +386,11 @@ static void snowwater(const nmp_ctx* c, const int* imelt, real dt, real sfctmp, 
       dzsnso[L(*isnow + 1)] = dzsnso[L(*isnow + 1)] + snowhin * dt;
     }
   }
-  if (*isnow < 0) compact(dt, stc, snice, snliq, imelt, ficeold, *isnow, dzsnso);
-  if (*isnow < 0) combine(isnow, sh2o, stc, snice, snliq, dzsnso, sice, snowh, sneqv, ponding1, ponding2);
-  if (*isnow < 0) divide(c->nsnow, isnow, stc, snice, snliq, dzsnso);
-  snowh2o(c, dt, qsnfro, qsnsub, qrain, isnow, dzsnso, snowh, sneqv, snice, snliq, sh2o, sice, stc,
-          qsnbot, ponding1, ponding2);
+  if (*isnow < 0) nmp_compact(dt, stc, snice, snliq, imelt, ficeold, *isnow, dzsnso);
+  if (*isnow < 0) nmp_combine(0, isnow, sh2o, stc, snice, snliq, dzsnso, sice, snowh, sneqv, ponding1, ponding2);
+  if (*isnow < 0) nmp_divide(c->nsnow, 0.20f, isnow, stc, snice, snliq, dzsnso);
+  nmp_snowh2o(c, 0, dt, qsnfro, qsnsub, qrain, isnow, dzsnso, snowh, sneqv, snice, snliq, sh2o, sice, stc,
+              qsnbot, ponding1, ponding2);
   for (int iz = -c->nsnow + 1; iz <= *isnow; iz++) {
     snice[L(iz)] = 0.f; snliq[L(iz)] = 0.f; stc[L(iz)] = 0.f; dzsnso[L(iz)] = 0.f; zsnso[L(iz)] = 0.f;
   }

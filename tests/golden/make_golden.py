@@ -54,7 +54,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "golden_config1.npz"), **out)
 
     # ---- mixed tile, free run
-    s = synth.mixed_small(tb, ni=64, nj=4, glacier_frac=0.0)
+    s = synth.mixed_small(tb, ni=64, nj=4)
     synth.first_step_fixups(s)
     out = {"t_offset": s.t_offset}
     pack("init", s, out)
@@ -67,7 +67,7 @@ def main():
 
     # ---- option sweep, single step at noon from the same initial state
     out = {}
-    base = synth.mixed_small(tb, ni=32, nj=4, glacier_frac=0.0)
+    base = synth.mixed_small(tb, ni=32, nj=4)
     synth.first_step_fixups(base)
     synth.diurnal_forcing(base, 12, t_offset=base.t_offset)
     pack("init", base, out)                       # one shared pre-step state for every option set

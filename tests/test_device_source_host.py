@@ -50,7 +50,7 @@ def test_device_source_free_run_bit_exact(emul, port, tables):
 
 @pytest.mark.parametrize("kw", SWEEP, ids=[repr(k) for k in SWEEP])
 def test_device_source_option_sweep_bit_exact(emul, port, tables, kw):
-    s = synth.mixed_small(tables[1], ni=32, nj=4, cfg=ModelConfig(**kw), glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=32, nj=4, cfg=ModelConfig(**kw))
     synth.first_step_fixups(s)
     so, se = s.copy(), s.copy()
     for it in range(1, 4):

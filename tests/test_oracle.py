@@ -37,7 +37,7 @@ def test_port_matches_golden_mixed(port):
     for it in range(1, 25):
         synth.diurnal_forcing(s, (it - 1) % 24, t_offset=toff)
         st = port.noahmplsm(s, it, 2000, 180.0)
-        assert st.code == 0 and st.n_land == 256
+        assert st.code == 0 and st.n_land + st.n_glacier == 256 and st.n_glacier > 0
         seen.update(np.unique(s["isnowxy"]).tolist())
         if it in (1, 12, 24):
             for k in _outs(s):
@@ -58,14 +58,19 @@ def test_port_matches_golden_option_sweep(port):
             s["wtxy"] = 0.0
         st = port.noahmplsm(s, 1, 2000, 180.0)
         assert st.code == 0, kw
+        # OPT_SFC=2: the reference reads FH2 uninitialised in its 2-m diagnostics (SFCDIF2 never sets
+        # it, lsm:3560/3929), so these six outputs are undefined there (stack garbage); oracle uses 0.
+        undefined = ("t2mvxy", "t2mbxy", "q2mvxy", "q2mbxy", "chv2xy", "chb2xy") if kw.get("iopt_sfc") == 2 else ()
         for k in _outs(s):
+            if k in undefined:
+                continue
             np.testing.assert_array_equal(s.a[k], g["opt%02d/%s" % (n, k)], err_msg="%s %s" % (k, kw))
 
 
 def test_port_vs_reference_live(port, reflib, tables):
     """Where the compiled reference is available: fresh seeded tile, 6 steps, bit-exact."""
     reflib.read_tables()
-    s = synth.mixed_small(tables[1], ni=48, nj=3, seed=11, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=48, nj=3, seed=11)
     synth.first_step_fixups(s)
     sr, sp = s.copy(), s.copy()
     for it in range(1, 7):
@@ -90,7 +95,7 @@ def test_tables_fixture_matches_reference(reflib, tables):
 
 def test_port_fatal_codes(port, tables):
     """Error channel: out-of-range soil type -> REDPRM fatal (lsm:9266) reported with (i,j)."""
-    s = synth.mixed_small(tables[1], ni=8, nj=2, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=8, nj=2)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     s["isltyp"][1, 3] = 25
@@ -100,13 +105,13 @@ def test_port_fatal_codes(port, tables):
 
 def test_water_points_skipped(port, tables):
     """Open water is skipped, sea ice only sets SH2O/XLAI (drv:434-441)."""
-    s = synth.mixed_small(tables[1], ni=8, nj=2, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=8, nj=2)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     s["xland"][0, 0] = 2.0
     s["xice"][0, 1] = 1.0
     before = s.copy()
     st = port.noahmplsm(s, 2, 2000, 180.0)
-    assert st.n_skipped == 2 and st.n_land == 14
+    assert st.n_skipped == 2 and st.n_land + st.n_glacier == 14
     assert s["tsk"][0, 0] == before["tsk"][0, 0] and s["tslb"][0, 0, 0] == before["tslb"][0, 0, 0]
     assert (s["sh2o"][0, :, 1] == 1.0).all() and s["xlaixy"][0, 1] == np.float32(0.01)

@@ -48,7 +48,7 @@ def test_config1_single_column_trajectory(engine):
 
 def test_mixed_tile_single_step_restart_vs_oracle(engine, port, tables):
     """Each of 24 steps: HIP starts from the oracle's state, compared after one step."""
-    s = synth.mixed_small(tables[1], ni=64, nj=8, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=64, nj=8)
     synth.first_step_fixups(s)
     so = s.copy()
     seen = set()
@@ -57,7 +57,7 @@ def test_mixed_tile_single_step_restart_vs_oracle(engine, port, tables):
         sd = so.copy()
         port.noahmplsm(so, it, 2000, 180.0)
         st = engine.noahmplsm(sd, it, 2000, 180.0)          # host-memory path of the C-ABI
-        assert st.code == 0 and st.n_land == 512
+        assert st.code == 0 and st.n_land + st.n_glacier == 512 and st.n_glacier > 0
         _check(so, sd, steps=1)
         seen.update(np.unique(so["isnowxy"]).tolist())
     assert seen == {0, -1, -2, -3}
@@ -101,7 +101,7 @@ def test_option_sweep_vs_golden(engine):
 
 
 def test_host_and_device_paths_bit_identical(engine, tables):
-    s = synth.mixed_small(tables[1], ni=64, nj=4, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=64, nj=4)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
     h = s.copy()
@@ -115,7 +115,7 @@ def test_host_and_device_paths_bit_identical(engine, tables):
 
 def test_launch_variants_bit_identical(engine, tables):
     """Block size and LDS-vs-scratch layer storage change scheduling only, never results."""
-    s = synth.mixed_small(tables[1], ni=64, nj=8, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=64, nj=8)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 11, t_offset=s.t_offset)
     outs = []
@@ -138,7 +138,7 @@ def test_tile_split_invariance(engine, tables):
     """its/ite/jts/jte sub-tiles of a larger memory block give the same columns as the whole tile."""
     import ctypes as C
     from noahmp_amd import abi
-    s = synth.mixed_small(tables[1], ni=48, nj=6, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=48, nj=6)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     whole = s.copy()
@@ -149,7 +149,7 @@ def test_tile_split_invariance(engine, tables):
         a.its, a.ite, a.jts, a.jte = i0, i1, j0, j1
         st = abi.Status()
         rc = engine.lib.noahmp_hip_step(C.byref(a), abi.MEM_HOST, None, C.byref(st))
-        assert rc == 0 and st.n_land == (i1 - i0 + 1) * (j1 - j0 + 1)
+        assert rc == 0 and st.n_land + st.n_glacier == (i1 - i0 + 1) * (j1 - j0 + 1)
     for k in _outs(whole):
         np.testing.assert_array_equal(whole.a[k], parts.a[k], err_msg=k)
 
@@ -157,7 +157,7 @@ def test_tile_split_invariance(engine, tables):
 def test_permutation_invariance_large(engine, tables):
     """Size-independent property at 262 144 columns: columns are independent, so permuting them
     permutes the results bit-for-bit (catches any cross-column / indexing / race error)."""
-    s = synth.config3(tables[1], ni=512, nj=512, seed=9, glacier_frac=0.0)
+    s = synth.config3(tables[1], ni=512, nj=512, seed=9)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     rng = np.random.Generator(np.random.Philox(1))
@@ -174,7 +174,7 @@ def test_permutation_invariance_large(engine, tables):
             p.a[k][...] = flat.reshape(nj, ni, nk).transpose(0, 2, 1)
     st = engine.noahmplsm(s, 3, 2000, 180.0)
     st2 = engine.noahmplsm(p, 3, 2000, 180.0)
-    assert st.code == 0 and st2.code == 0 and st.n_land == st2.n_land == s.ncol
+    assert st.code == 0 and st2.code == 0 and st.n_land == st2.n_land and st.n_land + st.n_glacier == s.ncol
     for k in _outs(s):
         v, w = s.a[k], p.a[k]
         if v.ndim == 2:
@@ -218,7 +218,7 @@ def test_sample_of_config2_vs_oracle(engine, port, tables):
 def test_error_channel_first_column_wins(engine, tables):
     """A fatal column is reported with its Fortran (i,j); lowest linear index wins; others advance."""
     from noahmp_amd.driver import NoahMPFatal
-    s = synth.mixed_small(tables[1], ni=32, nj=4, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=32, nj=4)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     s["isltyp"][2, 7] = 25          # REDPRM: too many input soil types (lsm:9266)
@@ -232,7 +232,7 @@ def test_error_channel_first_column_wins(engine, tables):
 
 
 def test_water_and_seaice_points(engine, port, tables):
-    s = synth.mixed_small(tables[1], ni=16, nj=2, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=16, nj=2)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     s["xland"][0, 0] = 2.0
@@ -240,14 +240,14 @@ def test_water_and_seaice_points(engine, port, tables):
     so, sd = s.copy(), s.copy()
     port.noahmplsm(so, 1, 2000, 180.0)       # itimestep 1: exercises the water-point init too
     st = engine.noahmplsm(sd, 1, 2000, 180.0)
-    assert st.n_skipped == 2 and st.n_land == 30
+    assert st.n_skipped == 2 and st.n_land + st.n_glacier == 30
     for k in ("smois", "tslb", "sh2o", "xlaixy", "smstav"):
         np.testing.assert_array_equal(so.a[k][..., :2], sd.a[k][..., :2], err_msg=k)
 
 
 def test_unsupported_options_are_rejected(engine, tables):
     from noahmp_amd.driver import NoahMPFatal
-    s = synth.mixed_small(tables[1], ni=8, nj=1, glacier_frac=0.0)
+    s = synth.mixed_small(tables[1], ni=8, nj=1)
     s.cfg = ModelConfig(iopt_sfc=3)
     with pytest.raises(NoahMPFatal) as e:
         engine.noahmplsm(s, 1, 2000, 180.0)
