@@ -128,8 +128,7 @@ def main():
         step(it)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -148,15 +147,8 @@ def main():
     if os.environ.get("NMP_BENCH_DEBUG"):
         print("per-step host overhead ms:", ["%.2f" % w for w in walls], file=sys.stderr)
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        nl = torch.tensor([n_land], device="cuda", dtype=torch.float64)
-        dist.all_reduce(nl, op=dist.ReduceOp.SUM)
-        n_land_all = float(nl.item())
-    else:
-        n_land_all = float(n_land)
+    dt = comm.reduce_max(dt)                    # MAX over ranks
+    n_land_all = comm.reduce_sum(n_land)        # columns advanced by the whole job
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU leg: after the timed GPU region, in a child process that never initialises the GPU
@@ -199,8 +191,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ def setup():
     T, tb = load_tables("usgs")
     port = PortLib(autobuild=not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libnoahmp_oracle.so")))
     port.set_tables(T)
-    eng = Engine(T, device=0)
+    eng = Engine(T, device=0, lib_path=os.environ.get("NMP_LIB"))
     return T, tb, port, eng
 
 
@@ -75,8 +75,8 @@ def perf(ni=1024, nj=1024):
     s = synth.config2(tb, ni=ni, nj=nj)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
-    for block in (64, 128, 256):
-        for lds in (1, 0):
+    for block in ((64, 128, 256) if not os.environ.get("NMP_QUICK") else (64,)):
+        for lds in ((1, 0) if not os.environ.get("NMP_QUICK") else (1,)):
             eng.set_option("block", block)
             eng.set_option("lds", lds)
             d = s.to_device("cuda:0")

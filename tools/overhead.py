@@ -19,3 +19,14 @@ for ni, nj in ((8, 1), (1024, 64), (1024, 1024)):
     torch.cuda.synchronize()
     w = (time.perf_counter() - t) / n * 1e3
     print("tile %dx%d: wall %.3f ms/step, kernel %.3f ms, overhead %.3f ms" % (ni, nj, w, km / n, w - km / n))
+
+# host-memory path (what the Fortran shim pays): H2D of all arrays + kernel + D2H, 1M columns
+s = synth.config2(tb, ni=1024, nj=1024)
+synth.first_step_fixups(s); synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+for it in range(2): eng.noahmplsm(s, it + 1, 2000, 180.0)
+t = time.perf_counter()
+n = 5
+for it in range(n):
+    st = eng.noahmplsm(s, it + 3, 2000, 180.0)
+w = (time.perf_counter() - t) / n
+print("host-memory path 1024x1024: %.1f ms/step (kernel %.2f ms) -> %.3e col-steps/s PCIe-inclusive" % (w * 1e3, st.kernel_ms, s.ncol / w))

@@ -22,7 +22,7 @@ def main(mode):
         from noahmp_amd.driver import Engine
         from oracle.portlib import PortLib
         a = PortLib(autobuild=False); a.set_tables(T)
-        b = Engine(T, device=0)
+        b = Engine(T, device=0, lib_path=os.environ.get("NMP_LIB"))
         stepa = lambda s, it: a.noahmplsm(s, it, 2000, 180.0)            # noqa: E731
         stepb = lambda s, it: b.noahmplsm(s, it, 2000, 180.0, check=False)   # noqa: E731
     else:
@@ -52,7 +52,7 @@ def main(mode):
         out[n] = dict(max=float(d.max()), p999=float(np.quantile(d, 0.999)), frac_tight=tight,
                       maxrel=float((d / np.maximum(m, 1e-30))[d > at].max()) if (d > at).any() else 0.0)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_stats_%s.json" % mode), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_stats_%s%s.json" % (mode, os.environ.get("NMP_TAG", ""))), "w"), indent=1)
     for n in names:
         o = out[n]
         if o["max"] > 0:
