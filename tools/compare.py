@@ -54,8 +54,9 @@ def compare(a, b, fields=None, steps=1, mask=None, verbose=False, skip=()):
         y = y.astype(np.float64)
         rt, at = tolerance(n, steps)
         both_nan = np.isnan(x) & np.isnan(y)
-        d = np.abs(x - y)
-        d[both_nan] = 0.0
+        with np.errstate(invalid="ignore"):
+            d = np.abs(x - y)
+        d[both_nan | (x == y)] = 0.0          # NaN==NaN and inf==inf count as agreement
         lim = at + rt * np.maximum(np.abs(x), np.abs(y))
         viol = ~(d <= lim)
         if verbose or viol.any():
@@ -130,8 +131,9 @@ def parity_check(ref, test, steps=1, frac=0.04, frac_medium=0.01, fields=None, m
             continue
         x = x.astype(np.float64)
         y = y.astype(np.float64)
-        d = np.abs(x - y)
-        d[np.isnan(x) & np.isnan(y)] = 0.0
+        with np.errstate(invalid="ignore"):
+            d = np.abs(x - y)
+        d[(np.isnan(x) & np.isnan(y)) | (x == y)] = 0.0     # NaN==NaN and inf==inf count as agreement
         mag = np.maximum(np.abs(x), np.abs(y))
         rt, at = tolerance(n, steps)
         nt = int((~(d <= at + rt * mag)).sum())
