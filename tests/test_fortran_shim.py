@@ -46,13 +46,16 @@ def test_fortran_shim_end_to_end(engine, tables):
     ref.set_tables(tables[0])                       # fills the reference's table modules (what NOAHMP_INIT does)
     lib = C.CDLL(build_shim.build())
     lib.shim_noahmplsm.argtypes = [C.POINTER(abi.StepArgs)]
-    s = synth.mixed_small(tables[1], ni=48, nj=4)
+    from noahmp_amd.state import ModelConfig
+    # iopt_rad=1 reads the crown-radius table RC: the option that exposed a local `rc` shadowing it
+    s = synth.mixed_small(tables[1], ni=48, nj=4, cfg=ModelConfig(iopt_rad=1))
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     via_c, via_f = s.copy(), s.copy()
     engine.noahmplsm(via_c, 1, 2000, 180.0)
     a = via_f.step_args(1, 2000, 180.0)
     lib.shim_noahmplsm(C.byref(a))                  # Fortran: noahmplsm(...) -> noahmp_hip_step
+    engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))   # the shim uploaded ITS table image; restore the fixture's
     for k in via_c.a:
         if FIELD_INFO[k][2] != "in":
             np.testing.assert_array_equal(via_c.a[k], via_f.a[k], err_msg=k)

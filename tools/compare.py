@@ -57,7 +57,7 @@ def compare(a, b, fields=None, steps=1, mask=None, verbose=False, skip=()):
         with np.errstate(invalid="ignore"):
             d = np.abs(x - y)
         d[both_nan | (x == y)] = 0.0          # NaN==NaN and inf==inf count as agreement
-        lim = at + rt * np.maximum(np.abs(x), np.abs(y))
+        lim = at + rt * np.nan_to_num(np.maximum(np.abs(x), np.abs(y)), nan=0.0, posinf=0.0)
         viol = ~(d <= lim)
         if verbose or viol.any():
             rel = d / np.maximum(np.maximum(np.abs(x), np.abs(y)), 1e-30)
@@ -134,7 +134,7 @@ def parity_check(ref, test, steps=1, frac=0.04, frac_medium=0.01, fields=None, m
         with np.errstate(invalid="ignore"):
             d = np.abs(x - y)
         d[(np.isnan(x) & np.isnan(y)) | (x == y)] = 0.0     # NaN==NaN and inf==inf count as agreement
-        mag = np.maximum(np.abs(x), np.abs(y))
+        mag = np.nan_to_num(np.maximum(np.abs(x), np.abs(y)), nan=0.0, posinf=0.0)
         rt, at = tolerance(n, steps)
         nt = int((~(d <= at + rt * mag)).sum())
         nm = int((~(d <= 10 * (at + rt * mag))).sum())
@@ -142,6 +142,6 @@ def parity_check(ref, test, steps=1, frac=0.04, frac_medium=0.01, fields=None, m
         ne = int((~(d <= ae + re_ * mag)).sum())
         if nt > max(frac * d.size, 3) or nm > max(frac_medium * d.size, 3) or ne:
             ok = False
-            lines.append("%-12s tight-viol %d  medium-viol %d  envelope-viol %d  of %d; max|d|=%.3e"
-                         % (n, nt, nm, ne, d.size, np.nanmax(d)))
+            lines.append("%-12s tight-viol %d  medium-viol %d  envelope-viol %d  of %d; max|d|=%.3e  (nan ref/test %d/%d)"
+                         % (n, nt, nm, ne, d.size, np.nanmax(d), int(np.isnan(x).sum()), int(np.isnan(y).sum())))
     return ok, lines
