@@ -76,8 +76,30 @@ NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij
   return (ice == -1) ? 1 : 0;
 }
 
+// Outputs that are final once the ENERGY phase is done (nothing in WATER / CARBON / the SFLX tail touches
+// them).  Land columns store them right after ENERGY so that their ~48 registers are free during the
+// water phase (fewer spills at 2 waves/SIMD); glacier columns store them with everything else.
+NMP_DEV void scatter_energy_outputs(const KArgs& k, const Col& s, size_t ij) {
+  G2(tsk) = s.trad; G2(hfx) = s.fsh; G2(grdflx) = s.ssoil;                             // drv:728-730
+  if (s.albedo > -999) G2(albedo) = s.albedo;                                          // drv:741
+  G2(snowc) = s.fsno; G2(emiss) = s.emissi;
+  G2(tgxy) = s.tg; G2(eahxy) = s.eah; G2(tahxy) = s.tah; G2(cmxy) = s.cm; G2(chxy) = s.ch;
+  G2(alboldxy) = s.albold; G2(taussxy) = s.tauss; G2(sneqvoxy) = s.sneqvo;
+  G2(t2mvxy) = s.t2mv; G2(t2mbxy) = s.t2mb; G2(q2mvxy) = s.q2v / (1.0f - s.q2v);       // drv:789-791
+  G2(tradxy) = s.trad; G2(fvegxy) = s.fveg; G2(fsaxy) = s.fsa; G2(firaxy) = s.fira;
+  G2(aparxy) = s.apar; G2(psnxy) = s.psn; G2(savxy) = s.sav; G2(sagxy) = s.sag;
+  G2(rssunxy) = s.rssun; G2(rsshaxy) = s.rssha; G2(bgapxy) = s.bgap; G2(wgapxy) = s.wgap;
+  G2(tgvxy) = s.tgv; G2(tgbxy) = s.tgb; G2(chvxy) = s.chv; G2(chbxy) = s.chb;
+  G2(ircxy) = s.irc; G2(irgxy) = s.irg; G2(shcxy) = s.shc; G2(shgxy) = s.shg; G2(evgxy) = s.evg;
+  G2(ghvxy) = s.ghv; G2(irbxy) = s.irb; G2(shbxy) = s.shb; G2(evbxy) = s.evb; G2(ghbxy) = s.ghb;
+  G2(trxy) = s.tr; G2(evcxy) = s.evc; G2(chleafxy) = s.chleaf; G2(chucxy) = s.chuc;
+  G2(chv2xy) = s.chv2; G2(chb2xy) = s.chb2;
+}
+
 // Gather -> REDPRM -> NOAHMP_SFLX | NOAHMP_GLACIER -> scatter for one land / glacier column.
-// returns the column's status word (0 = ok); a failing column is left untouched (the reference STOPs).
+// Returns the column's status word (0 = ok).  A column that fails before or inside the ENERGY phase is
+// left untouched; one that fails the closing water-balance check has already stored its energy-phase
+// outputs (the reference STOPs at that point, so nothing downstream can observe the difference).
 template <int STRIDE>
 NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base) {
   Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
@@ -135,28 +157,31 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   Parm P;
   redprm(k.c, s, P, vegtyp, soiltyp);
   s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
+  if (s.err) return s.err;                                                         // REDPRM fatals, lsm:9266-9344
 
   float qfx_out, lh_out;
   if (cls == 1) {
     s.tbot = fminf(s.tbot, 263.15f);                                               // drv:555
     glacier(k.c, s, y);
+    if (s.err) return s.err;
     glacier_fill_undefined(s);                                                     // drv:571-625
     qfx_out = s.edir; lh_out = s.fgev;                                             // drv:627-628
+    scatter_energy_outputs(k, s, ij);
   } else {
-    sflx(k.c, P, s, y);
-    qfx_out = s.ecan + s.edir + s.etran;                                           // drv:713-714
-    lh_out = s.fcev + s.fgev + s.fctr;
+    float beg_wb;
+    sflx_energy(k.c, P, s, y, beg_wb);
+    if (s.err) return s.err;
+    lh_out = s.fcev + s.fgev + s.fctr;                                             // drv:714
+    scatter_energy_outputs(k, s, ij);
+    sflx_water(k.c, P, s, y, beg_wb);
+    if (s.err) return s.err;
+    qfx_out = s.ecan + s.edir + s.etran;                                           // drv:713
   }
-
-  if (s.err) return s.err;
-  // ---- scatter, drv:728-835
+  // ---- scatter of everything the water phase (or the glacier tail) produced, drv:728-835
   G2(qfx) = qfx_out; G2(lh) = lh_out;
-  G2(tsk) = s.trad; G2(hfx) = s.fsh; G2(grdflx) = s.ssoil;
   G2(smstav) = 0.0f; G2(smstot) = 0.0f;
   G2(sfcrunoff) = G2(sfcrunoff) + s.runsrf * k.a.dt;
   G2(udrunoff) = G2(udrunoff) + s.runsub * k.a.dt;
-  if (s.albedo > -999) G2(albedo) = s.albedo;
-  G2(snowc) = s.fsno;
 #pragma unroll
   for (int l = 1; l <= NSOIL; l++) {
     G3(smois, l - 1, NSOIL) = y.smc[L(l)]; G3(sh2o, l - 1, NSOIL) = y.sh2o[L(l)];
@@ -166,10 +191,9 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   G2(canwat) = s.canliq + s.canice;
   G2(acsnow) = G2(acsnow) + s.prcp * s.fpice;                                      // no *DT (drv:751)
   G2(acsnom) = G2(acsnom) + s.qsnbot * k.a.dt + s.ponding + s.ponding1 + s.ponding2;
-  G2(emiss) = s.emissi; G2(qsfc) = s.qsfc;
-  G2(isnowxy) = s.isnow; G2(tvxy) = s.tv; G2(tgxy) = s.tg; G2(canliqxy) = s.canliq;
-  G2(canicexy) = s.canice; G2(eahxy) = s.eah; G2(tahxy) = s.tah; G2(cmxy) = s.cm; G2(chxy) = s.ch;
-  G2(fwetxy) = s.fwet; G2(sneqvoxy) = s.sneqvo; G2(alboldxy) = s.albold; G2(qsnowxy) = s.qsnow;
+  G2(qsfc) = s.qsfc;
+  G2(isnowxy) = s.isnow; G2(tvxy) = s.tv; G2(canliqxy) = s.canliq; G2(canicexy) = s.canice;
+  G2(fwetxy) = s.fwet; G2(qsnowxy) = s.qsnow;
   G2(wslakexy) = s.wslake; G2(zwtxy) = s.zwt; G2(waxy) = s.wa; G2(wtxy) = s.wt;
 #pragma unroll
   for (int l = -2; l <= 0; l++) {
@@ -180,19 +204,10 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   for (int l = -2; l <= NSOIL; l++) G3(zsnsoxy, l + 2, NSOIL + 3) = y.zsnso[L(l)];
   G2(lfmassxy) = s.lfmass; G2(rtmassxy) = s.rtmass; G2(stmassxy) = s.stmass; G2(woodxy) = s.wood;
   G2(stblcpxy) = s.stblcp; G2(fastcpxy) = s.fastcp; G2(xlaixy) = s.lai; G2(xsaixy) = s.sai;
-  G2(taussxy) = s.tauss;
-  G2(t2mvxy) = s.t2mv; G2(t2mbxy) = s.t2mb;
-  G2(q2mvxy) = s.q2v / (1.0f - s.q2v); G2(q2mbxy) = s.q2b / (1.0f - s.q2b);
-  G2(tradxy) = s.trad; G2(neexy) = s.nee; G2(gppxy) = s.gpp; G2(nppxy) = s.npp;
-  G2(fvegxy) = s.fveg; G2(runsfxy) = s.runsrf; G2(runsbxy) = s.runsub; G2(ecanxy) = s.ecan;
-  G2(edirxy) = s.edir; G2(etranxy) = s.etran; G2(fsaxy) = s.fsa; G2(firaxy) = s.fira;
-  G2(aparxy) = s.apar; G2(psnxy) = s.psn; G2(savxy) = s.sav; G2(sagxy) = s.sag;
-  G2(rssunxy) = s.rssun; G2(rsshaxy) = s.rssha; G2(bgapxy) = s.bgap; G2(wgapxy) = s.wgap;
-  G2(tgvxy) = s.tgv; G2(tgbxy) = s.tgb; G2(chvxy) = s.chv; G2(chbxy) = s.chb;
-  G2(ircxy) = s.irc; G2(irgxy) = s.irg; G2(shcxy) = s.shc; G2(shgxy) = s.shg; G2(evgxy) = s.evg;
-  G2(ghvxy) = s.ghv; G2(irbxy) = s.irb; G2(shbxy) = s.shb; G2(evbxy) = s.evb; G2(ghbxy) = s.ghb;
-  G2(trxy) = s.tr; G2(evcxy) = s.evc; G2(chleafxy) = s.chleaf; G2(chucxy) = s.chuc;
-  G2(chv2xy) = s.chv2; G2(chb2xy) = s.chb2;
+  G2(q2mbxy) = s.q2b / (1.0f - s.q2b);                                             // drv:792 (urban fix is late)
+  G2(neexy) = s.nee; G2(gppxy) = s.gpp; G2(nppxy) = s.npp;
+  G2(runsfxy) = s.runsrf; G2(runsbxy) = s.runsub; G2(ecanxy) = s.ecan;
+  G2(edirxy) = s.edir; G2(etranxy) = s.etran;
   G2(rechxy) = G2(rechxy) + s.rech * 1.E3f;
   G2(deeprechxy) = G2(deeprechxy) + s.deeprech;
   G2(smcwtdxy) = s.smcwtd;

@@ -318,12 +318,12 @@ NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, floa
   if (mozold * m.moz < 0.f) m.mozsgn = m.mozsgn + 1;
   if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
   if (m.moz < 0.f) {
-    float tmp1 = powf(1.f - 16.f * m.moz, 0.25f);
+    float tmp1 = pow_quarter(1.f - 16.f * m.moz);
     float tmp2 = logf((1.f + tmp1 * tmp1) / 2.f);
     float tmp3 = logf((1.f + tmp1) / 2.f);
     fmnew = 2.f * tmp3 + tmp2 - 2.f * atanf(tmp1) + 1.5707963f;
     fhnew = 2 * tmp2;
-    float tmp12 = powf(1.f - 16.f * moz2, 0.25f);
+    float tmp12 = pow_quarter(1.f - 16.f * moz2);
     float tmp22 = logf((1.f + tmp12 * tmp12) / 2.f);
     float tmp32 = logf((1.f + tmp12) / 2.f);
     fm2new = 2.f * tmp32 + tmp22 - 2.f * atanf(tmp12) + 1.5707963f;
@@ -535,11 +535,11 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
         float molg = -1.f * powi3(mo.fv) / tmp1;
         mozg = fminf((q.zpd - q.z0mg) / molg, 1.f);
       }
-      if (mozg < 0.f) fhgnew = powf(1.f - 15.f * mozg, -0.25f);
+      if (mozg < 0.f) fhgnew = pow_neg_quarter(1.f - 15.f * mozg);
       else fhgnew = 1.f + 4.7f * mozg;
       if (iter == 1) fhg = fhgnew;
       else fhg = 0.5f * (fhg + fhgnew);
-      float cwpc = powf(q.cwp * vaie * hcan * fhg, 0.5f);
+      float cwpc = pow_half(q.cwp * vaie * hcan * fhg);
       float tmp1 = expf(-cwpc * z0hg / hcan);
       float tmp2 = expf(-cwpc * (z0h + q.zpd) / hcan);
       float tmprah2 = hcan * expf(cwpc) / cwpc * (tmp1 - tmp2);
@@ -1080,7 +1080,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   if (fire <= 0.f) raise(s, NOAHMP_ERR_FIRE_NONPOSITIVE);
   s.emissi = s.fveg * (q.emg * (1 - q.emv) + q.emv + q.emv * (1 - q.emv) * (1 - q.emg)) +
              (1 - s.fveg) * q.emg;
-  s.trad = powf((fire - (1 - s.emissi) * s.lwdn) / (s.emissi * SB), 0.25f);
+  s.trad = pow_quarter((fire - (1 - s.emissi) * s.lwdn) / (s.emissi * SB));
   s.apar = r.parsun * r.laisun + r.parsha * r.laisha;
   s.psn = psnsun * r.laisun + psnsha * r.laisha;
   tsnosoi(c, P, s, y, df, hcpct);

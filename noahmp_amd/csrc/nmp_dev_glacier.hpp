@@ -361,7 +361,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
   float fire = s.lwdn + s.fira;
   if (fire <= 0.f) raise(s, NOAHMP_ERR_GLACIER_FIRE_NONPOSITIVE);
   s.emissi = emg;
-  s.trad = powf((fire - (1 - s.emissi) * s.lwdn) / (s.emissi * SB), 0.25f);
+  s.trad = pow_quarter((fire - (1 - s.emissi) * s.lwdn) / (s.emissi * SB));
   {
     Parm P = {};
     P.zbot = -8.0f;                                        // gla:260

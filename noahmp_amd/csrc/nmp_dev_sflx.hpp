@@ -173,8 +173,9 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
 }
 
 // NOAHMP_SFLX lsm:518-947 (with ATM lsm:949-1007 and ERROR lsm:1106-1228)
+// Split in two phases so that the caller can store the energy-phase outputs before the water phase.
 template <class A>
-NMP_DEV void sflx(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
+NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float& beg_wb_out) {
   const noahmp_tables* T = c.T;
   s.nee = 0.f; s.npp = 0.f; s.gpp = 0.f;
   // ATM
@@ -221,9 +222,22 @@ NMP_DEV void sflx(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
 
   energy(c, P, s, y);
 
+  s.sneqvo = s.sneqv;
+  beg_wb_out = beg_wb;
+  // the SW and energy parts of ERROR (lsm:1164-1197) only involve ENERGY outputs: evaluate them here
+  {
+    float errsw = s.swdown - (s.fsa + s.fsr);
+    if (fabsf(errsw) > 0.01f) raise(s, NOAHMP_ERR_SW_BALANCE);
+    float erreng = s.sav + s.sag - (s.fira + s.fsh + s.fcev + s.fgev + s.fctr + s.ssoil);
+    if (fabsf(erreng) > 0.01f) raise(s, NOAHMP_ERR_ENERGY_BALANCE);
+  }
+  s.albedo = (s.swdown != 0.f) ? (s.fsr / s.swdown) : -999.9f;                      // lsm:940-944
+}
+
+template <class A>
+NMP_DEV void sflx_water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float beg_wb) {
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) y.sice[L(iz)] = fmaxf(0.0f, y.smc[L(iz)] - y.sh2o[L(iz)]);
-  s.sneqvo = s.sneqv;
   float qvap = fmaxf(s.fgev / s.latheag, 0.f);
   float qdew = fabsf(fminf(s.fgev / s.latheag, 0.f));
   s.edir = qvap - qdew;
@@ -232,12 +246,8 @@ NMP_DEV void sflx(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
 
   if (c.O.dveg == 2 || c.O.dveg == 5) carbon(c, P, s, y);
 
-  // ERROR: the reference STOPs; here the column raises its status word and finishes the step
+  // water part of ERROR (lsm:1199-1222): the reference STOPs; here the column raises its status word
   {
-    float errsw = s.swdown - (s.fsa + s.fsr);
-    if (fabsf(errsw) > 0.01f) raise(s, NOAHMP_ERR_SW_BALANCE);
-    float erreng = s.sav + s.sag - (s.fira + s.fsh + s.fcev + s.fgev + s.fctr + s.ssoil);
-    if (fabsf(erreng) > 0.01f) raise(s, NOAHMP_ERR_ENERGY_BALANCE);
     float end_wb = s.canliq + s.canice + s.sneqv + s.wa;
 #pragma unroll
     for (int iz = 1; iz <= NSOIL; iz++) end_wb = end_wb + y.smc[L(iz)] * y.dzsnso[L(iz)] * 1000.f;
@@ -250,7 +260,6 @@ NMP_DEV void sflx(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
     s.q2b = s.qsfc;
   }
   if (s.snowh <= 1.E-6f || s.sneqv <= 1.E-3f) { s.snowh = 0.0f; s.sneqv = 0.0f; }
-  s.albedo = (s.swdown != 0.f) ? (s.fsr / s.swdown) : -999.9f;
 }
 
 }  // namespace nmp
