@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from .abi_spec import STEP_FIELDS, TABLE_FIELDS, ERROR_CODES, NSNOW
+from .abi_spec import STEP_FIELDS, TABLE_FIELDS, ERROR_CODES, NSNOW, WTABLE_FIELDS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnoahmp_hip.so")
@@ -25,6 +25,15 @@ def _step_ctype(kind):
 class StepArgs(C.Structure):
     """noahmp_step_args (include/noahmp_hip.h); mirrors the noahmplsm argument list, drv:11-44."""
     _fields_ = [(n, _step_ctype(k)) for n, k, lev, io, ln in STEP_FIELDS]
+
+
+class WtableArgs(C.Structure):
+    """noahmp_wtable_args; mirrors the WTABLE_mmf_noahmp argument list, gw:14-22."""
+    _fields_ = [(n, _step_ctype(k)) for n, k, lev, io, ln in WTABLE_FIELDS]
+
+
+WTABLE_INFO = {n: (k, lev, io) for n, k, lev, io, ln in WTABLE_FIELDS}
+WTABLE_ARRAYS = [n for n, k, lev, io, ln in WTABLE_FIELDS if k in ("pf", "pi")]
 
 
 def _tbl_ctype(kind, shape):
@@ -108,6 +117,8 @@ def load_library(path=None):
     lib.noahmp_hip_set_device.argtypes = [C.c_int]
     lib.noahmp_hip_set_tables.argtypes = [C.POINTER(Tables)]
     lib.noahmp_hip_step.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_void_p, C.POINTER(Status)]
+    lib.noahmp_hip_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.c_int, C.c_void_p, C.POINTER(Status)]
+    lib.noahmp_hip_sizeof_wtable_args.restype = C.c_size_t
     lib.noahmp_hip_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.noahmp_hip_error_string.argtypes = [C.c_int]
     lib.noahmp_hip_error_string.restype = C.c_char_p
@@ -116,6 +127,8 @@ def load_library(path=None):
     if lib.noahmp_hip_sizeof_step_args() != C.sizeof(StepArgs):
         raise RuntimeError("ABI drift: sizeof(noahmp_step_args) %d != ctypes %d"
                            % (lib.noahmp_hip_sizeof_step_args(), C.sizeof(StepArgs)))
+    if lib.noahmp_hip_sizeof_wtable_args() != C.sizeof(WtableArgs):
+        raise RuntimeError("ABI drift: sizeof(noahmp_wtable_args)")
     if lib.noahmp_hip_sizeof_tables() != C.sizeof(Tables):
         raise RuntimeError("ABI drift: sizeof(noahmp_tables)")
     if path is None:
@@ -126,7 +139,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "noahmp_hip_abi_version", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
     "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
-    "noahmp_hip_step", "noahmp_hip_set_option", "noahmp_hip_error_string",
+    "noahmp_hip_step", "noahmp_hip_wtable_mmf", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
     "noahmp_hip_last_error", "noahmp_hip_finalize",
 ]
 

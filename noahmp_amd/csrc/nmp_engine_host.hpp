@@ -1,0 +1,53 @@
+// Host-side engine state shared by the translation units of libnoahmp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "noahmp_hip.h"
+
+namespace nmp_host {
+
+// Tally counters (land / glacier / skipped columns) are spread over kCountSlots cache lines, indexed by
+// workgroup id: device-scope atomics on ONE address are resolved at the memory side of the 8 XCDs and
+// serialise (measured: 110k same-address atomicAdds cost 2.3 ms in the groundwater kernel, 40x its
+// streaming time).  The host adds the slots up.
+constexpr int kCountSlots = 256;
+constexpr int kCountStride = 16;   // ints per slot = one 64-byte line
+
+struct Engine {
+  int device = -1;
+  bool have_tables = false;
+  noahmp_tables* d_tables = nullptr;
+  unsigned long long* d_err = nullptr;
+  int* d_counts = nullptr;
+  unsigned long long* h_err = nullptr;   // pinned
+  int* h_counts = nullptr;               // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t own_stream = nullptr;
+  // host-mode mirrors of the noahmp_step_args arrays (one per field of nmp_fields.inc)
+  std::vector<void*> mirror;
+  std::vector<size_t> mirror_bytes;
+  // groundwater: host-mode mirrors (one per pointer member of noahmp_wtable_args) + KCELL/HEAD planes
+  std::vector<void*> gw_mirror;
+  std::vector<size_t> gw_mirror_bytes;
+  float* gw_kcell = nullptr;
+  float* gw_head = nullptr;
+  size_t gw_plane_bytes = 0;
+  int block = 64;
+  int use_lds = 1;
+  std::string last_error;
+};
+extern Engine g;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  nmp_host::g.last_error = b_; return -100; } } while (0)
+
+int ensure_init();
+// sum the slots of h_counts into out[0..3]
+void sum_counts(int* out);
+// grow-only device buffer
+int ensure_bytes(void** p, size_t* have, size_t need);
+
+}  // namespace nmp_host

@@ -12,6 +12,7 @@
 #include <vector>
 #include "noahmp_hip.h"
 #include "nmp_dev_column.hpp"
+#include "nmp_engine_host.hpp"
 
 using namespace nmp;
 
@@ -39,9 +40,10 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
   {                                           // per-wave tallies (64-wide wavefront)
     unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if ((threadIdx.x & 63) == 0) {
-      if (m0) atomicAdd(&k.counts[0], __popcll(m0));
-      if (m1) atomicAdd(&k.counts[1], __popcll(m1));
-      if (m2) atomicAdd(&k.counts[2], __popcll(m2));
+      int* cnt = k.counts + (blockIdx.x % nmp_host::kCountSlots) * nmp_host::kCountStride;   // see nmp_engine_host.hpp
+      if (m0) atomicAdd(&cnt[0], __popcll(m0));
+      if (m1) atomicAdd(&cnt[1], __popcll(m1));
+      if (m2) atomicAdd(&cnt[2], __popcll(m2));
     }
   }
   if (cls > 1) return;
@@ -59,28 +61,10 @@ const FieldDesc kFields[] = {
 };
 constexpr int kNumFields = sizeof(kFields) / sizeof(kFields[0]);
 
-struct Engine {
-  int device = -1;
-  bool have_tables = false;
-  noahmp_tables* d_tables = nullptr;
-  unsigned long long* d_err = nullptr;
-  int* d_counts = nullptr;
-  unsigned long long* h_err = nullptr;   // pinned
-  int* h_counts = nullptr;               // pinned
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipStream_t own_stream = nullptr;
-  // host-mode mirrors
-  std::vector<void*> mirror = std::vector<void*>(kNumFields, nullptr);
-  std::vector<size_t> mirror_bytes = std::vector<size_t>(kNumFields, 0);
-  int block = 64;
-  int use_lds = 1;
-  std::string last_error;
-};
-Engine g;
+}  // namespace
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
-  char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-  g.last_error = b_; return -100; } } while (0)
+namespace nmp_host {
+Engine g;
 
 int ensure_init() {
   if (g.d_err) return 0;
@@ -91,14 +75,39 @@ int ensure_init() {
   }
   if (g.device < 0) { HIPCHK(hipGetDevice(&g.device)); }
   HIPCHK(hipMalloc(&g.d_err, sizeof(unsigned long long)));
-  HIPCHK(hipMalloc(&g.d_counts, 4 * sizeof(int)));
+  HIPCHK(hipMalloc(&g.d_counts, kCountSlots * kCountStride * sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&g.h_err, sizeof(unsigned long long), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&g.h_counts, 4 * sizeof(int), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&g.h_counts, kCountSlots * kCountStride * sizeof(int), hipHostMallocDefault));
   HIPCHK(hipEventCreate(&g.ev0));
   HIPCHK(hipEventCreate(&g.ev1));
   HIPCHK(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking));
+  g.mirror.assign(kNumFields, nullptr);
+  g.mirror_bytes.assign(kNumFields, 0);
   return 0;
 }
+
+void sum_counts(int* out) {
+  for (int c = 0; c < 4; c++) out[c] = 0;
+  for (int s = 0; s < kCountSlots; s++)
+    for (int c = 0; c < 4; c++) out[c] += g.h_counts[s * kCountStride + c];
+}
+
+int ensure_bytes(void** p, size_t* have, size_t need) {
+  if (*have >= need) return 0;
+  if (*p) HIPCHK(hipFree(*p));
+  *p = nullptr; *have = 0;
+  HIPCHK(hipMalloc(p, need));
+  *have = need;
+  return 0;
+}
+}  // namespace nmp_host
+
+using nmp_host::g;
+using nmp_host::ensure_init;
+using nmp_host::kCountSlots;
+using nmp_host::kCountStride;
+
+namespace {
 
 size_t field_elems(const FieldDesc& f, const noahmp_step_args* a) {
   size_t ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1;
@@ -211,7 +220,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
 
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
-  HIPCHK(hipMemsetAsync(g.d_counts, 0, 4 * sizeof(int), s));
+  HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
   const long ncol = (long)k.nti * k.ntj;
   HIPCHK(hipEventRecord(g.ev0, s));
   if (ncol > 0) {
@@ -222,7 +231,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
 
   if (mem == NOAHMP_MEM_HOST) {
     for (int f = 0; f < kNumFields; f++) {
@@ -238,7 +247,9 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   int code = 0;
   if (st) {
     st->kernel_ms = ms;
-    st->n_land = g.h_counts[0]; st->n_glacier = g.h_counts[1]; st->n_skipped = g.h_counts[2];
+    int cnt[4];
+    nmp_host::sum_counts(cnt);
+    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
   }
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);
@@ -276,6 +287,9 @@ const char* noahmp_hip_last_error(void) { return g.last_error.c_str(); }
 void noahmp_hip_finalize(void) {
   for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& b : g.mirror_bytes) b = 0;
+  for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
+  if (g.gw_kcell) hipFree(g.gw_kcell);
+  if (g.gw_head) hipFree(g.gw_head);
   if (g.d_tables) hipFree(g.d_tables);
   if (g.d_err) hipFree(g.d_err);
   if (g.d_counts) hipFree(g.d_counts);
@@ -284,7 +298,7 @@ void noahmp_hip_finalize(void) {
   if (g.ev0) hipEventDestroy(g.ev0);
   if (g.ev1) hipEventDestroy(g.ev1);
   if (g.own_stream) hipStreamDestroy(g.own_stream);
-  g = Engine();
+  g = nmp_host::Engine();
 }
 
 }  // extern "C"

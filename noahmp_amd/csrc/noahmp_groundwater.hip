@@ -1,0 +1,154 @@
+// Miguez-Macho & Fan groundwater for MI355X (gfx950): kernels + the C-ABI entry noahmp_hip_wtable_mmf(),
+// the drop-in for WTABLE_mmf_noahmp (reference phys/module_sf_noahmp_groundwater.F90:14-198), called by the
+// reference driver every STEPWTD steps when OPT_RUN == 5 (driver/module_hrldas_noahmp_driver.F90:420-436).
+//
+// Both kernels are pure streaming passes over (i,j) planes in the caller's Fortran layout (i fastest):
+// ~216 algorithmic bytes per cell, a few dozen flops on most cells -> HBM-bound.
+// 2-D blocks of 64 x 4 threads: one wavefront per row segment keeps every plane access a full 256-byte
+// coalesced line, and the 9-point stencil's +-1 row neighbours are served from the same workgroup's L1/L2
+// lines.  blockIdx is linearised row-major so consecutive workgroups (which land on different XCDs) walk
+// along i; each XCD's L2 then holds a band of rows shared with its neighbours' halos only at the band edge.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <string.h>
+#include "noahmp_hip.h"
+#include "nmp_dev_groundwater.hpp"
+#include "nmp_engine_host.hpp"
+
+using namespace nmp;
+using nmp_host::g;
+
+namespace {
+
+constexpr int BX = 64, BY = 4;
+
+// KCELL / HEAD on the tile + ring rectangle (gw:237-252)
+__global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
+  const int gi = k.hi0 + blockIdx.x * BX + threadIdx.x;
+  const int gj = k.hj0 + blockIdx.y * BY + threadIdx.y;
+  if (gi > k.hi1 || gj > k.hj1) return;
+  gw_cell_head(k, (size_t)(gj - k.a.jms) * k.ni + (gi - k.a.ims));
+}
+
+// stencil + per-cell update over the tile (gw:105-195)
+__global__ void __launch_bounds__(BX * BY) gw_column_kernel(const GwArgs k) {
+  const int gi = k.a.its + blockIdx.x * BX + threadIdx.x;
+  const int gj = k.a.jts + blockIdx.y * BY + threadIdx.y;
+  const bool in = (gi <= k.a.ite && gj <= k.a.jte);
+  int land = 0;
+  if (in) land = gw_column(k, gi - k.a.ims, gj - k.a.jms, gi, gj);
+  const unsigned long long m = __ballot(land != 0), mi = __ballot(in);
+  if (((threadIdx.y * BX + threadIdx.x) & 63) == 0) {
+    int* cnt = k.counts + ((blockIdx.y * gridDim.x + blockIdx.x) % nmp_host::kCountSlots) * nmp_host::kCountStride;
+    if (m) atomicAdd(&cnt[0], __popcll(m));
+    if (mi != m) atomicAdd(&cnt[2], __popcll(mi) - __popcll(m));
+  }
+}
+
+struct WField { const char* name; size_t off; int kind; int lev; int io; };
+#define WF(n, kind, lev, io) {#n, offsetof(noahmp_wtable_args, n), kind, lev, io}
+const WField kW[] = {
+#include "nmp_wtable_fields.inc"
+};
+constexpr int kNW = sizeof(kW) / sizeof(kW[0]);
+
+inline int imax(int a, int b) { return a > b ? a : b; }
+inline int imin(int a, int b) { return a < b ? a : b; }
+
+}  // namespace
+
+extern "C" {
+
+size_t noahmp_hip_sizeof_wtable_args(void) { return sizeof(noahmp_wtable_args); }
+
+int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st) {
+  if (st) memset(st, 0, sizeof(*st));
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (!g.have_tables) { g.last_error = "noahmp_hip_set_tables() has not been called"; return -102; }
+  if (a->nsoil != NOAHMP_NSOIL) { if (st) st->code = NOAHMP_ERR_NSOIL_UNSUPPORTED; return NOAHMP_ERR_NSOIL_UNSUPPORTED; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+
+  GwArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.T = g.d_tables;
+  k.ni = a->ime - a->ims + 1;
+  const int nj = a->jme - a->jms + 1;
+  k.deltat = a->wtddt * 60.f;                                                      // gw:89
+  k.zsoil[0] = 0.f;                                                                // gw:91-95
+  k.zsoil[1] = -a->dzs[0];
+  for (int l = 2; l <= NOAHMP_NSOIL; l++) k.zsoil[l] = -a->dzs[l - 1] + k.zsoil[l - 1];
+  for (int l = 0; l < NOAHMP_NSOIL; l++) k.dzs[l] = a->dzs[l];
+  k.a.dzs = nullptr;
+  k.hi0 = imax(a->its - 1, a->ids); k.hi1 = imin(a->ite + 1, a->ide - 1);         // gw:231-234
+  k.hj0 = imax(a->jts - 1, a->jds); k.hj1 = imin(a->jte + 1, a->jde - 1);
+  k.qi0 = imax(a->its, a->ids + 1); k.qi1 = imin(a->ite, a->ide - 2);             // gw:254-257
+  k.qj0 = imax(a->jts, a->jds + 1); k.qj1 = imin(a->jte, a->jde - 2);
+  // The reference indexes KCELL/HEAD(ims:ime,...) at these bounds too; a tile whose ring is not inside the
+  // caller's memory is a caller bug there (out-of-bounds) and a refused call here.
+  if (k.hi0 < a->ims || k.hi1 > a->ime || k.hj0 < a->jms || k.hj1 > a->jme ||
+      a->its < a->ims || a->ite > a->ime || a->jts < a->jms || a->jte > a->jme) {
+    g.last_error = "noahmp_hip_wtable_mmf: memory dims (ims:ime,jms:jme) do not hold the tile plus its 1-cell ring";
+    return -103;
+  }
+  const size_t plane = (size_t)k.ni * nj * sizeof(float);
+  {
+    size_t have = g.gw_plane_bytes;
+    rc = nmp_host::ensure_bytes((void**)&g.gw_kcell, &have, plane);
+    if (rc) return rc;
+    have = g.gw_plane_bytes;
+    rc = nmp_host::ensure_bytes((void**)&g.gw_head, &have, plane);
+    if (rc) return rc;
+    g.gw_plane_bytes = have;
+  }
+  k.kcell = g.gw_kcell;
+  k.head = g.gw_head;
+  k.err = g.d_err;
+  k.counts = g.d_counts;
+
+  if (mem == NOAHMP_MEM_HOST) {
+    if (g.gw_mirror.empty()) { g.gw_mirror.assign(kNW, nullptr); g.gw_mirror_bytes.assign(kNW, 0); }
+    for (int f = 0; f < kNW; f++) {
+      const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);
+      rc = nmp_host::ensure_bytes(&g.gw_mirror[f], &g.gw_mirror_bytes[f], bytes);
+      if (rc) return rc;
+      void* host = *(void* const*)((const char*)a + kW[f].off);
+      HIPCHK(hipMemcpyAsync(g.gw_mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      *(void**)((char*)&k.a + kW[f].off) = g.gw_mirror[f];
+    }
+  }
+
+  HIPCHK(hipMemsetAsync(g.d_counts, 0, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), s));
+  HIPCHK(hipEventRecord(g.ev0, s));
+  const int hni = k.hi1 - k.hi0 + 1, hnj = k.hj1 - k.hj0 + 1;
+  const int tni = a->ite - a->its + 1, tnj = a->jte - a->jts + 1;
+  if (hni > 0 && hnj > 0)
+    hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX - 1) / BX, (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
+  if (tni > 0 && tnj > 0)
+    hipLaunchKernelGGL(gw_column_kernel, dim3((tni + BX - 1) / BX, (tnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (mem == NOAHMP_MEM_HOST) {
+    for (int f = 0; f < kNW; f++) {
+      if (kW[f].io == 0) continue;
+      const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);
+      void* host = *(void* const*)((const char*)a + kW[f].off);
+      HIPCHK(hipMemcpyAsync(host, g.gw_mirror[f], bytes, hipMemcpyDeviceToHost, s));
+    }
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (st) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    st->kernel_ms = ms;
+    int cnt[4];
+    nmp_host::sum_counts(cnt);
+    st->n_land = cnt[0];
+    st->n_skipped = cnt[2];
+  }
+  return 0;
+}
+
+}  // extern "C"

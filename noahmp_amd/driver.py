@@ -50,5 +50,17 @@ class Engine:
             raise NoahMPFatal(rc, st.i, st.j, self.lib.noahmp_hip_error_string(rc).decode())
         return st
 
+    def wtable_mmf(self, store, stream=None):
+        """WTABLE_mmf_noahmp (reference gw:14): lateral groundwater flow + water-table update, in place.
+        A decomposed domain must have exchanged the ZWTXY halo first (parallel.exchange_halo)."""
+        w = store.wtable_args()
+        mem = abi.MEM_DEVICE if isinstance(store, DeviceColumnStore) else abi.MEM_HOST
+        st = abi.Status()
+        rc = self.lib.noahmp_hip_wtable_mmf(C.byref(w), mem, stream, C.byref(st))
+        self.last_status = st
+        if rc:
+            raise RuntimeError("noahmp_hip_wtable_mmf: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        return st
+
     def finalize(self):
         self.lib.noahmp_hip_finalize()

@@ -2,12 +2,13 @@
 
 Backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests.
 The column physics needs no data-path collective: these helpers only carry the tile
-assignment, the timing barrier and the metric reductions.  The ZWTXY halo of the MMF lateral-flow
-stencil is the only physics exchange and lives with that kernel.
+assignment, the timing barrier and the metric reductions.  The one physics exchange is the 1-cell
+ring LATERALFLOW reads (gw:231-252): ``exchange_halo`` below, ZWTXY before every groundwater call and
+the static FDEPTH / TOPO / ISLTYP planes once.
 """
 import os
 
-from .partition import partition, neighbours
+from .partition import partition, neighbours, tile_geometry
 
 
 class Comm:
@@ -35,6 +36,51 @@ class Comm:
 
     def my_neighbours(self):
         return neighbours(self.rank, self.world)
+
+    def my_geometry(self, global_nx, global_ny, halo=1):
+        return tile_geometry(global_nx, global_ny, self.world, self.rank, halo)
+
+    # ---- the one physics exchange
+    def exchange_halo(self, planes, geom):
+        """Fill the 1-cell ring of 2-D planes shaped (jme-jms+1, ime-ims+1) from the neighbouring ranks.
+
+        Two phases, so that corners arrive without diagonal messages (the stencil has diagonal terms,
+        gw:264-286): (1) left/right over the tile's rows, (2) down/up over full memory rows, which by
+        then carry the columns received in (1) -- the order mpp_land_comlr_real / comub_real use
+        (mpp:344-369, 603-613).  Planes are torch tensors: HBM tensors travel over RCCL send/recv (xGMI,
+        GPU-direct), CPU tensors over gloo.  <= 4 messages of a tile edge each per plane: latency-bound, so
+        all planes of a phase go out as one batch.
+        """
+        if not self.dist:
+            return
+        nb = self.my_neighbours()
+        i0, i1 = geom["its"] - geom["ims"], geom["ite"] - geom["ims"]
+        j0, j1 = geom["jts"] - geom["jms"], geom["jte"] - geom["jms"]
+        rows = slice(j0, j1 + 1)
+        self._exchange(planes, [(nb["left"], (rows, i0), (rows, i0 - 1)),
+                                (nb["right"], (rows, i1), (rows, i1 + 1))])
+        full = slice(None)
+        self._exchange(planes, [(nb["down"], (j0, full), (j0 - 1, full)),
+                                (nb["up"], (j1, full), (j1 + 1, full))])
+
+    def _exchange(self, planes, legs):
+        dist = self.dist
+        ops, landing = [], []
+        for peer, send_ix, recv_ix in legs:
+            if peer < 0:
+                continue
+            for p in planes:
+                sbuf = p[send_ix].contiguous()
+                rbuf = sbuf.new_empty(sbuf.shape)
+                ops.append(dist.P2POp(dist.isend, sbuf, peer))
+                ops.append(dist.P2POp(dist.irecv, rbuf, peer))
+                landing.append((p, recv_ix, rbuf))
+        if not ops:
+            return
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for p, recv_ix, rbuf in landing:
+            p[recv_ix] = rbuf
 
     # ---- timing / metric plumbing
     def _dev(self):

@@ -42,3 +42,16 @@ def neighbours(rank, nproc):
     ipx, ipy = rank % npx, rank // npx
     return dict(left=rank - 1 if ipx > 0 else -1, right=rank + 1 if ipx < npx - 1 else -1,
                 down=rank - npx if ipy > 0 else -1, up=rank + npx if ipy < npy - 1 else -1)
+
+
+def tile_geometry(global_nx, global_ny, nproc, rank, halo=1):
+    """WRF-style index block of one rank: domain ids..jde = the global grid, tile its..jte = the rank's
+    block, memory ims..jme = the tile plus `halo` cells towards every side that has a neighbour (so the
+    LATERALFLOW ring of gw:231-234 is addressable).  All 1-based inclusive."""
+    t = partition(global_nx, global_ny, nproc)[rank]
+    its, jts = t["startx"], t["starty"]
+    ite, jte = its + t["nx"] - 1, jts + t["ny"] - 1
+    return dict(ids=1, ide=global_nx, jds=1, jde=global_ny, kds=1, kde=2,
+                ims=max(its - halo, 1), ime=min(ite + halo, global_nx),
+                jms=max(jts - halo, 1), jme=min(jte + halo, global_ny), kms=1, kme=2,
+                its=its, ite=ite, jts=jts, jte=jte, kts=1, kte=1)

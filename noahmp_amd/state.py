@@ -13,8 +13,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-from .abi import StepArgs, FIELD_INFO, ARRAY_FIELDS, nlev
-from .abi_spec import STEP_FIELDS
+from .abi import StepArgs, WtableArgs, FIELD_INFO, ARRAY_FIELDS, nlev
+from .abi_spec import STEP_FIELDS, WTABLE_FIELDS
 
 
 @dataclass
@@ -42,6 +42,7 @@ class ModelConfig:
     iopt_stc: int = 1
     iz0tlnd: int = 0
     zlvl: float = 30.0       # namelist.F90:52 (always 30: SURVEY section 5 config bug)
+    wtddt: float = 30.0      # minutes between WTABLE_mmf_noahmp calls (hdrv:1227 STEPWTD = nint(WTDDT*60/DTBL))
 
     def options(self):
         return dict(idveg=self.idveg, iopt_crs=self.iopt_crs, iopt_btr=self.iopt_btr,
@@ -57,6 +58,15 @@ def field_shape(name, ni, nj, nsoil):
     if lev is None:
         return (nj, ni)
     return (nj, nlev(lev, nsoil), ni)
+
+
+# WTABLE_mmf_noahmp dummy -> store array, as the reference driver wires them (hdrv:420-436).
+GW_ALIAS = dict(smois="smois", sh2oxy="sh2o", smcwtd="smcwtdxy", wtd="zwtxy", deeprech="deeprechxy",
+                rech="rechxy", smoiseq="smoiseq", isltyp="isltyp", ivgtyp="ivgtyp", xland="xland",
+                xice="xice", dzs="dzs")
+# MMF-only planes (hdrv:240-252 FDEPTHXY, AREAXY, TERRAIN, RIVERCONDXY, RIVERBEDXY, EQZWT, PEXPXY, Q*XY)
+GW_EXTRA = ("fdepth", "area", "topo", "rivercond", "riverbed", "eqwtd", "pexp", "qrf", "qspring", "qslat",
+            "qrfs", "qsprings")
 
 
 def field_dtype(name):
@@ -75,6 +85,45 @@ class ColumnStore:
             self.a[n] = np.full(field_shape(n, ni, nj, ns), fill, dtype=field_dtype(n))
         self.a["dzs"][:] = np.asarray(self.cfg.dzs, dtype=np.float32)
         self.device = None
+        self.idx = None
+
+    # ------------------------------------------------------------------ index block
+    def set_index(self, **kw):
+        """Override the WRF index block (ids..kte).  Default: domain == memory == tile (hdrv:112-129).
+        A rank of a decomposed domain keeps a halo: ims = its-1 etc., ids..ide = the global domain."""
+        d = self.index()
+        d.update(kw)
+        assert d["ime"] - d["ims"] + 1 == self.ni and d["jme"] - d["jms"] + 1 == self.nj, "memory dims are fixed"
+        self.idx = d
+        return self
+
+    def index(self):
+        if getattr(self, "idx", None):
+            return dict(self.idx)
+        return dict(ids=1, ide=self.ni, jds=1, jde=self.nj, kds=1, kde=2,
+                    ims=1, ime=self.ni, jms=1, jme=self.nj, kms=1, kme=2,
+                    its=1, ite=self.ni, jts=1, jte=self.nj, kts=1, kte=1)
+
+    def add_groundwater(self):
+        """Allocate the planes only WTABLE_mmf_noahmp uses (OPT_RUN = 5)."""
+        for n in GW_EXTRA:
+            if n not in self.a:
+                self.a[n] = np.zeros((self.nj, self.ni), dtype=np.float32)
+        return self
+
+    def wtable_args(self):
+        """Pack a noahmp_wtable_args block (field order = WTABLE_mmf_noahmp dummy order, gw:14-22)."""
+        cfg = self.cfg
+        w = WtableArgs()
+        scal = dict(nsoil=cfg.nsoil, xice_threshold=cfg.xice_thres, isice=cfg.isice, wtddt=cfg.wtddt,
+                    isurban=cfg.isurban)
+        scal.update(self.index())
+        for n, k, lev, io, ln in WTABLE_FIELDS:
+            if k in ("pf", "pi"):
+                setattr(w, n, self.ptr(GW_ALIAS.get(n, n)))
+            else:
+                setattr(w, n, scal[n])
+        return w
 
     def __getitem__(self, k):
         return self.a[k]
@@ -89,6 +138,7 @@ class ColumnStore:
     def copy(self):
         o = ColumnStore.__new__(ColumnStore)
         o.ni, o.nj, o.cfg, o.device = self.ni, self.nj, self.cfg, None
+        o.idx = dict(self.idx) if self.idx else None
         o.a = {k: np.array(v, copy=True) for k, v in self.a.items()}
         return o
 
@@ -102,10 +152,7 @@ class ColumnStore:
         scal = dict(itimestep=itimestep, yr=yr, julian=julian, dt=cfg.dt, nsoil=cfg.nsoil, dx=cfg.dx,
                     xice_thres=cfg.xice_thres, isice=cfg.isice, isurban=cfg.isurban,
                     iz0tlnd=cfg.iz0tlnd, **cfg.options())
-        idx = dict(ids=1, ide=self.ni, jds=1, jde=self.nj, kds=1, kde=2,
-                   ims=1, ime=self.ni, jms=1, jme=self.nj, kms=1, kme=2,
-                   its=1, ite=self.ni, jts=1, jte=self.nj, kts=1, kte=1)
-        scal.update(idx)
+        scal.update(self.index())
         for n, k, lev, io, ln in STEP_FIELDS:
             if k in ("pf", "pi"):
                 setattr(s, n, self.ptr(n))
@@ -118,6 +165,7 @@ class ColumnStore:
         import torch
         d = DeviceColumnStore.__new__(DeviceColumnStore)
         d.ni, d.nj, d.cfg, d.device = self.ni, self.nj, self.cfg, torch.device(device)
+        d.idx = dict(self.idx) if self.idx else None
         d.a = {k: torch.from_numpy(np.ascontiguousarray(v)).to(d.device) for k, v in self.a.items()}
         d.a["dzs"] = np.array(self.a["dzs"], copy=True)   # config vector: always host memory at the ABI
         return d
@@ -133,6 +181,7 @@ class DeviceColumnStore(ColumnStore):
     def to_host(self):
         h = ColumnStore.__new__(ColumnStore)
         h.ni, h.nj, h.cfg, h.device = self.ni, self.nj, self.cfg, None
+        h.idx = dict(self.idx) if self.idx else None
         h.a = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v.detach().cpu().numpy())
                for k, v in self.a.items()}
         return h
@@ -140,6 +189,7 @@ class DeviceColumnStore(ColumnStore):
     def copy(self):
         o = DeviceColumnStore.__new__(DeviceColumnStore)
         o.ni, o.nj, o.cfg, o.device = self.ni, self.nj, self.cfg, self.device
+        o.idx = dict(self.idx) if self.idx else None
         o.a = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v.clone())
                for k, v in self.a.items()}
         return o

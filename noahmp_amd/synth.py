@@ -148,3 +148,49 @@ def mixed_small(tables, ni=64, nj=8, seed=7, cfg=None, **kw):
     return config3(tables, ni=ni, nj=nj, seed=seed, cfg=cfg,
                    snow_frac=kw.get("snow_frac", 0.4), urban_frac=kw.get("urban_frac", 0.05),
                    glacier_frac=kw.get("glacier_frac", 0.05))
+
+
+def groundwater_fields(store, tables_dict, seed=4, area=1.0e6, stress=0.0, water_frac=0.03):
+    """MMF planes for OPT_RUN=5: FDEPTH~U(50,200), TOPO = smooth random field,
+    EQZWT~U(-20,-1), RIVERCOND~U(0,1e-2), RIVERBED=EQZWT-1, PEXP=1, AREA=dx*dx.
+
+    The water table starts around its equilibrium depth with a spread that puts columns in all three
+    UPDATEWTD regimes (inside the 2 m soil column, in the layer below it, deep).  ``stress`` > 0 adds a
+    pending DEEPRECH of that standard deviation [m] so that multi-layer fills/drains are exercised too
+    (with AREA = 1 km2 the lateral and river fluxes alone move only ~1e-5 m of water per call).
+    """
+    r = _rng(seed)
+    store.add_groundwater()
+    a = store.a
+    nj, ni = store.nj, store.ni
+    shp = (nj, ni)
+    y, x = np.meshgrid(np.arange(nj, dtype=np.float64), np.arange(ni, dtype=np.float64), indexing="ij")
+    topo = 300.0 + 40.0 * np.sin(x / 17.0 + 0.3) * np.cos(y / 23.0) + 15.0 * np.sin((x + 2 * y) / 7.0)
+    a["topo"][...] = (topo + r.normal(0.0, 0.5, size=shp)).astype(F)
+    a["fdepth"][...] = r.uniform(50.0, 200.0, size=shp).astype(F)
+    a["fdepth"][r.random(size=shp) < 0.02] = 0.0                       # gw:239 FDEPTH <= 0 branch
+    a["area"][...] = F(area)
+    a["eqwtd"][...] = r.uniform(-20.0, -1.0, size=shp).astype(F)
+    a["rivercond"][...] = r.uniform(0.0, 1.0e-2, size=shp).astype(F)
+    a["riverbed"][...] = a["eqwtd"] - F(1.0)
+    a["pexp"][...] = 1.0
+    u = r.random(size=shp)
+    wtd = np.where(u < 0.4, r.uniform(-2.0, -0.02, size=shp),
+                   np.where(u < 0.6, r.uniform(-3.0, -2.0, size=shp), r.uniform(-20.0, -3.0, size=shp)))
+    a["zwtxy"][...] = wtd.astype(F)
+    smcmax = np.asarray(tables_dict["maxsmc"], dtype=F)[np.clip(a["isltyp"], 1, 19) - 1]
+    urban = a["ivgtyp"] == store.cfg.isurban
+    smcmax = np.where(urban, F(0.45), smcmax).astype(F)
+    for k in range(store.cfg.nsoil):
+        sm = np.minimum(a["smois"][:, k, :], smcmax)
+        a["smois"][:, k, :] = sm
+        a["sh2o"][:, k, :] = np.minimum(a["sh2o"][:, k, :], sm)
+        a["smoiseq"][:, k, :] = np.clip(sm * r.uniform(0.7, 1.1, size=shp).astype(F), F(0.02), smcmax * F(0.98))
+    a["smcwtdxy"][...] = (smcmax * r.uniform(0.4, 1.0, size=shp)).astype(F)
+    a["deeprechxy"][...] = (r.normal(0.0, 1.0e-5 + stress, size=shp)).astype(F)
+    a["rechxy"][...] = 0.0
+    for n in ("qrf", "qspring", "qslat", "qrfs", "qsprings"):
+        a[n][...] = 0.0
+    wat = r.random(size=shp) < water_frac
+    a["xland"][wat] = 2.0
+    return store

@@ -268,6 +268,8 @@ void nmp_sflx(nmp_ctx* c, nmp_column* s) {
 static noahmp_tables g_tables;
 static int g_have_tables = 0;
 
+const noahmp_tables* nmp_oracle_tables(void) { return g_have_tables ? &g_tables : 0; }
+
 int nmp_oracle_set_tables(const noahmp_tables* t) {
   g_tables = *t;
   g_have_tables = 1;

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 import subprocess
 
-from noahmp_amd.abi import StepArgs, Tables, Status
+from noahmp_amd.abi import StepArgs, Tables, Status, WtableArgs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_PATH = os.path.join(_HERE, "_build", "libnoahmp_oracle.so")
@@ -23,6 +23,7 @@ class PortLib:
         self.lib = C.CDLL(PORT_PATH)
         self.lib.nmp_oracle_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.nmp_oracle_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
+        self.lib.nmp_oracle_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, tables):
         self.lib.nmp_oracle_set_tables(C.byref(tables))
@@ -31,4 +32,11 @@ class PortLib:
         a = store.step_args(itimestep, yr, julian)
         st = Status()
         self.lib.nmp_oracle_step(C.byref(a), C.byref(st))
+        return st
+
+    def wtable_mmf(self, store):
+        w = store.wtable_args()
+        st = Status()
+        rc = self.lib.nmp_oracle_wtable_mmf(C.byref(w), C.byref(st))
+        assert rc == 0, rc
         return st

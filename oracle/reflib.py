@@ -7,7 +7,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 import ctypes as C
 import os
 
-from noahmp_amd.abi import StepArgs, Tables, tables_to_dict
+from noahmp_amd.abi import StepArgs, Tables, WtableArgs, tables_to_dict
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REF_DIR = os.path.join(_HERE, "_ref")
@@ -35,6 +35,7 @@ class RefLib:
         self.lib.ref_noahmplsm.argtypes = [C.POINTER(StepArgs)]
         self.lib.ref_get_tables.argtypes = [C.POINTER(Tables)]
         self.lib.ref_set_tables.argtypes = [C.POINTER(Tables)]
+        self.lib.ref_wtable_mmf.argtypes = [C.POINTER(WtableArgs)]
         self.tables_loaded = False
 
     def read_tables(self, run_dir=REF_RUN_DIR, modis=False):
@@ -78,3 +79,9 @@ class RefLib:
         assert self.tables_loaded
         a = store.step_args(itimestep, yr, julian)
         self.lib.ref_noahmplsm(C.byref(a))
+
+    def wtable_mmf(self, store):
+        """WTABLE_mmf_noahmp of the compiled reference (gw:14) on the store's arrays."""
+        assert self.tables_loaded
+        w = store.wtable_args()
+        self.lib.ref_wtable_mmf(C.byref(w))

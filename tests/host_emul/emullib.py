@@ -3,7 +3,7 @@ import ctypes as C
 import os
 import subprocess
 
-from noahmp_amd.abi import StepArgs, Tables, Status
+from noahmp_amd.abi import StepArgs, Tables, Status, WtableArgs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(_HERE))
@@ -27,6 +27,7 @@ class EmulLib:
         self.lib = C.CDLL(LIB)
         self.lib.emul_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
+        self.lib.emul_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, t):
         self.lib.emul_set_tables(C.byref(t))
@@ -35,4 +36,11 @@ class EmulLib:
         a = store.step_args(itimestep, yr, julian)
         st = Status()
         self.lib.emul_step(C.byref(a), C.byref(st))
+        return st
+
+    def wtable_mmf(self, store):
+        w = store.wtable_args()
+        st = Status()
+        rc = self.lib.emul_wtable_mmf(C.byref(w), C.byref(st))
+        assert rc == 0, rc
         return st

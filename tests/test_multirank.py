@@ -104,3 +104,75 @@ def test_ranks_cover_domain_and_match_single_process(world, port, tables):
         x0, y0 = tile["startx"] - 1, tile["starty"] - 1
         for k, v in part.items():
             np.testing.assert_array_equal(g.a[k][y0:y0 + tile["ny"], ..., x0:x0 + tile["nx"]], v, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------
+# the ZWTXY halo exchange of the MMF lateral-flow stencil over torch.distributed (gloo here,
+# RCCL on the GPUs).  Parity target: the single-domain sequential oracle.
+def _gw_worker(rank, world, port, gx, gy, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    from noahmp_amd.parallel import Comm
+    from noahmp_amd.state import ColumnStore
+    from noahmp_amd.tables import load_tables
+    from oracle.portlib import PortLib
+    from test_groundwater import gw_store, GW_OUT
+    comm = Comm(backend="gloo")
+    tabs = load_tables("usgs")
+    port_ = PortLib(autobuild=False)
+    port_.set_tables(tabs[0])
+    g = gw_store(tabs, ni=gx, nj=gy, stress=0.02)          # every rank builds the same global fields
+    geo = comm.my_geometry(gx, gy)
+    ims, ime, jms, jme = geo["ims"], geo["ime"], geo["jms"], geo["jme"]
+    its, ite, jts, jte = geo["its"], geo["ite"], geo["jts"], geo["jte"]
+    loc = ColumnStore(ime - ims + 1, jme - jms + 1, g.cfg).add_groundwater()
+    for k, v in g.a.items():
+        if k != "dzs":
+            loc.a[k][...] = v[jms - 1:jme, ..., ims - 1:ime]
+    loc.set_index(**geo)
+    # poison the ring: only the exchange may provide it
+    ring = np.ones((loc.nj, loc.ni), dtype=bool)
+    ring[jts - jms:jte - jms + 1, its - ims:ite - ims + 1] = False
+    for k in ("zwtxy", "fdepth", "topo"):
+        loc.a[k][ring] = np.nan
+    loc.a["isltyp"][ring] = -7
+    static = [torch.from_numpy(loc.a[k]) for k in ("fdepth", "topo", "isltyp")]   # views: exchanged in place
+    comm.exchange_halo(static, geo)                                               # once (static planes)
+    wtd = torch.from_numpy(loc.a["zwtxy"])
+    for call in range(3):
+        comm.exchange_halo([wtd], geo)                                            # before every call
+        port_.wtable_mmf(loc)
+        loc.a["deeprechxy"][...] = g.a["deeprechxy"][jms - 1:jme, ims - 1:ime]
+    part = {k: loc.a[k][jts - jms:jte - jms + 1, ..., its - ims:ite - ims + 1].copy() for k in GW_OUT}
+    parts = comm.gather_to_root((geo, part))
+    if rank == 0:
+        q.put(parts)
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_groundwater_halo_exchange_matches_single_domain(world, port, tables):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_groundwater import gw_store, GW_OUT
+    gx, gy = 37, 26
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = _free_port()
+    procs = [ctx.Process(target=_gw_worker, args=(r, world, p, gx, gy, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    parts = q.get(timeout=240)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    g = gw_store(tables, ni=gx, nj=gy, stress=0.02)
+    d0 = g.a["deeprechxy"].copy()
+    for call in range(3):
+        port.wtable_mmf(g)
+        g.a["deeprechxy"][...] = d0
+    for geo, part in parts:
+        for k in GW_OUT:
+            want = g.a[k][geo["jts"] - 1:geo["jte"], ..., geo["its"] - 1:geo["ite"]]
+            np.testing.assert_array_equal(want, part[k], err_msg="%s tile its=%d jts=%d" % (k, geo["its"], geo["jts"]))

@@ -252,3 +252,148 @@ def test_unsupported_options_are_rejected(engine, tables):
     with pytest.raises(NoahMPFatal) as e:
         engine.noahmplsm(s, 1, 2000, 180.0)
     assert e.value.code == 11
+
+
+# ------------------------------------------------------------------------------------------------
+# MMF groundwater: noahmp_hip_wtable_mmf vs the oracle of WTABLE_mmf_noahmp (gw:14-606)
+from test_groundwater import gw_store, GW_OUT, CASES  # noqa: E402
+
+# The device differs from the oracle's glibc only in expf/powf (ocml, <= 1-2 ulp) feeding a few dozen
+# float32 operations, so the deviations are ulp-level: rtol 5e-6.  QSLAT and RECH are sums of cancelling
+# terms (8 stencil fluxes; recharge minus its clamps), so an ulp of a term is a larger relative error of the
+# sum: they get an absolute allowance of 1e-4 of the field's rms on top.
+GW_TOL = {n: (5e-6, 1e-7) for n in GW_OUT}
+GW_TOL.update(qslat=(1e-5, 1e-4), rechxy=(1e-5, 1e-4), deeprechxy=(1e-5, 1e-4),
+              qspring=(2e-5, 1e-5), qsprings=(2e-5, 1e-5))   # QSPRING = what is left after all capacities are subtracted
+
+
+def _gw_close(ref, test, what=""):
+    """Every cell within 20x the tolerance; all but 1e-4 of the cells (at least 3) within the tolerance itself:
+    the deep-recharge update (gw:147-161) subtracts two large fluxes and divides by the distance to the water
+    table, which amplifies an ulp of powf by 10-100x in a handful of cells of the 1 m stress case."""
+    for n in GW_OUT:
+        x, y = ref.a[n].astype(np.float64), test.a[n].astype(np.float64)
+        rtol, arms = GW_TOL[n]
+        tol = rtol * np.abs(x) + arms * max(float(np.sqrt(np.mean(x * x))), 1e-30) + 1e-30
+        d = np.abs(x - y)
+        bad = ~(d <= tol)
+        worse = ~(d <= 20 * tol)
+        msg = "%s %s: %d cells out of tolerance (%d beyond 20x), worst |d|=%g at value %g" % (
+            what, n, int(bad.sum()), int(worse.sum()), float(d[bad].max()) if bad.any() else 0.0,
+            float(x[bad][d[bad].argmax()]) if bad.any() else 0.0)
+        assert not worse.any(), msg
+        assert bad.sum() <= max(3, 1e-4 * x.size), msg
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "stress%g_area%g" % (c["stress"], c["area"]))
+def test_groundwater_vs_oracle(engine, port, tables, case):
+    s0 = gw_store(tables, ni=256, nj=128, **case)
+    a = s0.copy()
+    for call in range(3):
+        b = a.copy()                                  # the GPU restarts from the oracle's state each call
+        so = port.wtable_mmf(a)
+        sg = engine.wtable_mmf(b)
+        assert sg.n_land == so.n_land and sg.n_skipped == so.n_skipped
+        _gw_close(a, b, what="call %d" % call)
+        a.a["deeprechxy"][...] = s0.a["deeprechxy"]
+
+
+def test_groundwater_golden_fixture(engine):
+    """The committed reference output (tests/golden/make_golden_gw.py, compiled reference)."""
+    from noahmp_amd.state import ColumnStore
+    z = np.load(os.path.join(GOLDEN, "golden_gw.npz"))
+    ni, nj = int(z["ni"]), int(z["nj"])
+    s = ColumnStore(ni, nj, ModelConfig(iopt_run=5)).add_groundwater()
+    for k in s.a:
+        if "in/" + k in z:
+            s.a[k][...] = z["in/" + k]
+    want = s.copy()
+    for n in GW_OUT:
+        want.a[n][...] = z["out/" + n]
+    engine.wtable_mmf(s)
+    _gw_close(want, s, what="golden")
+
+
+def test_groundwater_host_and_device_paths_bit_identical(engine, tables):
+    s = gw_store(tables, ni=96, nj=40, stress=0.02)
+    h = s.copy()
+    d = s.to_device("cuda:0")
+    engine.wtable_mmf(h)
+    engine.wtable_mmf(d)
+    dh = d.to_host()
+    for k in GW_OUT:
+        np.testing.assert_array_equal(h.a[k], dh.a[k], err_msg=k)
+    for k in ("fdepth", "topo", "eqwtd", "smoiseq", "isltyp"):       # IN planes are not written
+        np.testing.assert_array_equal(s.a[k], dh.a[k], err_msg=k)
+
+
+def _run_tiles(engine, s0, nproc):
+    """Each 'rank' gets its tile + 1-cell ring cut from the global state (what exchange_halo delivers)."""
+    from noahmp_amd.partition import tile_geometry
+    from noahmp_amd.state import ColumnStore
+    out = s0.copy()
+    for rank in range(nproc):
+        geo = tile_geometry(s0.ni, s0.nj, nproc, rank)
+        ims, ime, jms, jme = geo["ims"], geo["ime"], geo["jms"], geo["jme"]
+        its, ite, jts, jte = geo["its"], geo["ite"], geo["jts"], geo["jte"]
+        loc = ColumnStore(ime - ims + 1, jme - jms + 1, s0.cfg).add_groundwater()
+        for k in set(loc.a) & (set(GW_OUT) | {"fdepth", "topo", "isltyp", "ivgtyp", "xland", "xice", "area",
+                                            "eqwtd", "rivercond", "riverbed", "pexp", "smoiseq"}):
+            loc.a[k][...] = s0.a[k][jms - 1:jme, ..., ims - 1:ime]
+        loc.set_index(**geo)
+        engine.wtable_mmf(loc)
+        for k in GW_OUT:
+            out.a[k][jts - 1:jte, ..., its - 1:ite] = loc.a[k][jts - jms:jte - jms + 1, ..., its - ims:ite - ims + 1]
+    return out
+
+
+def test_groundwater_decomposition_invariance(engine, tables):
+    """SURVEY 8e parity target: tiles with a ZWTXY ring reproduce the single-domain result bit for bit."""
+    s0 = gw_store(tables, ni=101, nj=67, stress=0.02)
+    whole = s0.copy()
+    engine.wtable_mmf(whole)
+    for nproc in (2, 4, 8):
+        out = _run_tiles(engine, s0, nproc)
+        for k in GW_OUT:
+            np.testing.assert_array_equal(whole.a[k], out.a[k], err_msg="%s nproc=%d" % (k, nproc))
+
+
+def test_groundwater_refuses_tile_without_ring(engine, tables):
+    import ctypes as C
+    from noahmp_amd import abi
+    s = gw_store(tables, ni=32, nj=16)
+    w = s.wtable_args()
+    w.ids, w.ide = -10, 100                    # tile is interior to the domain but memory has no ring
+    st = abi.Status()
+    rc = engine.lib.noahmp_hip_wtable_mmf(C.byref(w), abi.MEM_HOST, None, C.byref(st))
+    assert rc == -103 and b"ring" in engine.lib.noahmp_hip_last_error()
+
+
+def test_groundwater_full_size_config4(engine, port, tables):
+    """BASELINE config-4 grid (4608 x 1536 = 7.08 M cells): the whole field against the oracle, plus the
+    8-rank (4 x 2, mpp rule) decomposition against the single domain, bit for bit."""
+    from noahmp_amd.state import ColumnStore
+    ni, nj = 4608, 1536
+    cfg = ModelConfig(iopt_run=5)
+    r = np.random.default_rng(44)
+    s = ColumnStore(ni, nj, cfg).add_groundwater()
+    a = s.a
+    a["ivgtyp"][...] = synth.CONUS_VEG[r.integers(0, len(synth.CONUS_VEG), size=(nj, ni))]
+    a["isltyp"][...] = r.integers(1, 13, size=(nj, ni)).astype(np.int32)
+    a["xland"][...] = 1.0
+    for k, sm in enumerate((0.25, 0.27, 0.30, 0.31)):
+        a["smois"][:, k, :] = np.float32(sm) + r.uniform(-0.05, 0.05, size=(nj, ni)).astype(np.float32)
+        a["sh2o"][:, k, :] = a["smois"][:, k, :] * np.float32(0.9)
+    synth.groundwater_fields(s, tables[1], seed=45, stress=0.02)
+    s.a = {k: s.a[k] for k in set(GW_OUT) | {"fdepth", "topo", "isltyp", "ivgtyp", "xland", "xice", "area", "eqwtd",
+                                            "rivercond", "riverbed", "pexp", "smoiseq", "dzs"}}
+    # (the planes the groundwater step never touches are dropped: 3 copies of 118 full-size fields is 10 GB)
+    o = s.copy()
+    g = s.copy()
+    so = port.wtable_mmf(o)
+    sg = engine.wtable_mmf(g)
+    assert sg.n_land == so.n_land > 6_000_000
+    _gw_close(o, g, what="full size")
+    out = _run_tiles(engine, s, 8)
+    for k in GW_OUT:
+        np.testing.assert_array_equal(g.a[k], out.a[k], err_msg=k)
