@@ -45,31 +45,45 @@ NMP_DEV float powi3(float a) { return a * (a * a); }
 NMP_DEV float powi4(float a) { float b = a * a; return b * b; }
 NMP_DEV float powi5(float a) { float b = a * a; return a * (b * b); }
 
-// x**0.25, x**0.5, x**-0.25 with a literal exponent.  On the GPU: IEEE sqrt chains (each step correctly
-// rounded, total <= 0.75 ulp, ~10 VALU ops) instead of ocml powf (~1 ulp, ~70 ops); these sit inside the
-// 20-iteration canopy loop (SFCDIF1, RAGRB).  The host emulation keeps powf so that it stays bit-identical
-// with the oracle, whose glibc powf is correctly rounded.
-NMP_DEV float pow_quarter(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return sqrtf(sqrtf(x));
-#else
-  return powf(x, 0.25f);
+// Transcendentals.  NMP_EXACT_LIBM=1 (default): the reference libm's own algorithms (nmp_libm.hpp), so that
+// EXP / LOG / ** / LOG10 / ATAN / TANH return the reference's bits on the GPU.  NMP_EXACT_LIBM=0: ocml's
+// float32 routines (<= 1-2 ulp, a little faster, statistically equivalent results -- DESIGN.md section 5).
+#ifndef NMP_EXACT_LIBM
+#define NMP_EXACT_LIBM 1
 #endif
-}
-NMP_DEV float pow_half(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return sqrtf(x);
+}  // namespace nmp
+#include "nmp_libm.hpp"
+namespace nmp {
+#if defined(NMP_LIBM_COUNT) && !defined(__HIP_DEVICE_COMPILE__)
+// host-emulation instrumentation (tests/host_emul): dynamic call counts per routine
+extern "C" long nmp_libm_calls[8];
+#define NMP_CNT(i) (nmp_libm_calls[i]++)
 #else
-  return powf(x, 0.5f);
+#define NMP_CNT(i) ((void)0)
 #endif
-}
-NMP_DEV float pow_neg_quarter(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return 1.0f / sqrtf(sqrtf(x));
+#if NMP_EXACT_LIBM
+NMP_DEV float nmp_expf(float x) { NMP_CNT(0); return libm::expf_(x); }
+NMP_DEV float nmp_logf(float x) { NMP_CNT(1); return libm::logf_(x); }
+NMP_DEV float nmp_powf(float x, float y) { NMP_CNT(2); return libm::powf_(x, y); }
+NMP_DEV float nmp_log10f(float x) { NMP_CNT(3); return libm::log10f_(x); }
+NMP_DEV float nmp_atanf(float x) { NMP_CNT(4); return libm::atanf_(x); }
+NMP_DEV float nmp_tanhf(float x) { NMP_CNT(5); return libm::tanhf_(x); }
+// x**0.25, x**0.5, x**-0.25 with a literal exponent (SFCDIF1, RAGRB): the reference calls powf
+NMP_DEV float pow_quarter(float x) { NMP_CNT(6); return libm::powf_(x, 0.25f); }
+NMP_DEV float pow_half(float x) { NMP_CNT(6); return libm::powf_(x, 0.5f); }
+NMP_DEV float pow_neg_quarter(float x) { NMP_CNT(6); return libm::powf_(x, -0.25f); }
 #else
-  return powf(x, -0.25f);
+NMP_DEV float nmp_expf(float x) { return expf(x); }
+NMP_DEV float nmp_logf(float x) { return logf(x); }
+NMP_DEV float nmp_powf(float x, float y) { return powf(x, y); }
+NMP_DEV float nmp_log10f(float x) { return log10f(x); }
+NMP_DEV float nmp_atanf(float x) { return atanf(x); }
+NMP_DEV float nmp_tanhf(float x) { return tanhf(x); }
+// IEEE sqrt chains (each step correctly rounded, total <= 0.75 ulp, ~10 VALU ops) instead of ocml powf
+NMP_DEV float pow_quarter(float x) { return sqrtf(sqrtf(x)); }
+NMP_DEV float pow_half(float x) { return sqrtf(x); }
+NMP_DEV float pow_neg_quarter(float x) { return 1.0f / sqrtf(sqrtf(x)); }
 #endif
-}
 
 struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)
   int dveg, crs, btr, run, sfc, frz, inf, rad, alb, snf, tbot, stc;

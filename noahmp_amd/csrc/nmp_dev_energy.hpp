@@ -25,15 +25,15 @@ NMP_DEV float tdc(float t) { return fminf(50.f, fmaxf(-50.f, (t - TFRZ))); }   /
 // TDFCND lsm:2014-2118
 NMP_DEV float tdfcnd(const Parm& P, float smc, float sh2o) {
   float satratio = smc / P.smcmax;
-  float thks = powf(7.7f, P.quartz) * powf(2.0f, 1.f - P.quartz);
+  float thks = nmp_powf(7.7f, P.quartz) * nmp_powf(2.0f, 1.f - P.quartz);
   float xunfroz = sh2o / smc;
   float xu = xunfroz * P.smcmax;
-  float thksat = powf(thks, 1.f - P.smcmax) * powf(TKICE, P.smcmax - xu) * powf(0.57f, xu);
+  float thksat = nmp_powf(thks, 1.f - P.smcmax) * nmp_powf(TKICE, P.smcmax - xu) * nmp_powf(0.57f, xu);
   float gammd = (1.f - P.smcmax) * 2700.f;
   float thkdry = (0.135f * gammd + 64.7f) / (2700.f - 0.947f * gammd);
   float ake;
   if ((sh2o + 0.0005f) < smc) ake = satratio;
-  else ake = (satratio > 0.1f) ? (log10f(satratio) + 1.0f) : 0.0f;
+  else ake = (satratio > 0.1f) ? (nmp_log10f(satratio) + 1.0f) : 0.0f;
   return ake * (thksat - thkdry) + thkdry;
 }
 
@@ -78,8 +78,8 @@ NMP_DEV void snow_age(float dt, float tg, float sneqvo, float sneqv, float& taus
   else {
     float dela0 = 1.E-6f * dt;
     float arg = 5.E3f * (1.f / TFRZ - 1.f / tg);
-    float age1 = expf(arg);
-    float age2 = expf(fminf(0.f, 10.f * arg));
+    float age1 = nmp_expf(arg);
+    float age2 = nmp_expf(fminf(0.f, 10.f * arg));
     float tage = age1 + age2 + 0.3f;
     float dela = dela0 * tage;
     float dels = fmaxf(0.0f, sneqv - sneqvo) / SWEMX;
@@ -104,14 +104,14 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
     gap = 0.f; kopen = 0.f;
     if (c.O.rad == 1) {
       float rc = T->rc[v];
-      float denfveg = -logf(fmaxf(1.0f - fveg, 0.01f)) / (PAI * powi2(rc));
+      float denfveg = -nmp_logf(fmaxf(1.0f - fveg, 0.01f)) / (PAI * powi2(rc));
       float hd = T->hvt[v] - T->hvb[v];
       float bb = 0.5f * hd;
-      float thetap = atanf(bb / rc * tanf(acosf(fmaxf(0.01f, cosz))));
-      bgap = expf(-denfveg * PAI * powi2(rc) / cosf(thetap));
-      float fa = vai / (1.33f * PAI * powf(rc, 3.0f) * (bb / rc) * denfveg);
+      float thetap = nmp_atanf(bb / rc * tanf(acosf(fmaxf(0.01f, cosz))));
+      bgap = nmp_expf(-denfveg * PAI * powi2(rc) / cosf(thetap));
+      float fa = vai / (1.33f * PAI * nmp_powf(rc, 3.0f) * (bb / rc) * denfveg);
       float newvai = hd * fa;
-      wgap = (1.0f - bgap) * expf(-0.5f * newvai / cosz);
+      wgap = (1.0f - bgap) * nmp_expf(-0.5f * newvai / cosz);
       gap = fminf(1.0f - fveg, bgap + wgap);
       kopen = 0.05f;
     }
@@ -125,11 +125,11 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
   float phi2 = 0.877f * (1.f - 2.f * phi1);
   gdir = phi1 + phi2 * coszi;
   float ext = gdir / coszi;
-  float avmu = (1.f - phi1 / phi2 * logf((phi1 + phi2) / phi1)) / phi2;
+  float avmu = (1.f - phi1 / phi2 * nmp_logf((phi1 + phi2) / phi1)) / phi2;
   float omegal = rho + tau;
   float tmp0 = gdir + phi2 * coszi;
   float tmp1 = phi1 * coszi;
-  float asu = 0.5f * omegal * gdir / tmp0 * (1.f - tmp1 / tmp0 * logf((tmp1 + tmp0) / tmp1));
+  float asu = 0.5f * omegal * gdir / tmp0 * (1.f - tmp1 / tmp0 * nmp_logf((tmp1 + tmp0) / tmp1));
   float betadl = (1.f + avmu * ext) / (omegal * avmu * ext) * asu;
   float betail = 0.5f * (rho + tau + (rho - tau) * powi2((1.f + chil) / 2.f)) / omegal;
   float tmp2;
@@ -151,7 +151,7 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
   float sigma = tmp0 * tmp0 - tmp1;
   if (fabsf(sigma) < 1.e-6f) sigma = copysignf(1.e-6f, sigma);
   float p1 = b + avmu * h, p2 = b - avmu * h, p3 = b + tmp0, p4 = b - tmp0;
-  float s1 = expf(-h * vai), s2 = expf(-ext * vai);
+  float s1 = nmp_expf(-h * vai), s2 = nmp_expf(-ext * vai);
   float alb = (ic == 0) ? albgrd : albgri;
   float u1 = b - cc / alb, u2 = b - cc * alb, u3 = f + cc * alb;
   tmp2 = u1 - avmu * h;
@@ -225,7 +225,7 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
       albsnd[0] = albsni[0] + 0.4f * fzen * (1.f - albsni[0]);
       albsnd[1] = albsni[1] + 0.4f * fzen * (1.f - albsni[1]);
     } else {                                            // SNOWALB_CLASS lsm:2652-2700
-      float alb = 0.55f + (s.albold - 0.55f) * expf(-0.01f * c.dt / 3600.f);
+      float alb = 0.55f + (s.albold - 0.55f) * nmp_expf(-0.01f * c.dt / 3600.f);
       if (s.qsnow > 0.f) alb = alb + fminf(s.qsnow * c.dt, SWEMX) * (0.84f - alb) / (SWEMX);
       albsni[0] = albsni[1] = albsnd[0] = albsnd[1] = alb;
       s.albold = alb;
@@ -253,7 +253,7 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
       }
     }
     float ext = gdir / s.cosz * sqrtf(1.f - rho[0] - tau[0]);
-    fsun = (1.f - expf(-ext * vai)) / fmaxf(ext * vai, MPE);
+    fsun = (1.f - nmp_expf(-ext * vai)) / fmaxf(ext * vai, MPE);
     if (fsun < 0.01f) fsun = 0.f;
   }
   RadOut r;
@@ -301,10 +301,10 @@ NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, floa
   float mozold = m.moz;
   float moz2, fmnew, fhnew, fm2new, fh2new;
   if (zlvl <= zpd) { raise(s, NOAHMP_ERR_STABILITY_STOP); }
-  float tmpcm = logf((zlvl - zpd) / z0m);
-  float tmpch = logf((zlvl - zpd) / z0h);
-  float tmpcm2 = logf((2.0f + z0m) / z0m);
-  float tmpch2 = logf((2.0f + z0h) / z0h);
+  float tmpcm = nmp_logf((zlvl - zpd) / z0m);
+  float tmpch = nmp_logf((zlvl - zpd) / z0h);
+  float tmpcm2 = nmp_logf((2.0f + z0m) / z0m);
+  float tmpch2 = nmp_logf((2.0f + z0h) / z0h);
   if (iter == 1) {
     m.fv = 0.0f; m.moz = 0.0f; moz2 = 0.0f;
   } else {
@@ -319,14 +319,14 @@ NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, floa
   if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
   if (m.moz < 0.f) {
     float tmp1 = pow_quarter(1.f - 16.f * m.moz);
-    float tmp2 = logf((1.f + tmp1 * tmp1) / 2.f);
-    float tmp3 = logf((1.f + tmp1) / 2.f);
-    fmnew = 2.f * tmp3 + tmp2 - 2.f * atanf(tmp1) + 1.5707963f;
+    float tmp2 = nmp_logf((1.f + tmp1 * tmp1) / 2.f);
+    float tmp3 = nmp_logf((1.f + tmp1) / 2.f);
+    fmnew = 2.f * tmp3 + tmp2 - 2.f * nmp_atanf(tmp1) + 1.5707963f;
     fhnew = 2 * tmp2;
     float tmp12 = pow_quarter(1.f - 16.f * moz2);
-    float tmp22 = logf((1.f + tmp12 * tmp12) / 2.f);
-    float tmp32 = logf((1.f + tmp12) / 2.f);
-    fm2new = 2.f * tmp32 + tmp22 - 2.f * atanf(tmp12) + 1.5707963f;
+    float tmp22 = nmp_logf((1.f + tmp12 * tmp12) / 2.f);
+    float tmp32 = nmp_logf((1.f + tmp12) / 2.f);
+    fm2new = 2.f * tmp32 + tmp22 - 2.f * nmp_atanf(tmp12) + 1.5707963f;
     fh2new = 2 * tmp22;
   } else {
     fmnew = -5.f * m.moz; fhnew = fmnew;
@@ -354,10 +354,10 @@ NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, floa
 
 // SFCDIF2 lsm:4224-4422
 NMP_DEV float pspmu(float xx) {
-  return -2.f * logf((xx + 1.f) * 0.5f) - logf((xx * xx + 1.f) * 0.5f) + 2.f * atanf(xx) -
+  return -2.f * nmp_logf((xx + 1.f) * 0.5f) - nmp_logf((xx * xx + 1.f) * 0.5f) + 2.f * nmp_atanf(xx) -
          (3.14159265f / 2.f);
 }
-NMP_DEV float psphu(float xx) { return -2.f * logf((xx * xx + 1.f) * 0.5f); }
+NMP_DEV float psphu(float xx) { return -2.f * nmp_logf((xx * xx + 1.f) * 0.5f); }
 
 NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, float czil, float zlm,
                      float& akms, float& akhs, float& rlmo, float& wstar2, float& ustar) {
@@ -372,16 +372,16 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   float du2 = fmaxf(sfcspd * sfcspd, EPSU2);
   float btgh = BTG * HPBL;
   if (iter == 1) {
-    if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
+    if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * nmp_powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
     else wstar2 = 0.0f;
     ustar = fmaxf(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
     rlmo = ELFC * akhs * dthv / powi3(ustar);
   }
-  float zt = fmaxf(1.E-6f, expf(zilfc * sqrtf(ustar * z0)) * z0);
+  float zt = fmaxf(1.E-6f, nmp_expf(zilfc * sqrtf(ustar * z0)) * z0);
   float zslu = zlm + zu;
   float zslt = zlm + zt;
-  float rlogu = logf(zslu / zu);
-  float rlogt = logf(zslt / zt);
+  float rlogu = nmp_logf(zslu / zu);
+  float rlogt = nmp_logf(zslt / zt);
   float zetalt = fmaxf(zslt * rlmo, ZTMIN);
   rlmo = zetalt / zslt;
   float zetalu = zslu * rlmo;
@@ -407,7 +407,7 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   float ustark = ustar * VKRM;
   akms = fmaxf(ustark / simm, cxch);
   akhs = fmaxf(ustark / simh, cxch);
-  if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
+  if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * nmp_powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
   else wstar2 = 0.0f;
   float rlmn = ELFC * akhs * dthv / powi3(ustar);
   rlmo = rlmo * WOLD + rlmn * WNEW;
@@ -428,12 +428,12 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
   float tc = tv - TFRZ;
   float ppf = 4.6f * apar;
   float j = ppf * T->qe25[v];
-  float kc = T->kc25[v] * powf(T->akc[v], (tc - 25.0f) / 10.0f);
-  float ko = T->ko25[v] * powf(T->ako[v], (tc - 25.0f) / 10.0f);
+  float kc = T->kc25[v] * nmp_powf(T->akc[v], (tc - 25.0f) / 10.0f);
+  float ko = T->ko25[v] * nmp_powf(T->ako[v], (tc - 25.0f) / 10.0f);
   float awc = kc * (1.0f + o2 / ko);
   float cp = 0.5f * kc / ko * o2 * 0.21f;
-  float vcmx = T->vcmx25[v] / (1.0f + expf((-2.2E05f + 710.0f * (tc + TFRZ)) / (8.314f * (tc + TFRZ)))) *
-               fnf * btran * powf(T->avcmx[v], (tc - 25.0f) / 10.0f);
+  float vcmx = T->vcmx25[v] / (1.0f + nmp_expf((-2.2E05f + 710.0f * (tc + TFRZ)) / (8.314f * (tc + TFRZ)))) *
+               fnf * btran * nmp_powf(T->avcmx[v], (tc - 25.0f) / 10.0f);
   float rlb = rb / cf;
   float cihi = 1.5f * co2, cilow = 0.0f;
 #pragma unroll 1
@@ -465,7 +465,7 @@ NMP_DEV void canres(const Parm& P, float par, float sfctmp, float rcsoil, float 
                     float& rc, float& psn) {
   float q2 = 0.622f * eah / (sfcprs - 0.378f * eah);
   q2 = q2 / (1.0f + q2);
-  float es = 0.611f * expf(2.501E6f / 461.0f * (1.f / 273.15f - 1.f / sfctmp));
+  float es = 0.611f * nmp_expf(2.501E6f / 461.0f * (1.f / 273.15f - 1.f / sfctmp));
   float sfcprsx = sfcprs * 1.E-3f;
   float q2sat = 0.622f * es / (sfcprsx - es);
   q2sat = q2sat * 1.E3f;
@@ -511,7 +511,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   estg = (t > 0.f) ? esatw : esati;
   s.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
   const float hcan = s.htop;
-  float uc = ur * logf(hcan / q.z0m) / logf(q.zlvl / q.z0m);
+  float uc = ur * nmp_logf(hcan / q.z0m) / nmp_logf(q.zlvl / q.z0m);
   if ((hcan - q.zpd) <= 0.f) raise(s, NOAHMP_ERR_HCAN_LE_ZPD);
   float air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(tg);
   float cir = (2.f - q.emv * (1.f - q.emg)) * q.emv * SB;
@@ -540,13 +540,13 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
       if (iter == 1) fhg = fhgnew;
       else fhg = 0.5f * (fhg + fhgnew);
       float cwpc = pow_half(q.cwp * vaie * hcan * fhg);
-      float tmp1 = expf(-cwpc * z0hg / hcan);
-      float tmp2 = expf(-cwpc * (z0h + q.zpd) / hcan);
-      float tmprah2 = hcan * expf(cwpc) / cwpc * (tmp1 - tmp2);
+      float tmp1 = nmp_expf(-cwpc * z0hg / hcan);
+      float tmp2 = nmp_expf(-cwpc * (z0h + q.zpd) / hcan);
+      float tmprah2 = hcan * nmp_expf(cwpc) / cwpc * (tmp1 - tmp2);
       float kh = fmaxf(VKC * mo.fv * (hcan - q.zpd), MPE);
       rahg = tmprah2 / kh;
       rawg = rahg;
-      float tmprb = cwpc * 50.f / (1.f - expf(-cwpc / 2.f));
+      float tmprb = cwpc * 50.f / (1.f - nmp_expf(-cwpc / 2.f));
       rb = tmprb * sqrtf(dleaf / uc);
     }
     t = tdc(tv);
@@ -636,7 +636,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     }
   }
   // 2-m diagnostics lsm:3557-3571 (OPT_SFC 1/2; FH2 is 0 under OPT_SFC=2)
-  float cah2 = mo.fv * VKC / (logf((2.f + z0h) / z0h) - mo.fh2);
+  float cah2 = mo.fv * VKC / (nmp_logf((2.f + z0h) / z0h) - mo.fh2);
   s.chv2 = cah2;
   if (cah2 < 1.E-5f) {
     s.t2mv = tah;
@@ -707,7 +707,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
       s.ghb = s.sag - (s.irb + s.shb + s.evb);
     }
   }
-  float ehb2 = mo.fv * VKC / (logf((2.f + z0h) / z0h) - mo.fh2);
+  float ehb2 = mo.fv * VKC / (nmp_logf((2.f + z0h) / z0h) - mo.fh2);
   s.chb2 = ehb2;
   if (ehb2 < 1.E-5f) {
     s.t2mb = tgb;
@@ -820,8 +820,8 @@ NMP_DEV float frh2o(const Parm& P, float tkelv, float smc, float sh2o) {
   while ((nlog < 10) && (kcount == 0)) {
     nlog = nlog + 1;
     float t1 = 1.f + CK * swl;
-    float df = logf((P.psisat * GRAV / HFUS) * (t1 * t1) * powf(P.smcmax / (smc - swl), bx)) -
-               logf(-(tkelv - TFRZ) / tkelv);
+    float df = nmp_logf((P.psisat * GRAV / HFUS) * (t1 * t1) * nmp_powf(P.smcmax / (smc - swl), bx)) -
+               nmp_logf(-(tkelv - TFRZ) / tkelv);
     float denom = 2.f * CK / (1.f + CK * swl) + bx / (smc - swl);
     float swlk = swl - df / denom;
     if (swlk > (smc - 0.02f)) swlk = smc - 0.02f;
@@ -832,7 +832,7 @@ NMP_DEV float frh2o(const Parm& P, float tkelv, float smc, float sh2o) {
   }
   free_ = smc - swl;
   if (kcount == 0) {
-    float fk = powf((HFUS / (GRAV * (-P.psisat))) * ((tkelv - TFRZ) / tkelv), -1 / bx) * P.smcmax;
+    float fk = nmp_powf((HFUS / (GRAV * (-P.psisat))) * ((tkelv - TFRZ) / tkelv), -1 / bx) * P.smcmax;
     if (fk < 0.02f) fk = 0.02f;
     free_ = fminf(fk, smc);
   }
@@ -871,7 +871,7 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     if (c.O.frz == 1) {
       if (stc[L(j)] < TFRZ) {
         float smp = HFUS * (TFRZ - stc[L(j)]) / (GRAV * stc[L(j)]);
-        supercool[L(j)] = P.smcmax * powf(smp / P.psisat, -1.f / P.bexp);
+        supercool[L(j)] = P.smcmax * nmp_powf(smp / P.psisat, -1.f / P.bexp);
         supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;
       }
     } else {
@@ -979,8 +979,8 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   s.fsno = 0.f;
   if (s.snowh > 0.f) {
     float bdsno = s.sneqv / s.snowh;
-    float fmelt = powf(bdsno / 100.f, M_MELT);
-    s.fsno = tanhf(s.snowh / (2.5f * Z0 * fmelt));
+    float fmelt = nmp_powf(bdsno / 100.f, M_MELT);
+    s.fsno = nmp_tanhf(s.snowh / (2.5f * Z0 * fmelt));
   }
   q.z0mg = Z0 * (1.0f - s.fsno) + s.fsno * Z0SNO;
   const float zpdg = s.snowh;
@@ -1001,7 +1001,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   thermoprop(c, P, s, y, df, hcpct, fact);
   RadOut r = radiation(c, s, y.smc[L(1)]);
   q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
-  q.emv = 1.f - expf(-(s.elai + s.esai) / 1.0f);
+  q.emv = 1.f - nmp_expf(-(s.elai + s.esai) / 1.0f);
   q.emg = T->eg[s.ist - 1] * (1.f - s.fsno) + 1.0f * s.fsno;    // ICE is 0 on this path (drv:549)
   // BTRAN lsm:1617-1640
   s.btran = 0.f;
@@ -1013,9 +1013,9 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
       if (c.O.btr == 1) {
         gx = (sh - P.smcwlt) / (P.smcref - P.smcwlt);
       } else {
-        float psi = fmaxf(PSIWLT, -P.psisat * powf(fmaxf(0.01f, sh) / P.smcmax, -P.bexp));
+        float psi = fmaxf(PSIWLT, -P.psisat * nmp_powf(fmaxf(0.01f, sh) / P.smcmax, -P.bexp));
         if (c.O.btr == 2) gx = (1.f - psi / PSIWLT) / (1.f + P.psisat / PSIWLT);
-        else gx = 1.f - expf(-5.8f * (logf(PSIWLT / psi)));
+        else gx = 1.f - nmp_expf(-5.8f * (nmp_logf(PSIWLT / psi)));
       }
       gx = fminf(1.f, fmaxf(0.f, gx));
       float bt = fmaxf(MPE, y.dzsnso[L(iz)] / zroot * gx);
@@ -1030,13 +1030,13 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   // soil surface resistance lsm:1644-1669
   {
     float sh1 = y.sh2o[L(1)];
-    float l_rsurf = (-c.zsoil[L(1)]) * (expf(powi5(1.0f - fminf(1.0f, sh1 / P.smcmax))) - 1.0f) /
+    float l_rsurf = (-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - fminf(1.0f, sh1 / P.smcmax))) - 1.0f) /
                     (2.71828f - 1.0f);
-    float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * powf(1.0f - P.smcwlt / P.smcmax, 2.0f + 3.0f / P.bexp);
+    float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * nmp_powf(1.0f - P.smcwlt / P.smcmax, 2.0f + 3.0f / P.bexp);
     q.rsurf = l_rsurf / d_rsurf;
     if (sh1 < 0.01f && s.snowh == 0.f) q.rsurf = 1.E6f;
-    float psi = -P.psisat * powf(fmaxf(0.01f, sh1) / P.smcmax, -P.bexp);
-    q.rhsur = s.fsno + (1.f - s.fsno) * expf(psi * GRAV / (RW * s.tg));
+    float psi = -P.psisat * nmp_powf(fmaxf(0.01f, sh1) / P.smcmax, -P.bexp);
+    q.rhsur = s.fsno + (1.f - s.fsno) * nmp_expf(psi * GRAV / (RW * s.tg));
   }
   if (s.vegtyp == c.isurban && s.snowh == 0.f) q.rsurf = 1.E6f;
   if (s.tv > TFRZ) { s.latheav = HVAP; s.frozen_canopy = 0; } else { s.latheav = HSUB; s.frozen_canopy = 1; }

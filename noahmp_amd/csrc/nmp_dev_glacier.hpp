@@ -279,7 +279,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
       albsnd[1] = albsni[1] + 0.4f * fzen * (1.f - albsni[1]);
     }
     if (c.O.alb == 2) {
-      float alb = 0.55f + (s.albold - 0.55f) * expf(-0.01f * dt / 3600.f);
+      float alb = 0.55f + (s.albold - 0.55f) * nmp_expf(-0.01f * dt / 3600.f);
       if (s.qsnow > 0.f) alb = alb + fminf(s.qsnow * dt, SWEMX) * (0.84f - alb) / (SWEMX);
       albsni[0] = albsni[1] = albsnd[0] = albsnd[1] = alb;
       s.albold = alb;
@@ -347,7 +347,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
         s.ssoil = s.sag - (s.fira + s.fsh + s.fgev);
       }
     }
-    float ehb2 = mo.fv * VKC / (logf((2.f + z0m) / z0m) - mo.fh2);
+    float ehb2 = mo.fv * VKC / (nmp_logf((2.f + z0m) / z0m) - mo.fh2);
     s.chb2 = ehb2;
     if (ehb2 < 1.E-5f) {
       s.t2mb = tgb;
@@ -396,7 +396,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     fpice = (s.sfctmp >= TFRZ) ? 0.f : 1.0f;
   }
   s.fpice = fpice;
-  float bdfall = fminf(120.f, 67.92f + 51.25f * expf((s.sfctmp - TFRZ) / 2.59f));
+  float bdfall = fminf(120.f, 67.92f + 51.25f * nmp_expf((s.sfctmp - TFRZ) / 2.59f));
   float qrain = s.prcp * (1.f - fpice);
   s.qsnow = s.prcp * fpice;
   float snowhin = s.qsnow / bdfall;

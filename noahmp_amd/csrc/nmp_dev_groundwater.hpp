@@ -52,7 +52,7 @@ NMP_DEV void gw_cell_head(const GwArgs& g, size_t x) {
     const int st = g.a.isltyp[x];
     const float satdk = (st >= 1 && st <= 30 /* NSLTYPE, lsm:83 */) ? g.T->satdk[st - 1] : 0.f;
     const float klat = satdk * gw_klatfactor(st);
-    if (wtd < -1.5f) kc = fdepth * klat * expf((wtd + 1.5f) / fdepth);
+    if (wtd < -1.5f) kc = fdepth * klat * nmp_expf((wtd + 1.5f) / fdepth);
     else kc = klat * (wtd + 1.5f + fdepth);
   }
   g.kcell[x] = kc;
@@ -101,7 +101,7 @@ NMP_DEV void gw_fill_up(GwCol& c, const Soil4& smceq, const float* zsoil, const 
 }
 
 NMP_DEV float gw_smceqdeep(float smcmax, float psisat, float bexp, float dz) {   // gw:395-398 and twins
-  const float e = smcmax * powf(psisat / (psisat - dz), 1.f / bexp);
+  const float e = smcmax * nmp_powf(psisat / (psisat - dz), 1.f / bexp);
   return fmax2(e, 1.E-4f);
 }
 
@@ -196,7 +196,7 @@ NMP_DEV void gw_updatewtd(GwCol& c, const Soil4& smceq, const float* zsoil, cons
     } else if (c.wtd >= zbot - dzn) {                                             // gw:556
       deep = true;
     } else {                                                                      // gw:585-595
-      float wgpmid = smcmax * powf(psisat / (psisat - (zbot - c.wtd)), 1.f / bexp);
+      float wgpmid = smcmax * nmp_powf(psisat / (psisat - (zbot - c.wtd)), 1.f / bexp);
       wgpmid = fmax2(wgpmid, 1.E-4f);
       const float syielddw = smcmax - wgpmid;
       const float wtdold = c.wtd;
@@ -281,7 +281,7 @@ NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) {
     }
     {                                                                             // gw:116-124
       float rcond = rivercond;
-      if (wtd > riverbed && eqwtd > riverbed) rcond = rcond * expf(pexp * (wtd - eqwtd));
+      if (wtd > riverbed && eqwtd > riverbed) rcond = rcond * nmp_expf(pexp * (wtd - eqwtd));
       qrf = rcond * (wtd - riverbed) * g.deltat / area;
       qrf = fmax2(qrf, 0.f);
     }
@@ -295,8 +295,8 @@ NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) {
     if (wtd < zbot - dzn) {                                                       // gw:147-161
       const float ddz = zbot - wtd;
       const float smcwtdmid = 0.5f * (c.smcwtd + smcmax);
-      const float psi = psisat * powf(smcmax / c.smcwtd, bexp);
-      const float wcnddeep = dksat * powf(smcwtdmid / smcmax, 2.0f * bexp + 3.0f);
+      const float psi = psisat * nmp_powf(smcmax / c.smcwtd, bexp);
+      const float wcnddeep = dksat * nmp_powf(smcwtdmid / smcmax, 2.0f * bexp + 3.0f);
       float wfluxdeep = -g.deltat * wcnddeep * ((psisat - psi) / ddz - 1.f);
       c.smcwtd = c.smcwtd + (deeprech - wfluxdeep) / ddz;
       const float wplus = fmax2(c.smcwtd - smcmax, 0.0f) * ddz;

@@ -65,7 +65,7 @@ NMP_DEV void phenology(const Ctx& c, Col& s) {
   float db = fminf(fmaxf(s.snowh - hvb, 0.f), hvt - hvb);
   float fb = db / fmaxf(1.E-06f, hvt - hvb);
   if (hvt > 0.f && hvt <= 1.0f) {
-    float snowhc = hvt * expf(-s.snowh / 0.2f);
+    float snowhc = hvt * nmp_expf(-s.snowh / 0.2f);
     fb = fminf(s.snowh, snowhc) / snowhc;
   }
   s.elai = s.lai * (1.f - fb);
@@ -112,20 +112,20 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float rf = (s.igs == 0.f) ? 0.5f : 1.0f;
   float tv = s.tv;
   float fnf = fminf(s.foln / fmaxf(1.E-06f, T->folnmx[v]), 1.0f);
-  float tf = powf(T->arm[v], (tv - 298.16f) / 10.f);
+  float tf = nmp_powf(T->arm[v], (tv - 298.16f) / 10.f);
   float resp = T->rmf25[v] * tf * fnf * s.lai * rf * (1.f - wstres);
   float rsleaf = fminf(s.lfmass / dt, resp * 12.e-6f);
   float rsroot = T->rmr25[v] * (s.rtmass * 1E-3f) * tf * rf * 12.e-6f;
   float rsstem = T->rms25[v] * (s.stmass * 1E-3f) * tf * rf * 12.e-6f;
-  float rswood = rswoodc * expf(0.08f * (tv - 298.16f)) * s.wood * T->wdpool[v];
+  float rswood = rswoodc * nmp_expf(0.08f * (tv - 298.16f)) * s.wood * T->wdpool[v];
   float carbfx = s.psn * 12.e-6f;
-  float leafpt = expf(0.01f * (1.f - expf(0.75f * s.lai)) * s.lai);
-  if (s.vegtyp == T->eblforest) leafpt = expf(0.01f * (1.f - expf(0.50f * s.lai)) * s.lai);
+  float leafpt = nmp_expf(0.01f * (1.f - nmp_expf(0.75f * s.lai)) * s.lai);
+  if (s.vegtyp == T->eblforest) leafpt = nmp_expf(0.01f * (1.f - nmp_expf(0.50f * s.lai)) * s.lai);
   float nonlef = 1.0f - leafpt;
   float stempt = s.lai / 10.0f;
   leafpt = leafpt - stempt;
   float woodf;
-  if (s.wood > 0) woodf = (1.f - expf(-bf * (T->wrrat[v] * s.rtmass / s.wood)) / bf) * T->wdpool[v];
+  if (s.wood > 0) woodf = (1.f - nmp_expf(-bf * (T->wrrat[v] * s.rtmass / s.wood)) / bf) * T->wdpool[v];
   else woodf = 0.f;
   float rootpt = nonlef * (1.f - woodf);
   float woodpt = nonlef * woodf;
@@ -133,8 +133,8 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float sttovr = T->ltovrc[v] * 1.E-6f * s.stmass;
   float rttovr = rtovrc * s.rtmass;
   float wdtovr = 9.5E-10f * s.wood;
-  float sc = expf(-0.3f * fmaxf(0.f, tv - T->tdlef[v])) * (s.lfmass / 120.f);
-  float sd = expf((wstres - 1.f) * wstrc);
+  float sc = nmp_expf(-0.3f * fmaxf(0.f, tv - T->tdlef[v])) * (s.lfmass / 120.f);
+  float sd = nmp_expf((wstres - 1.f) * wstrc);
   float dielf = s.lfmass * 1.E-6f * (T->dilefw[v] * sd + T->dilefc[v] * sc);
   float diest = s.stmass * 1.E-6f * (T->dilefw[v] * sd + T->dilefc[v] * sc);
   float grleaf = fmaxf(0.0f, T->fragr[v] * (leafpt * carbfx - rsleaf));
@@ -158,7 +158,7 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   if (s.rtmass < 0.0f) { rttovr = nppr; s.rtmass = 0.0f; }
   s.wood = (s.wood + (nppw - wdtovr) * dt) * T->wdpool[v];
   s.fastcp = s.fastcp + (rttovr + lftovr + sttovr + wdtovr + dielf) * dt;
-  float fst = powf(2.0f, (y.stc[L(1)] - 283.16f) / 10.f);
+  float fst = nmp_powf(2.0f, (y.stc[L(1)] - 283.16f) / 10.f);
   float fsw = wroot / (0.20f + wroot) * 0.23f / (0.23f + wroot);
   float rssoil = fsw * fst * T->mrp[v] * fmaxf(0.f, s.fastcp * 1.E-3f) * 12.E-6f;
   float stablc = 0.1f * rssoil;
@@ -208,7 +208,7 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
     s.fveg = s.shdfac;
     if (s.fveg <= 0.01f) s.fveg = 0.01f;
   } else if (c.O.dveg == 2 || c.O.dveg == 3) {
-    s.fveg = 1.f - expf(-0.52f * (s.lai + s.sai));
+    s.fveg = 1.f - nmp_expf(-0.52f * (s.lai + s.sai));
     if (s.fveg <= 0.01f) s.fveg = 0.01f;
   } else if (c.O.dveg == 4 || c.O.dveg == 5) {
     s.fveg = s.shdmax;

@@ -27,7 +27,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
     fpice = (sfctmp >= TFRZ) ? 0.f : 1.0f;
   }
   s.fpice = fpice;
-  float bdfall = fminf(120.f, 67.92f + 51.25f * expf((sfctmp - TFRZ) / 2.59f));
+  float bdfall = fminf(120.f, 67.92f + 51.25f * nmp_expf((sfctmp - TFRZ) / 2.59f));
   float rain = (s.qprecc + s.qprecl) * (1.f - fpice);
   float snow = (s.qprecc + s.qprecl) * fpice;
   if (s.qprecc + s.qprecl > 0.f) fp = (s.qprecc + s.qprecl) / (10.f * s.qprecc + s.qprecl);
@@ -35,7 +35,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   float maxliq = T->ch2op[v] * vai;
   if (vai > 0.f) {
     qintr = fveg * rain * fp;
-    qintr = fminf(qintr, (maxliq - s.canliq) / dt * (1.f - expf(-rain * dt / maxliq)));
+    qintr = fminf(qintr, (maxliq - s.canliq) / dt * (1.f - nmp_expf(-rain * dt / maxliq)));
     qintr = fmaxf(qintr, 0.f);
     qdripr = fveg * rain - qintr;
     qthror = (1.f - fveg) * rain;
@@ -59,7 +59,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   float maxsno = 6.6f * (0.27f + 46.f / bdfall) * vai;
   if (vai > 0.f) {
     qints = fveg * snow * fp;
-    qints = fminf(qints, (maxsno - s.canice) / dt * (1.f - expf(-snow * dt / maxsno)));
+    qints = fminf(qints, (maxsno - s.canice) / dt * (1.f - nmp_expf(-snow * dt / maxsno)));
     qints = fmaxf(qints, 0.f);
     float ft = fmaxf(0.0f, (s.tv - 270.15f) / 1.87E5f);
     float fv = sqrtf(s.uu * s.uu + s.vv * s.vv) / 1.56E5f;
@@ -73,7 +73,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   if (s.canice <= 1.E-6f) s.canice = 0.f;
   if (s.canice > 0.f) s.fwet = fmaxf(0.f, s.canice) / fmaxf(maxsno, 1.E-06f);
   else s.fwet = fmaxf(0.f, s.canliq) / fmaxf(maxliq, 1.E-06f);
-  s.fwet = powf(fminf(s.fwet, 1.f), 0.667f);
+  s.fwet = nmp_powf(fminf(s.fwet, 1.f), 0.667f);
   if (s.canice > 1.E-6f && s.tv > TFRZ) {
     float qmeltc = fminf(s.canice / dt, (s.tv - TFRZ) * CICE * s.canice / DENICE / (dt * HFUS));
     s.canice = fmaxf(0.f, s.canice - qmeltc * dt);
@@ -284,11 +284,11 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
       if (void_ > 0.001f && snice > 0.1f) {
         float bi = snice / dz;
         float td = fmaxf(0.f, TFRZ - y.stc[L(j)]);
-        float dexpf = expf(-C4 * td);
+        float dexpf = nmp_expf(-C4 * td);
         float ddz1 = -C3 * dexpf, ddz3;
-        if (bi > DM) ddz1 = ddz1 * expf(-46.0E-3f * (bi - DM));
+        if (bi > DM) ddz1 = ddz1 * nmp_expf(-46.0E-3f * (bi - DM));
         if (snliq > 0.01f * dz) ddz1 = ddz1 * C5;
-        float ddz2 = -(burden + 0.5f * wx) * expf(-0.08f * td - C2 * bi) / ETA0;
+        float ddz2 = -(burden + 0.5f * wx) * nmp_expf(-0.08f * td - C2 * bi) / ETA0;
         if (y.imelt[L(j)] == 1.f) {
           float fo = y.ficeold[L(j)];
           ddz3 = fmaxf(0.f, (fo - fice) / fmaxf(1.E-6f, fo));
@@ -446,21 +446,21 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
 // WDFCND1 lsm:8329-8362 / WDFCND2 lsm:8364-8400
 NMP_DEV void wdfcnd1(const Parm& P, float& wdf, float& wcnd, float smc, float fcr) {
   float factr = fmaxf(0.01f, smc / P.smcmax);
-  wdf = P.dwsat * powf(factr, P.bexp + 2.0f);
+  wdf = P.dwsat * nmp_powf(factr, P.bexp + 2.0f);
   wdf = wdf * (1.0f - fcr);
-  wcnd = P.dksat * powf(factr, 2.0f * P.bexp + 3.0f);
+  wcnd = P.dksat * nmp_powf(factr, 2.0f * P.bexp + 3.0f);
   wcnd = wcnd * (1.0f - fcr);
 }
 NMP_DEV void wdfcnd2(const Parm& P, float& wdf, float& wcnd, float smc, float sice) {
   float factr = fmaxf(0.01f, smc / P.smcmax);
   float expon = P.bexp + 2.0f;
-  wdf = P.dwsat * powf(factr, expon);
+  wdf = P.dwsat * nmp_powf(factr, expon);
   if (sice > 0.0f) {
     float x = 500.f * sice;
-    float vkwgt = 1.f / (1.f + powf(x, 3.f));
-    wdf = vkwgt * wdf + (1.f - vkwgt) * P.dwsat * powf(0.2f / P.smcmax, expon);
+    float vkwgt = 1.f / (1.f + nmp_powf(x, 3.f));
+    wdf = vkwgt * wdf + (1.f - vkwgt) * P.dwsat * nmp_powf(0.2f / P.smcmax, expon);
   }
-  wcnd = P.dksat * powf(factr, 2.0f * P.bexp + 3.0f);
+  wcnd = P.dksat * nmp_powf(factr, 2.0f * P.bexp + 3.0f);
 }
 
 // SOILWATER lsm:7680-7936 with ZWTEQ (7938-7989), INFIL (7992-8087), SRT (8089-8217), SSTEP (8220-8327)
@@ -482,11 +482,11 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     rsat = rsat + fmaxf(0.f, sh2o[L(k)] - epore) * dz[L(k)];
     sh2o[L(k)] = fminf(epore, sh2o[L(k)]);
   }
-  const float ea4 = expf(-4.0f);
+  const float ea4 = nmp_expf(-4.0f);
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
     float fice = fminf(1.0f, sice[L(k)] / P.smcmax);
-    fcr[L(k)] = fmaxf(0.0f, expf(-4.0f * (1.f - fice)) - ea4) / (1.0f - ea4);
+    fcr[L(k)] = fmaxf(0.0f, nmp_expf(-4.0f * (1.f - fice)) - ea4) / (1.0f - ea4);
     if (sice[L(k)] > sicemax) sicemax = sice[L(k)];
     if (fcr[L(k)] > fcrmax) fcrmax = fcr[L(k)];
   }
@@ -501,17 +501,17 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     for (int k = 1; k <= 100; k++) {
       float zfine = (float)k * dzfine;
       float temp = 1.f + (zwt0 - zfine) / P.psisat;
-      wd2 = wd2 + P.smcmax * (1.f - powf(temp, -1.f / P.bexp)) * dzfine;
+      wd2 = wd2 + P.smcmax * (1.f - nmp_powf(temp, -1.f / P.bexp)) * dzfine;
       if (fabsf(wd2 - wd1) <= 0.01f) { s.zwt = zfine; break; }
     }
-    s.runsub = (1.0f - fcrmax) * 4.0f * expf(-TIMEAN) * expf(-2.0f * s.zwt);
+    s.runsub = (1.0f - fcrmax) * 4.0f * nmp_expf(-TIMEAN) * nmp_expf(-2.0f * s.zwt);
   }
   if (s.vegtyp == c.isurban) fcr[L(1)] = 0.95f;
   if (c.O.run == 1 || c.O.run == 2 || c.O.run == 4 || c.O.run == 5) {
     float fsat;
-    if (c.O.run == 1) fsat = FSATMX * expf(-0.5f * 6.0f * (s.zwt - 2.0f));
-    else if (c.O.run == 5) fsat = FSATMX * expf(-0.5f * 6.0f * fmaxf(-2.0f - s.zwt, 0.f));
-    else if (c.O.run == 2) fsat = FSATMX * expf(-0.5f * 2.0f * s.zwt);
+    if (c.O.run == 1) fsat = FSATMX * nmp_expf(-0.5f * 6.0f * (s.zwt - 2.0f));
+    else if (c.O.run == 5) fsat = FSATMX * nmp_expf(-0.5f * 6.0f * fmaxf(-2.0f - s.zwt, 0.f));
+    else if (c.O.run == 2) fsat = FSATMX * nmp_expf(-0.5f * 2.0f * s.zwt);
     else {
       float smctot = 0.f, dztot = 0.f;
       bool done = false;
@@ -524,7 +524,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
         }
       }
       smctot = smctot / dztot;
-      fsat = powf(fmaxf(0.01f, smctot / P.smcmax), 4.f);
+      fsat = nmp_powf(fmaxf(0.01f, smctot / P.smcmax), 4.f);
     }
     if (qinsur > 0.f) {
       s.runsrf = qinsur * ((1.0f - fcr[L(1)]) * fsat + fcr[L(1)]);
@@ -547,7 +547,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
         dmax = dmax * (1.0f - (sh2o[L(k)] + sice[L(k)] - P.smcwlt) / smcav);
         dd = dd + dmax;
       }
-      float val = (1.f - expf(-P.kdt * dt1));
+      float val = (1.f - nmp_expf(-P.kdt * dt1));
       float ddt = dd * val;
       float px = fmaxf(0.f, qinsur * dt);
       float infmax = (px * (ddt / (px + ddt))) / dt;
@@ -557,7 +557,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
         float sum = 1.f;
         sum = sum + (acrt * acrt) / 2.f;                  // J=1: ACRT**2 / (2)
         sum = sum + acrt / 1.f;                           // J=2: ACRT**1 / 1
-        fcr_ = 1.f - expf(-acrt) * sum;
+        fcr_ = 1.f - nmp_expf(-acrt) * sum;
       }
       infmax = infmax * fcr_;
       float wdf_, wcnd_;
@@ -753,7 +753,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     for (int iz = 2; iz <= NSOIL; iz++)
       if (!found && s.zwt <= -c.zsoil[L(iz)]) { iwt = iz - 1; found = true; }
   }
-  qdis = (1.0f - fcrmax) * 5.0f * expf(-TIMEAN) * expf(-6.0f * (s.zwt - 2.0f));
+  qdis = (1.0f - fcrmax) * 5.0f * nmp_expf(-TIMEAN) * nmp_expf(-6.0f * (s.zwt - 2.0f));
   float smc_iwt = (iwt == 1) ? smc[L(1)] : (iwt == 2) ? smc[L(2)] : (iwt == 3) ? smc[L(3)] : smc[L(4)];
   float hk_iwt = (iwt == 1) ? hk[L(1)] : (iwt == 2) ? hk[L(2)] : (iwt == 3) ? hk[L(3)] : hk[L(4)];
   float zn_iwt = (iwt == 1) ? znode[L(1)] : (iwt == 2) ? znode[L(2)] : (iwt == 3) ? znode[L(3)] : znode[L(4)];
@@ -862,7 +862,7 @@ NMP_DEV void shallowwatertable(const Ctx& c, const Parm& P, Col& s, const Lay<A>
         s.rech = s.rech - (wtdold - wtd) * (P.smcmax - smceq[L(kwtd)]);
       } else {
         wtdold = wtd;
-        float smceqdeep = P.smcmax * powf(-P.psisat / (-P.psisat - dzn), 1.f / P.bexp);
+        float smceqdeep = P.smcmax * nmp_powf(-P.psisat / (-P.psisat - dzn), 1.f / P.bexp);
         wtd = fminf((s.smcwtd * dzn - smceqdeep * zsoil0[L(NSOIL)] + P.smcmax * (zsoil0[L(NSOIL)] - dzn)) /
                     (P.smcmax - smceqdeep), zsoil0[L(NSOIL)]);
         s.rech = s.rech - (wtdold - wtd) * (P.smcmax - smceqdeep);
@@ -870,7 +870,7 @@ NMP_DEV void shallowwatertable(const Ctx& c, const Parm& P, Col& s, const Lay<A>
     }
   } else if (wtd >= zsoil0[L(NSOIL)] - dzn) {
     wtdold = wtd;
-    float smceqdeep = P.smcmax * powf(-P.psisat / (-P.psisat - dzn), 1.f / P.bexp);
+    float smceqdeep = P.smcmax * nmp_powf(-P.psisat / (-P.psisat - dzn), 1.f / P.bexp);
     if (s.smcwtd > smceqdeep) {
       wtd = fminf((s.smcwtd * dzn - smceqdeep * zsoil0[L(NSOIL)] + P.smcmax * (zsoil0[L(NSOIL)] - dzn)) /
                   (P.smcmax - smceqdeep), zsoil0[L(NSOIL)]);

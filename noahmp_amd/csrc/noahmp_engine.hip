@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
   float priv[USE_LDS ? 1 : LAY_SLOTS];
   float* base = USE_LDS ? (lds + threadIdx.x) : priv;
 
+  libm::libm_stage_tables();
   const long t = (long)blockIdx.x * BLOCK + threadIdx.x;
   int ii = 0, jj = 0;
   size_t ij = 0;
@@ -161,6 +162,7 @@ int noahmp_hip_set_option(const char* key, int value) {
   int prev = -1;
   if (!strcmp(key, "block")) { prev = g.block; if (value == 64 || value == 128 || value == 256) g.block = value; }
   else if (!strcmp(key, "lds")) { prev = g.use_lds; g.use_lds = value ? 1 : 0; }
+  else if (!strcmp(key, "exact_libm")) prev = NMP_EXACT_LIBM;   // read-only: how this library was built
   return prev;
 }
 

@@ -24,6 +24,7 @@ constexpr int BX = 64, BY = 4;
 
 // KCELL / HEAD on the tile + ring rectangle (gw:237-252)
 __global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
+  libm::libm_stage_tables();
   const int gi = k.hi0 + blockIdx.x * BX + threadIdx.x;
   const int gj = k.hj0 + blockIdx.y * BY + threadIdx.y;
   if (gi > k.hi1 || gj > k.hj1) return;
@@ -32,6 +33,7 @@ __global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
 
 // stencil + per-cell update over the tile (gw:105-195)
 __global__ void __launch_bounds__(BX * BY) gw_column_kernel(const GwArgs k) {
+  libm::libm_stage_tables();
   const int gi = k.a.its + blockIdx.x * BX + threadIdx.x;
   const int gj = k.a.jts + blockIdx.y * BY + threadIdx.y;
   const bool in = (gi <= k.a.ite && gj <= k.a.jte);

@@ -35,6 +35,11 @@ class Engine:
             raise RuntimeError("noahmp_hip_set_tables: " + self.lib.noahmp_hip_last_error().decode())
         self.last_status = abi.Status()
 
+    @property
+    def exact_libm(self):
+        """True if the library was built with the reference libm's algorithms (bit-identical results)."""
+        return self.lib.noahmp_hip_set_option(b"exact_libm", -1) == 1
+
     def set_option(self, key, value):
         return self.lib.noahmp_hip_set_option(key.encode(), int(value))
 

@@ -1,0 +1,91 @@
+// TEST INFRASTRUCTURE -- compares noahmp_amd/csrc/nmp_libm.hpp (host compilation of the device source) with
+// the live libm of this machine, bit for bit.  Never shipped.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+#include "nmp_libm.hpp"
+
+using namespace nmp::libm;
+
+static inline bool same(float a, float b) {
+  if (isnan(a) && isnan(b)) return true;
+  return asuint(a) == asuint(b);
+}
+
+// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f.  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
+extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t* first_bad) {
+  std::vector<long> bad(nthreads, 0);
+  std::vector<uint32_t> fb(nthreads, 0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() {
+      const uint64_t lo = (uint64_t)t * (1ull << 32) / nthreads, hi = (uint64_t)(t + 1) * (1ull << 32) / nthreads;
+      for (uint64_t u = lo + (stride - lo % stride) % stride; u < hi; u += stride) {
+        const float x = asfloat((uint32_t)u);
+        float a, b;
+        switch (fn) {
+          case 0: a = expf_(x); b = ::expf(x); break;
+          case 1: a = logf_(x); b = ::logf(x); break;
+          case 2: a = log10f_(x); b = ::log10f(x); break;
+          case 3: a = atanf_(x); b = ::atanf(x); break;
+          case 4: a = tanhf_(x); b = ::tanhf(x); break;
+          default: a = expm1f_(x); b = ::expm1f(x); break;
+        }
+        if (!same(a, b)) { if (!bad[t]) fb[t] = (uint32_t)u; bad[t]++; }
+      }
+    });
+  for (auto& x : th) x.join();
+  long n = 0;
+  for (int t = 0; t < nthreads; t++) { if (bad[t] && !n) *first_bad = fb[t]; n += bad[t]; }
+  return n;
+}
+
+static inline uint64_t splitmix(uint64_t& s) {
+  uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// mode 0: x, y = random bit patterns (all specials included); mode 1: x in (0, 2^20), y in (-32, 32)
+// (the model's range: positive bases, moderate exponents); mode 2: specials cross product.
+extern "C" long libm_check_pow(int mode, long n, int nthreads, uint32_t* bad_xy) {
+  std::vector<long> bad(nthreads, 0);
+  std::vector<uint32_t> bx(nthreads, 0), by(nthreads, 0);
+  std::vector<std::thread> th;
+  static const uint32_t sp[] = {0x00000000u, 0x80000000u, 0x3f800000u, 0xbf800000u, 0x7f800000u, 0xff800000u,
+                                0x7fc00000u, 0x00000001u, 0x80000001u, 0x007fffffu, 0x00800000u, 0x7f7fffffu,
+                                0xff7fffffu, 0x40000000u, 0xc0000000u, 0x40400000u, 0xc0400000u, 0x3f000000u,
+                                0xbf000000u, 0x4b800000u, 0xcb800001u, 0x4b000001u, 0x3eaaaaabu, 0x42fc0000u,
+                                0xc3160000u, 0x43000000u};
+  const int nsp = sizeof(sp) / sizeof(sp[0]);
+  for (int t = 0; t < nthreads; t++)
+    th.emplace_back([&, t]() {
+      uint64_t s = 0x1234567ull * (t + 1) + mode;
+      const long cnt = mode == 2 ? (long)nsp * nsp : n / nthreads;
+      for (long c = 0; c < cnt; c++) {
+        float x, y;
+        if (mode == 2) {
+          if (t) break;
+          x = asfloat(sp[c / nsp]); y = asfloat(sp[c % nsp]);
+        } else {
+          const uint64_t r = splitmix(s);
+          if (mode == 0) { x = asfloat((uint32_t)r); y = asfloat((uint32_t)(r >> 32)); }
+          else {
+            x = ldexpf((float)((uint32_t)r >> 8) * 0x1p-24f + 0x1p-25f, (int)((r >> 32) % 40) - 19);
+            y = ((float)((uint32_t)(r >> 40)) * 0x1p-24f - 0.5f) * 64.f;
+          }
+        }
+        const float a = powf_(x, y), b = ::powf(x, y);
+        if (!same(a, b)) { if (!bad[t]) { bx[t] = asuint(x); by[t] = asuint(y); } bad[t]++; }
+      }
+    });
+  for (auto& x : th) x.join();
+  long nb = 0;
+  for (int t = 0; t < nthreads; t++) { if (bad[t] && !nb) { bad_xy[0] = bx[t]; bad_xy[1] = by[t]; } nb += bad[t]; }
+  return nb;
+}

@@ -145,3 +145,31 @@ def parity_check(ref, test, steps=1, frac=0.04, frac_medium=0.02, fields=None, m
             lines.append("%-12s tight-viol %d  medium-viol %d  envelope-viol %d  of %d; max|d|=%.3e  (nan ref/test %d/%d)"
                          % (n, nt, nm, ne, d.size, np.nanmax(d), int(np.isnan(x).sum()), int(np.isnan(y).sum())))
     return ok, lines
+
+
+def exact_check(ref, test, fields=None, skip=(), allow_cols=0):
+    """Bit-for-bit comparison (NaN == NaN).  Returns (ok, lines); `allow_cols` columns may differ (used only
+    at >= 1e6 columns, where the 2-in-2^32 arguments on which this machine's FMA variant of libm expf rounds
+    differently from the plain-multiply-add evaluation can show up)."""
+    import numpy as np
+    from noahmp_amd.abi import FIELD_INFO
+    names = fields or [k for k in ref.a if k in FIELD_INFO and FIELD_INFO[k][2] != "in"]
+    names = [n for n in names if n in ref.a and n in test.a]
+    lines, cols = [], None
+    for n in names:
+        if n in skip:
+            continue
+        x, y = np.asarray(ref.a[n]), np.asarray(test.a[n])
+        if x.dtype.kind == "f":
+            ne = ~((x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y)))
+        else:
+            ne = x != y
+        if ne.any():
+            c = ne.any(axis=1) if ne.ndim == 3 else ne
+            cols = c if cols is None else (cols | c)
+            idx = tuple(np.argwhere(ne)[0])
+            lines.append("%s: %d entries differ, first at %s: %r vs %r" % (n, int(ne.sum()), idx, x[idx], y[idx]))
+    nbad = int(cols.sum()) if cols is not None else 0
+    if nbad:
+        lines.insert(0, "%d column(s) not bit-identical (allowed %d)" % (nbad, allow_cols))
+    return nbad <= allow_cols, lines

@@ -49,14 +49,17 @@ def main(mode):
         d = np.concatenate(acc[n]); m = np.concatenate(acc[n + "/mag"])
         rt, at = tolerance(n, 1)
         tight = float((d > at + rt * m).mean())
-        out[n] = dict(max=float(d.max()), p999=float(np.quantile(d, 0.999)), frac_tight=tight,
+        out[n] = dict(max=float(d.max()), p999=float(np.quantile(d, 0.999)), frac_tight=tight, frac_ne=float((d > 0).mean()),
                       maxrel=float((d / np.maximum(m, 1e-30))[d > at].max()) if (d > at).any() else 0.0)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_stats_%s%s.json" % (mode, os.environ.get("NMP_TAG", ""))), "w"), indent=1)
     for n in names:
         o = out[n]
         if o["max"] > 0:
-            print("%-12s max %.3e  p99.9 %.3e  maxrel %.2e  frac>tight %.4f" % (n, o["max"], o["p999"], o["maxrel"], o["frac_tight"]))
+            print("%-12s max %.3e  p99.9 %.3e  maxrel %.2e  frac>tight %.4f  frac!= %.5f"
+                  % (n, o["max"], o["p999"], o["maxrel"], o["frac_tight"], o["frac_ne"]))
+    print("fields with any differing entry: %d of %d; overall differing fraction %.6f"
+          % (sum(1 for n in names if out[n]["max"] > 0), len(names), float(np.mean([out[n]["frac_ne"] for n in names]))))
 
 
 if __name__ == "__main__":
