@@ -89,3 +89,57 @@ extern "C" long libm_check_pow(int mode, long n, int nthreads, uint32_t* bad_xy)
   for (int t = 0; t < nthreads; t++) { if (bad[t] && !nb) { bad_xy[0] = bx[t]; bad_xy[1] = by[t]; } nb += bad[t]; }
   return nb;
 }
+
+// ---- the same routines evaluated ON THE GPU against this machine's libm (needs a device)
+__global__ void libm_eval_kernel(int fn, uint32_t start, uint32_t stride, long n, const float* __restrict__ y,
+                                 float* __restrict__ out) {
+  libm_stage_tables();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = asfloat(start + (uint32_t)i * stride);
+  float r;
+  switch (fn) {
+    case 0: r = expf_(x); break;
+    case 1: r = logf_(x); break;
+    case 2: r = log10f_(x); break;
+    case 3: r = atanf_(x); break;
+    case 4: r = tanhf_(x); break;
+    case 5: r = expm1f_(x); break;
+    default: r = powf_(x, y[i]); break;
+  }
+  out[i] = r;
+}
+
+// fn 0..5 unary as above, 6 = powf with y drawn from a splitmix stream.  Returns mismatches, -1 on HIP error.
+extern "C" long libm_gpu_check(int fn, uint32_t start, uint32_t stride, long n, uint32_t* first_bad) {
+  float *d_out = nullptr, *d_y = nullptr;
+  std::vector<float> out(n), y;
+  if (hipMalloc(&d_out, n * sizeof(float)) != hipSuccess) return -1;
+  if (fn == 6) {
+    y.resize(n);
+    uint64_t s = 99;
+    for (long i = 0; i < n; i++) y[i] = ((float)((uint32_t)(splitmix(s) >> 40)) * 0x1p-24f - 0.5f) * 64.f;
+    if (hipMalloc(&d_y, n * sizeof(float)) != hipSuccess) return -1;
+    if (hipMemcpy(d_y, y.data(), n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  }
+  hipLaunchKernelGGL(libm_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, fn, start, stride, n, d_y, d_out);
+  if (hipMemcpy(out.data(), d_out, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  hipFree(d_out);
+  if (d_y) hipFree(d_y);
+  long bad = 0;
+  for (long i = 0; i < n; i++) {
+    const float x = asfloat(start + (uint32_t)i * stride);
+    float b;
+    switch (fn) {
+      case 0: b = ::expf(x); break;
+      case 1: b = ::logf(x); break;
+      case 2: b = ::log10f(x); break;
+      case 3: b = ::atanf(x); break;
+      case 4: b = ::tanhf(x); break;
+      case 5: b = ::expm1f(x); break;
+      default: b = ::powf(x, y[i]); break;
+    }
+    if (!same(out[i], b)) { if (!bad) *first_bad = start + (uint32_t)i * stride; bad++; }
+  }
+  return bad;
+}

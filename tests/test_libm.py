@@ -1,0 +1,75 @@
+"""noahmp_amd/csrc/nmp_libm.hpp against the live libm of the machine, bit for bit.
+
+The reference's EXP / LOG / ** / LOG10 / ATAN / TANH resolve to glibc's float32 routines; the device runs
+restatements of the same algorithms.  CPU: the host compilation of that header over a stride of the whole
+2^32 argument space (the exhaustive run -- stride 1, ~1 min on 8 cores -- gives expf 2 mismatches, which are
+the arguments where x86 libm's FMA variant rounds the float64 polynomial differently; every other routine 0).
+GPU: the device code itself over 2^24 arguments per routine.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "host_emul", "libm_check.hip")
+LIB = os.path.join(HERE, "host_emul", "liblibm_check.so")
+NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f"]
+
+
+def _lib():
+    csrc = os.path.join(ROOT, "noahmp_amd", "csrc")
+    deps = [SRC, os.path.join(csrc, "nmp_libm.hpp"), os.path.join(csrc, "nmp_libm_tables.inc")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
+                               "-ffp-contract=off", "-I" + csrc, SRC, "-o", LIB, "-lpthread"])
+    lib = C.CDLL(LIB)
+    lib.libm_check_unary.restype = C.c_long
+    lib.libm_check_unary.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+    lib.libm_check_pow.restype = C.c_long
+    lib.libm_check_pow.argtypes = [C.c_int, C.c_long, C.c_int, C.POINTER(C.c_uint32)]
+    lib.libm_gpu_check.restype = C.c_long
+    lib.libm_gpu_check.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_long, C.POINTER(C.c_uint32)]
+    return lib
+
+
+@pytest.mark.parametrize("fn", range(6), ids=NAMES)
+def test_host_build_matches_libm(fn):
+    lib = _lib()
+    fb = C.c_uint32(0)
+    stride = int(os.environ.get("NMP_LIBM_STRIDE", "61"))          # 7e7 arguments per routine by default
+    n = lib.libm_check_unary(fn, stride, 8, C.byref(fb))
+    assert n <= (2 if fn == 0 else 0), "%s: %d mismatches, first at bits 0x%08x" % (NAMES[fn], n, fb.value)
+
+
+def test_host_powf_matches_libm():
+    lib = _lib()
+    xy = (C.c_uint32 * 2)()
+    for mode, n in ((2, 0), (1, 40_000_000), (0, 40_000_000)):   # specials x specials, model range, random bits
+        bad = lib.libm_check_pow(mode, n, 8, xy)
+        assert bad == 0, "powf mode %d: %d mismatches, first x=0x%08x y=0x%08x" % (mode, bad, xy[0], xy[1])
+
+
+def test_tables_regenerate_identically(tmp_path):
+    """tools/gen_libm_tables.py on this image's libm reproduces the committed constants."""
+    inc = os.path.join(ROOT, "noahmp_amd", "csrc", "nmp_libm_tables.inc")
+    before = open(inc).read()
+    subprocess.check_call(["python", os.path.join(ROOT, "tools", "gen_libm_tables.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fn", range(7), ids=NAMES + ["powf"])
+def test_device_code_matches_libm(fn):
+    lib = _lib()
+    fb = C.c_uint32(0)
+    n = 1 << 24
+    if fn == 6:
+        bad = lib.libm_gpu_check(6, 0x00800000, 127, n, C.byref(fb))      # positive normal bases, y in (-32, 32)
+    else:
+        bad = lib.libm_gpu_check(fn, 12345, 256, n, C.byref(fb))          # every 256th bit pattern, all of 2^32
+    assert bad >= 0, "HIP error"
+    assert bad <= (1 if fn == 0 else 0), "%s on the GPU: %d mismatches, first at bits 0x%08x" % (
+        (NAMES + ["powf"])[fn], bad, fb.value)
