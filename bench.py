@@ -95,15 +95,13 @@ def main():
 
     cpu = None
     import torch
-    import torch.distributed as dist
     from noahmp_amd import synth
     from noahmp_amd.driver import Engine
     from noahmp_amd.state import ModelConfig
 
+    from noahmp_amd.parallel import Comm
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = Comm()                                           # one process per GPU; "nccl" = RCCL when world > 1
 
     eng = Engine(T, device=local_rank)
     cfg = ModelConfig(idveg=1)                              # "dynamic_veg off", config 2

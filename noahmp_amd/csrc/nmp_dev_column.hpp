@@ -106,6 +106,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   // value-initialise (NOT memset(): HIP's device memset is a byte loop through a pointer PHI, which
   // pins the whole struct in scratch and defeats scalar replacement -- 556 B/lane of scratch traffic)
   Col s = {};
+  NMP_TIC0();
   // ---- gather, drv:449-545
   s.cosz = G2(coszin); s.lat = G2(xlatin);
   s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
@@ -155,7 +156,9 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   if (vegtyp == k.a.isurban || vegtyp == 31 || vegtyp == 32 || vegtyp == 33) vegtyp = k.a.isurban;
   if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }
   Parm P;
+  NMP_TIC(0);    // gather
   redprm(k.c, s, P, vegtyp, soiltyp);
+  NMP_TIC(1);    // redprm
   s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
   if (s.err) return s.err;                                                         // REDPRM fatals, lsm:9266-9344
 
@@ -173,6 +176,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
     if (s.err) return s.err;
     lh_out = s.fcev + s.fgev + s.fctr;                                             // drv:714
     scatter_energy_outputs(k, s, ij);
+    NMP_TIC(11);   // energy tail + early scatter
     sflx_water(k.c, P, s, y, beg_wb);
     if (s.err) return s.err;
     qfx_out = s.ecan + s.edir + s.etran;                                           // drv:713
@@ -211,6 +215,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   G2(rechxy) = G2(rechxy) + s.rech * 1.E3f;
   G2(deeprechxy) = G2(deeprechxy) + s.deeprech;
   G2(smcwtdxy) = s.smcwtd;
+  NMP_TIC(15);   // water tail + final scatter
   return 0;
 }
 

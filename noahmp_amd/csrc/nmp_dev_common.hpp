@@ -85,6 +85,26 @@ NMP_DEV float pow_half(float x) { return sqrtf(x); }
 NMP_DEV float pow_neg_quarter(float x) { return 1.0f / sqrtf(sqrtf(x)); }
 #endif
 
+// Phase timers (profiling build only, -DNMP_PHASE_TIMERS): the first active lane of every wave adds the shader-clock ticks since
+// its previous NMP_TIC to a per-phase counter (spread over 256 slots).  
+// With 2 waves interleaved per SIMD a tick interval contains the other wave's issue slots too, so the numbers
+// are shares of the kernel's time, not instruction counts.
+#if defined(NMP_PHASE_TIMERS)
+constexpr int NMP_NPHASE = 24;
+static __device__ unsigned long long g_nmp_prof[NMP_NPHASE * 256];
+#endif
+#if defined(NMP_PHASE_TIMERS) && defined(__HIP_DEVICE_COMPILE__)
+static __shared__ long long s_nmp_last[8];
+#define NMP_TIC(ph) do { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { const long long now_ = clock64(); \
+    const int w_ = threadIdx.x >> 6; \
+    atomicAdd(&g_nmp_prof[(ph) * 256 + (blockIdx.x & 255)], (unsigned long long)(now_ - s_nmp_last[w_])); \
+    s_nmp_last[w_] = now_; } } while (0)
+#define NMP_TIC0() do { if ((threadIdx.x & 63) == 0) s_nmp_last[threadIdx.x >> 6] = clock64(); } while (0)
+#else
+#define NMP_TIC(ph) ((void)0)
+#define NMP_TIC0() ((void)0)
+#endif
+
 struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)
   int dveg, crs, btr, run, sfc, frz, inf, rad, alb, snf, tbot, stc;
 };

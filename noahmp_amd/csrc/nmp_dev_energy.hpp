@@ -10,25 +10,36 @@
 namespace nmp {
 
 // ESAT lsm:5272-5321
-NMP_DEV void esat(float t, float& esw, float& esi, float& desw, float& desi) {
-  esw = 100.f * (6.107799961f + t * (4.436518521E-01f + t * (1.428945805E-02f + t * (2.650648471E-04f +
-        t * (3.031240396E-06f + t * (2.034080948E-08f + t * 6.136820929E-11f))))));
-  esi = 100.f * (6.109177956f + t * (5.034698970E-01f + t * (1.886013408E-02f + t * (4.176223716E-04f +
-        t * (5.824720280E-06f + t * (4.838803174E-08f + t * 1.838826904E-10f))))));
-  desw = 100.f * (4.438099984E-01f + t * (2.857002636E-02f + t * (7.938054040E-04f + t * (1.215215065E-05f +
-         t * (1.036561403E-07f + t * (3.532421810e-10f + t * -7.090244804E-13f))))));
-  desi = 100.f * (5.030305237E-01f + t * (3.773255020E-02f + t * (1.267995369E-03f + t * (2.477563108E-05f +
-         t * (3.005693132E-07f + t * (2.158542548E-09f + t * 7.131097725E-12f))))));
+// The callers of ESAT (lsm:3246-3250 etc.) always pick the water pair for T > 0 C and the ice pair otherwise; evaluating
+// only the pair that is picked gives the same bits with half the arithmetic (the branch is wave-uniform except in
+// waves that straddle 0 C).
+NMP_DEV void esat_sel(float t, float& es, float& des) {
+  if (t > 0.f) {
+    es = 100.f * (6.107799961f + t * (4.436518521E-01f + t * (1.428945805E-02f + t * (2.650648471E-04f +
+         t * (3.031240396E-06f + t * (2.034080948E-08f + t * 6.136820929E-11f))))));
+    des = 100.f * (4.438099984E-01f + t * (2.857002636E-02f + t * (7.938054040E-04f + t * (1.215215065E-05f +
+          t * (1.036561403E-07f + t * (3.532421810e-10f + t * -7.090244804E-13f))))));
+  } else {
+    es = 100.f * (6.109177956f + t * (5.034698970E-01f + t * (1.886013408E-02f + t * (4.176223716E-04f +
+         t * (5.824720280E-06f + t * (4.838803174E-08f + t * 1.838826904E-10f))))));
+    des = 100.f * (5.030305237E-01f + t * (3.773255020E-02f + t * (1.267995369E-03f + t * (2.477563108E-05f +
+          t * (3.005693132E-07f + t * (2.158542548E-09f + t * 7.131097725E-12f))))));
+  }
 }
 NMP_DEV float tdc(float t) { return fminf(50.f, fmaxf(-50.f, (t - TFRZ))); }   // lsm:3247
 
 // TDFCND lsm:2014-2118
-NMP_DEV float tdfcnd(const Parm& P, float smc, float sh2o) {
-  float satratio = smc / P.smcmax;
+// `thks_pow` = THKS**(1-SMCMAX) with THKS = 7.7**QUARTZ * 2**(1-QUARTZ): per-column constants, evaluated once by
+// the caller instead of once per soil layer.
+NMP_DEV float tdfcnd_thks_pow(const Parm& P) {
   float thks = nmp_powf(7.7f, P.quartz) * nmp_powf(2.0f, 1.f - P.quartz);
+  return nmp_powf(thks, 1.f - P.smcmax);
+}
+NMP_DEV float tdfcnd(const Parm& P, float thks_pow, float smc, float sh2o) {
+  float satratio = smc / P.smcmax;
   float xunfroz = sh2o / smc;
   float xu = xunfroz * P.smcmax;
-  float thksat = nmp_powf(thks, 1.f - P.smcmax) * nmp_powf(TKICE, P.smcmax - xu) * nmp_powf(0.57f, xu);
+  float thksat = thks_pow * nmp_powf(TKICE, P.smcmax - xu) * nmp_powf(0.57f, xu);
   float gammd = (1.f - P.smcmax) * 2700.f;
   float thkdry = (0.135f * gammd + 64.7f) / (2700.f - 0.947f * gammd);
   float ake;
@@ -55,12 +66,13 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
     }
   }
   const bool urban = (s.vegtyp == c.isurban);
+  const float thks_pow = tdfcnd_thks_pow(P);
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     float smc = y.smc[L(iz)], sh2o = y.sh2o[L(iz)];
     float sice = smc - sh2o;
     hcpct[L(iz)] = sh2o * CWAT + (1.0f - P.smcmax) * P.csoil + (P.smcmax - smc) * CPAIR + sice * CICE;
-    df[L(iz)] = urban ? 3.24f : tdfcnd(P, smc, sh2o);
+    df[L(iz)] = urban ? 3.24f : tdfcnd(P, thks_pow, smc, sh2o);
   }
 #pragma unroll
   for (int iz = -2; iz <= NSOIL; iz++)
@@ -292,7 +304,12 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
   return r;
 }
 
-struct MoState { float moz, fm, fh, fm2, fh2, fv; int mozsgn; };
+struct MoState {
+  float moz, fm, fh, fm2, fh2, fv; int mozsgn;
+  // LOG((ZLVL-ZPD)/Z0M) etc. (lsm:4117-4120): the reference re-evaluates them in every iteration of the
+  // flux loops with unchanged arguments; here they are evaluated when the arguments change (iteration 1)
+  float tmpcm, tmpch, tmpcm2, tmpch2, z0h_c;
+};
 
 // SFCDIF1 lsm:4061-4220
 NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, float qair, float zlvl,
@@ -301,10 +318,16 @@ NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, floa
   float mozold = m.moz;
   float moz2, fmnew, fhnew, fm2new, fh2new;
   if (zlvl <= zpd) { raise(s, NOAHMP_ERR_STABILITY_STOP); }
-  float tmpcm = nmp_logf((zlvl - zpd) / z0m);
-  float tmpch = nmp_logf((zlvl - zpd) / z0h);
-  float tmpcm2 = nmp_logf((2.0f + z0m) / z0m);
-  float tmpch2 = nmp_logf((2.0f + z0h) / z0h);
+  if (iter == 1) {                     // zlvl, zpd, z0m are fixed over the caller's loop
+    m.tmpcm = nmp_logf((zlvl - zpd) / z0m);
+    m.tmpcm2 = nmp_logf((2.0f + z0m) / z0m);
+  }
+  if (iter == 1 || z0h != m.z0h_c) {   // z0h is fixed too unless the caller updates it (glacier / IZ0TLND)
+    if (z0h == z0m) { m.tmpch = m.tmpcm; m.tmpch2 = m.tmpcm2; }
+    else { m.tmpch = nmp_logf((zlvl - zpd) / z0h); m.tmpch2 = nmp_logf((2.0f + z0h) / z0h); }
+    m.z0h_c = z0h;
+  }
+  const float tmpcm = m.tmpcm, tmpch = m.tmpch, tmpcm2 = m.tmpcm2, tmpch2 = m.tmpch2;
   if (iter == 1) {
     m.fv = 0.0f; m.moz = 0.0f; moz2 = 0.0f;
   } else {
@@ -495,9 +518,9 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   const float MPE = 1E-6f;
   const float fveg = s.fveg, rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur;
   int liter = 0;
-  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0};
+  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
   float dtv = 0.f, hg = 0.f, h = 0.f, wstar = 0.f;
-  float t, esatw, esati, dsatw, dsati, estg, destg, estv = 0.f, destv = 0.f;
+  float t, estg, destg, estv = 0.f, destv = 0.f;
   float rahc = 0.f, rawc, rahg = 0.f, rawg = 0.f, rb = 0.f, fhg = 0.f;
   float cah = 0.f, cvh = 0.f, cgh, cond, ata, bta, csh, caw, cew, ctw, cgw, aea, bea, cev, ctr;
   float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah; float& ch = s.chv;
@@ -507,8 +530,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   float laisune = fminf(6.f, q.laisun / fveg);
   float laishae = fminf(6.f, q.laisha / fveg);
   t = tdc(tg);
-  esat(t, esatw, esati, dsatw, dsati);
-  estg = (t > 0.f) ? esatw : esati;
+  esat_sel(t, estg, destg);
   s.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
   const float hcan = s.htop;
   float uc = ur * nmp_logf(hcan / q.z0m) / nmp_logf(q.zlvl / q.z0m);
@@ -516,6 +538,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   float air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(tg);
   float cir = (2.f - q.emv * (1.f - q.emg)) * q.emv * SB;
   const float dleaf = T->dleaf[v];
+  const float sqrt_dleaf_uc = sqrtf(dleaf / uc);        // loop-invariant factor of RB (lsm:4054)
 #pragma unroll 1
   for (int iter = 1; iter <= 20; iter++) {              // loop1, NITERC = 20 (lsm:3234)
     if (c.O.sfc == 1) {
@@ -525,6 +548,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
       ch = ch / ur;
       cm = cm / ur;
     }
+    NMP_TIC(16);   // vege loop1: sfcdif
     rahc = fmaxf(1.f, 1.f / (ch * ur));
     rawc = rahc;
     {                                                   // RAGRB lsm:3960-4057
@@ -547,11 +571,12 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
       rahg = tmprah2 / kh;
       rawg = rahg;
       float tmprb = cwpc * 50.f / (1.f - nmp_expf(-cwpc / 2.f));
-      rb = tmprb * sqrtf(dleaf / uc);
+      rb = tmprb * sqrt_dleaf_uc;
     }
+    NMP_TIC(17);   // vege loop1: ragrb
     t = tdc(tv);
-    esat(t, esatw, esati, dsatw, dsati);
-    if (t > 0.f) { estv = esatw; destv = dsatw; } else { estv = esati; destv = dsati; }
+    esat_sel(t, estv, destv);
+    NMP_TIC(18);   // vege loop1: esat
     if (iter == 1) {
 #pragma unroll 1
       for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
@@ -564,6 +589,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
         if (leaf) { s.rssha = rs_; psnsha = psn_; } else { s.rssun = rs_; psnsun = psn_; }
       }
     }
+    NMP_TIC(19);   // vege loop1: stomata (first iteration only)
     cah = 1.f / rahc;
     cvh = 2.f * vaie / rb;
     cgh = 1.f / rahg;
@@ -599,9 +625,11 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     h = rhoair * CPAIR * (tah - sfctmp) / rahc;
     hg = rhoair * CPAIR * (tg - tah) / rahg;
     s.qsfc = (0.622f * eah) / (s.sfcprs - 0.378f * eah);
+    NMP_TIC(20);   // vege loop1: flux solve
     if (liter == 1) break;
     if (iter >= 5 && fabsf(dtv) <= 0.01f && liter == 0) liter = 1;
   }
+  NMP_TIC(21);
   // under-canopy ground, lsm:3495-3542
   air = -q.emg * (1.f - q.emv) * s.lwdn - q.emg * q.emv * SB * powi4(tv);
   cir = q.emg * SB;
@@ -611,8 +639,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop2, NITERG = 5
     t = tdc(tg);
-    esat(t, esatw, esati, dsatw, dsati);
-    if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
+    esat_sel(t, estg, destg);
     s.irg = cir * powi4(tg) + air;
     s.shg = csh * (tg - tah);
     s.evg = cev * (estg * q.rhsur - eah);
@@ -654,9 +681,9 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float zpdg, float& cmb) {
   const float MPE = 1E-6f;
   const float rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur, z0m = q.z0mg;
-  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0};
+  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
   float h = 0.f, wstar = 0.f;
-  float t, esatw, esati, dsatw, dsati, estg = 0.f, destg, csh = 0.f, cev = 0.f, ehb = 0.f;
+  float t, estg = 0.f, destg, csh = 0.f, cev = 0.f, ehb = 0.f;
   float& tgb = s.tgb; float& ch = s.chb; float& cm = cmb;
   const float z0h = z0m;
   const float cir = q.emg * SB;
@@ -676,8 +703,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     float rawb = rahb;
     ehb = 1.f / rahb;
     t = tdc(tgb);
-    esat(t, esatw, esati, dsatw, dsati);
-    if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
+    esat_sel(t, estg, destg);
     csh = rhoair * CPAIR / rahb;
     cev = rhoair * CPAIR / gamma / (q.rsurf + rawb);
     s.irb = cir * powi4(tgb) - q.emg * s.lwdn;
@@ -694,8 +720,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     tgb = tgb + dtg;
     h = csh * (tgb - sfctmp);
     t = tdc(tgb);
-    esat(t, esatw, esati, dsatw, dsati);
-    estg = (t > 0.f) ? esatw : esati;
+    { float dummy; esat_sel(t, estg, dummy); }
     s.qsfc = 0.622f * (estg * q.rhsur) / (s.psfc - 0.378f * (estg * q.rhsur));
   }
   if (c.O.stc == 1) {
@@ -998,8 +1023,11 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float df[NL], hcpct[NL], fact[NL];
 #pragma unroll
   for (int k = 0; k < NL; k++) { df[k] = 0.f; hcpct[k] = 0.f; fact[k] = 0.f; }
+  NMP_TIC(2);    // energy: preamble
   thermoprop(c, P, s, y, df, hcpct, fact);
+  NMP_TIC(3);    // thermoprop
   RadOut r = radiation(c, s, y.smc[L(1)]);
+  NMP_TIC(4);    // radiation
   q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
   q.emv = 1.f - nmp_expf(-(s.elai + s.esai) / 1.0f);
   q.emg = T->eg[s.ist - 1] * (1.f - s.fsno) + 1.0f * s.fsno;    // ICE is 0 on this path (drv:549)
@@ -1049,16 +1077,19 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
 
   float cmv = 0.f, cmb;
   const bool canopy = veg && s.fveg > 0;
+  NMP_TIC(5);    // btran, rsurf, psychrometric constants
   if (canopy) {
     s.tgv = s.tg;
     cmv = s.cm;
     s.chv = s.ch;
     vege_flux(c, P, s, q, cmv, psnsun, psnsha);
   }
+  NMP_TIC(6);    // vege_flux
   s.tgb = s.tg;
   cmb = s.cm;
   s.chb = s.ch;
   bare_flux(c, P, s, q, zpdg, cmb);
+  NMP_TIC(7);    // bare_flux
   if (canopy) {
     s.fira = s.fveg * s.irg + (1.0f - s.fveg) * s.irb + s.irc;
     s.fsh = s.fveg * s.shg + (1.0f - s.fveg) * s.shb + s.shc;
@@ -1083,7 +1114,9 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   s.trad = pow_quarter((fire - (1 - s.emissi) * s.lwdn) / (s.emissi * SB));
   s.apar = r.parsun * r.laisun + r.parsha * r.laisha;
   s.psn = psnsun * r.laisun + psnsha * r.laisha;
+  NMP_TIC(8);    // flux merge, trad
   tsnosoi(c, P, s, y, df, hcpct);
+  NMP_TIC(9);    // tsnosoi
   if (c.O.stc == 2) {
     if (s.snowh > 0.05f && s.tg > TFRZ) {
       s.tgv = TFRZ; s.tgb = TFRZ;
@@ -1092,6 +1125,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
     }
   }
   phasechange(c, P, s, y, fact);
+  NMP_TIC(10);   // phasechange
 }
 
 }  // namespace nmp

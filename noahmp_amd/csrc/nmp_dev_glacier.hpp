@@ -301,7 +301,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
   const float gamma = CPAIR * s.sfcprs / (0.622f * lathea);
   {                                                       // GLACIER_FLUX gla:942-1148
     MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0};
-    float h = 0.f, t, esatw, esati, dsatw, dsati, estg = 0.f, destg, csh = 0.f, cev = 0.f, rahb = 1.f;
+    float h = 0.f, t, estg = 0.f, destg, csh = 0.f, cev = 0.f, rahb = 1.f;
     const float cir = emg * SB;
     const float df_top = at_top(df, s.isnow);
     const float cgh = 2.f * df_top / y.dzsnso[L(s.isnow + 1)];
@@ -313,8 +313,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
       rahb = fmaxf(1.f, 1.f / (s.ch * ur));
       float rawb = rahb;
       t = tdc(tgb);
-      esat(t, esatw, esati, dsatw, dsati);
-      if (t > 0.f) { estg = esatw; destg = dsatw; } else { estg = esati; destg = dsati; }
+      esat_sel(t, estg, destg);
       csh = s.rhoair * CPAIR / rahb;
       cev = s.rhoair * CPAIR / gamma / (rsurf + rawb);
       s.fira = cir * powi4(tgb) - emg * s.lwdn;
@@ -331,8 +330,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
       tgb = tgb + dtg;
       h = csh * (tgb - s.sfctmp);
       t = tdc(tgb);
-      esat(t, esatw, esati, dsatw, dsati);
-      estg = (t > 0.f) ? esatw : esati;
+      { float dummy; esat_sel(t, estg, dummy); }
       s.qsfc = 0.622f * (estg * rhsur) / (s.sfcprs - 0.378f * (estg * rhsur));
     }
     float sicemax = -1.e30f;

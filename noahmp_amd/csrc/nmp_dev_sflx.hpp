@@ -242,9 +242,12 @@ NMP_DEV void sflx_water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, fl
   float qdew = fabsf(fminf(s.fgev / s.latheag, 0.f));
   s.edir = qvap - qdew;
 
+  NMP_TIC(12);   // water preamble
   water(c, P, s, y, qvap, qdew);
+  NMP_TIC(13);   // water
 
   if (c.O.dveg == 2 || c.O.dveg == 5) carbon(c, P, s, y);
+  NMP_TIC(14);   // carbon
 
   // water part of ERROR (lsm:1199-1222): the reference STOPs; here the column raises its status word
   {

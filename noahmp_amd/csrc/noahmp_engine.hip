@@ -286,6 +286,21 @@ const char* noahmp_hip_error_string(int code) {
 
 const char* noahmp_hip_last_error(void) { return g.last_error.c_str(); }
 
+#ifdef NMP_PHASE_TIMERS
+// profiling build only: read and clear the phase tick counters (summed over their 256 slots)
+int noahmp_hip_debug_phase_ticks(unsigned long long* out, int n) {
+  std::vector<unsigned long long> h(nmp::NMP_NPHASE * 256);
+  HIPCHK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(nmp::g_nmp_prof), h.size() * 8));
+  for (int p = 0; p < n && p < nmp::NMP_NPHASE; p++) {
+    out[p] = 0;
+    for (int s2 = 0; s2 < 256; s2++) out[p] += h[p * 256 + s2];
+  }
+  std::fill(h.begin(), h.end(), 0ull);
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nmp::g_nmp_prof), h.data(), h.size() * 8));
+  return 0;
+}
+#endif
+
 void noahmp_hip_finalize(void) {
   for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& b : g.mirror_bytes) b = 0;

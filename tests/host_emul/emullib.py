@@ -17,7 +17,7 @@ def build():
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-fPIC", "-shared", "-std=c++17",
-                           "-ffp-contract=off", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"),
+                           "-ffp-contract=off", "-mfma", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"),
                            "-I" + csrc, src, "-o", LIB])
 
 

@@ -24,7 +24,7 @@ def _lib():
     deps = [SRC, os.path.join(csrc, "nmp_libm.hpp"), os.path.join(csrc, "nmp_libm_tables.inc")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
-                               "-ffp-contract=off", "-I" + csrc, SRC, "-o", LIB, "-lpthread"])
+                               "-ffp-contract=off", "-mfma", "-I" + csrc, SRC, "-o", LIB, "-lpthread"])
     lib = C.CDLL(LIB)
     lib.libm_check_unary.restype = C.c_long
     lib.libm_check_unary.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
