@@ -100,13 +100,22 @@ NMP_DEV void scatter_energy_outputs(const KArgs& k, const Col& s, size_t ij) {
 // Returns the column's status word (0 = ok).  A column that fails before or inside the ENERGY phase is
 // left untouched; one that fails the closing water-balance check has already stored its energy-phase
 // outputs (the reference STOPs at that point, so nothing downstream can observe the difference).
-template <int STRIDE>
-NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base) {
+//
+// `runner` executes iterations 2..20 of the canopy loop (SimpleLoop: each lane its own column).  The interface
+// lets a runner synchronise the workgroup, which is why threads without a column (cls == 2) may call this
+// function too and every phase is guarded by `live`; see DESIGN.md section 6 for the lane-compaction runner that
+// was measured and dropped.
+template <int STRIDE, class Runner>
+NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base, Runner& runner) {
   Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
   // value-initialise (NOT memset(): HIP's device memset is a byte loop through a pointer PHI, which
   // pins the whole struct in scratch and defeats scalar replacement -- 556 B/lane of scratch traffic)
   Col s = {};
+  Parm P = {};
+  bool live = (cls == 0);          // advances through NOAHMP_SFLX
+  int failed = 0;
   NMP_TIC0();
+  if (cls <= 1) {
   // ---- gather, drv:449-545
   s.cosz = G2(coszin); s.lat = G2(xlatin);
   s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
@@ -155,32 +164,40 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   if (soiltyp == 14 && G2(xice) == 0.f) soiltyp = 7;
   if (vegtyp == k.a.isurban || vegtyp == 31 || vegtyp == 32 || vegtyp == 33) vegtyp = k.a.isurban;
   if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }
-  Parm P;
   NMP_TIC(0);    // gather
   redprm(k.c, s, P, vegtyp, soiltyp);
   NMP_TIC(1);    // redprm
   s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
-  if (s.err) return s.err;                                                         // REDPRM fatals, lsm:9266-9344
+  if (s.err) { failed = s.err; live = false; }                                     // REDPRM fatals, lsm:9266-9344
+  }  // cls <= 1
 
-  float qfx_out, lh_out;
-  if (cls == 1) {
+  float qfx_out = 0.f, lh_out = 0.f;
+  if (cls == 1 && !failed) {
     s.tbot = fminf(s.tbot, 263.15f);                                               // drv:555
     glacier(k.c, s, y);
-    if (s.err) return s.err;
-    glacier_fill_undefined(s);                                                     // drv:571-625
-    qfx_out = s.edir; lh_out = s.fgev;                                             // drv:627-628
-    scatter_energy_outputs(k, s, ij);
-  } else {
-    float beg_wb;
-    sflx_energy(k.c, P, s, y, beg_wb);
-    if (s.err) return s.err;
-    lh_out = s.fcev + s.fgev + s.fctr;                                             // drv:714
-    scatter_energy_outputs(k, s, ij);
-    NMP_TIC(11);   // energy tail + early scatter
-    sflx_water(k.c, P, s, y, beg_wb);
-    if (s.err) return s.err;
-    qfx_out = s.ecan + s.edir + s.etran;                                           // drv:713
+    if (s.err) failed = s.err;
+    else {
+      glacier_fill_undefined(s);                                                   // drv:571-625
+      qfx_out = s.edir; lh_out = s.fgev;                                           // drv:627-628
+      scatter_energy_outputs(k, s, ij);
+    }
   }
+  {
+    float beg_wb = 0.f;
+    sflx_energy(k.c, P, s, y, beg_wb, live, runner);                               // all threads (see above)
+    if (live) {
+      if (s.err) failed = s.err;
+      else {
+        lh_out = s.fcev + s.fgev + s.fctr;                                         // drv:714
+        scatter_energy_outputs(k, s, ij);
+        NMP_TIC(11);   // energy tail + early scatter
+        sflx_water(k.c, P, s, y, beg_wb);
+        if (s.err) failed = s.err;
+        qfx_out = s.ecan + s.edir + s.etran;                                       // drv:713
+      }
+    }
+  }
+  if (cls > 1 || failed) return failed;
   // ---- scatter of everything the water phase (or the glacier tail) produced, drv:728-835
   G2(qfx) = qfx_out; G2(lh) = lh_out;
   G2(smstav) = 0.0f; G2(smstot) = 0.0f;

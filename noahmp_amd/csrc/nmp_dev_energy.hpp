@@ -312,12 +312,12 @@ struct MoState {
 };
 
 // SFCDIF1 lsm:4061-4220
-NMP_DEV void sfcdif1(Col& s, int iter, float sfctmp, float rhoair, float h, float qair, float zlvl,
+NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, float rhoair, float h, float qair, float zlvl,
                      float zpd, float z0m, float z0h, float ur, float mpe, MoState& m, float& cm,
                      float& ch) {
   float mozold = m.moz;
   float moz2, fmnew, fhnew, fm2new, fh2new;
-  if (zlvl <= zpd) { raise(s, NOAHMP_ERR_STABILITY_STOP); }
+  if (zlvl <= zpd) { if (!err) err = NOAHMP_ERR_STABILITY_STOP; }
   if (iter == 1) {                     // zlvl, zpd, z0m are fixed over the caller's loop
     m.tmpcm = nmp_logf((zlvl - zpd) / z0m);
     m.tmpcm2 = nmp_logf((2.0f + z0m) / z0m);
@@ -511,131 +511,194 @@ struct VegIn {
         parsun, parsha, df_top, dz_top, stc_top;
 };
 
-NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float& cmv, float& psnsun,
-                       float& psnsha) {
-  const noahmp_tables* T = c.T;
-  const int v = s.vegtyp - 1;
+// ---- the canopy iteration (loop1 of VEGE_FLUX, lsm:3234-3459) as an explicit state machine ------------------
+// Trip counts of this loop run from 6 to NITERC = 20 and differ from column to column: a 64-lane wavefront needs
+// ~18 rounds for a mean of ~9.  Everything an iteration reads or carries is in VegLoop, so
+// that a runner can decide where and when a column's iterations execute.
+struct VegLoop {
+  // fixed during the loop
+  float sfctmp, rhoair, qair, zlvl, zpd, z0m, ur, z0mg, hcan, cwp, vaie, sqrt_dleaf_uc, fveg, tg, laisune,
+        laishae, rssun, rssha, rsurf, eair, estg, gammav, air, cir, canliq, canice, latheav, sav, fwet, sfcprs,
+        thair, czil;
+  // carried from iteration to iteration / read after the loop
+  MoState mo;
+  float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, qsfc,
+        wstar;
+  int liter, err, iter, done;    // iter = the next iteration to run (2..21); done = loop1 has exited
+};
+constexpr int VEGLOOP_WORDS = sizeof(VegLoop) / 4;
+
+struct VegFirst {   // what only iteration 1 needs (STOMATA / CANRES run there, lsm:3287-3320)
+  const Parm* P; int v; float parsun, parsha, foln, o2air, co2air, igs, btran; float psnsun, psnsha;
+};
+
+// one pass of the loop body, lsm:3236-3456
+template <bool FIRST>
+NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   const float MPE = 1E-6f;
-  const float fveg = s.fveg, rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur;
-  int liter = 0;
-  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float dtv = 0.f, hg = 0.f, h = 0.f, wstar = 0.f;
-  float t, estg, destg, estv = 0.f, destv = 0.f;
-  float rahc = 0.f, rawc, rahg = 0.f, rawg = 0.f, rb = 0.f, fhg = 0.f;
-  float cah = 0.f, cvh = 0.f, cgh, cond, ata, bta, csh, caw, cew, ctw, cgw, aea, bea, cev, ctr;
-  float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah; float& ch = s.chv;
-  float& cm = cmv;
-  const float z0h = q.z0m, z0hg = q.z0mg;
-  float vaie = fminf(6.f, q.vai / fveg);
-  float laisune = fminf(6.f, q.laisun / fveg);
-  float laishae = fminf(6.f, q.laisha / fveg);
-  t = tdc(tg);
-  esat_sel(t, estg, destg);
-  s.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
-  const float hcan = s.htop;
-  float uc = ur * nmp_logf(hcan / q.z0m) / nmp_logf(q.zlvl / q.z0m);
-  if ((hcan - q.zpd) <= 0.f) raise(s, NOAHMP_ERR_HCAN_LE_ZPD);
-  float air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(tg);
-  float cir = (2.f - q.emv * (1.f - q.emg)) * q.emv * SB;
-  const float dleaf = T->dleaf[v];
-  const float sqrt_dleaf_uc = sqrtf(dleaf / uc);        // loop-invariant factor of RB (lsm:4054)
-#pragma unroll 1
-  for (int iter = 1; iter <= 20; iter++) {              // loop1, NITERC = 20 (lsm:3234)
-    if (c.O.sfc == 1) {
-      sfcdif1(s, iter, sfctmp, rhoair, h, s.qair, q.zlvl, q.zpd, q.z0m, z0h, ur, MPE, mo, cm, ch);
-    } else {
-      sfcdif2(iter, q.z0m, tah, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
-      ch = ch / ur;
-      cm = cm / ur;
-    }
-    NMP_TIC(16);   // vege loop1: sfcdif
-    rahc = fmaxf(1.f, 1.f / (ch * ur));
-    rawc = rahc;
-    {                                                   // RAGRB lsm:3960-4057
-      float mozg = 0.f, fhgnew;
-      if (iter > 1) {
-        float tmp1 = VKC * (GRAV / tah) * hg / (rhoair * CPAIR);
-        if (fabsf(tmp1) <= MPE) tmp1 = MPE;
-        float molg = -1.f * powi3(mo.fv) / tmp1;
-        mozg = fminf((q.zpd - q.z0mg) / molg, 1.f);
-      }
-      if (mozg < 0.f) fhgnew = pow_neg_quarter(1.f - 15.f * mozg);
-      else fhgnew = 1.f + 4.7f * mozg;
-      if (iter == 1) fhg = fhgnew;
-      else fhg = 0.5f * (fhg + fhgnew);
-      float cwpc = pow_half(q.cwp * vaie * hcan * fhg);
-      float tmp1 = nmp_expf(-cwpc * z0hg / hcan);
-      float tmp2 = nmp_expf(-cwpc * (z0h + q.zpd) / hcan);
-      float tmprah2 = hcan * nmp_expf(cwpc) / cwpc * (tmp1 - tmp2);
-      float kh = fmaxf(VKC * mo.fv * (hcan - q.zpd), MPE);
-      rahg = tmprah2 / kh;
-      rawg = rahg;
-      float tmprb = cwpc * 50.f / (1.f - nmp_expf(-cwpc / 2.f));
-      rb = tmprb * sqrt_dleaf_uc;
-    }
-    NMP_TIC(17);   // vege loop1: ragrb
-    t = tdc(tv);
-    esat_sel(t, estv, destv);
-    NMP_TIC(18);   // vege loop1: esat
-    if (iter == 1) {
-#pragma unroll 1
-      for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
-        float par = leaf ? q.parsha : q.parsun, rs_, psn_;
-        if (c.O.crs == 1)
-          stomata(c, v, MPE, par, s.foln, tv, estv, eah, sfctmp, s.sfcprs, s.o2air, s.co2air, s.igs,
-                  s.btran, rb, rs_, psn_);
-        else
-          canres(P, par, tv, s.btran, eah, s.sfcprs, rs_, psn_);
-        if (leaf) { s.rssha = rs_; psnsha = psn_; } else { s.rssun = rs_; psnsun = psn_; }
-      }
-    }
-    NMP_TIC(19);   // vege loop1: stomata (first iteration only)
-    cah = 1.f / rahc;
-    cvh = 2.f * vaie / rb;
-    cgh = 1.f / rahg;
-    cond = cah + cvh + cgh;
-    ata = (sfctmp * cah + tg * cgh) / cond;
-    bta = cvh / cond;
-    csh = (1.f - bta) * rhoair * CPAIR * cvh;
-    caw = 1.f / rawc;
-    cew = s.fwet * vaie / rb;
-    ctw = (1.f - s.fwet) * (laisune / (rb + s.rssun) + laishae / (rb + s.rssha));
-    cgw = 1.f / (rawg + q.rsurf);
-    cond = caw + cew + ctw + cgw;
-    aea = (s.eair * caw + estg * cgw) / cond;
-    bea = (cew + ctw) / cond;
-    cev = (1.f - bea) * cew * rhoair * CPAIR / q.gammav;
-    ctr = (1.f - bea) * ctw * rhoair * CPAIR / q.gammav;
-    tah = ata + bta * tv;
-    eah = aea + bea * estv;
-    s.irc = fveg * (air + cir * powi4(tv));
-    s.shc = fveg * rhoair * CPAIR * cvh * (tv - tah);
-    s.evc = fveg * rhoair * CPAIR * cew * (estv - eah) / q.gammav;
-    s.tr = fveg * rhoair * CPAIR * ctw * (estv - eah) / q.gammav;
-    if (tv > TFRZ) s.evc = fminf(s.canliq * s.latheav / c.dt, s.evc);
-    else s.evc = fminf(s.canice * s.latheav / c.dt, s.evc);
-    float b = s.sav - s.irc - s.shc - s.evc - s.tr;
-    float a = fveg * (4.f * cir * powi3(tv) + csh + (cev + ctr) * destv);
-    dtv = b / a;
-    s.irc = s.irc + fveg * 4.f * cir * powi3(tv) * dtv;
-    s.shc = s.shc + fveg * csh * dtv;
-    s.evc = s.evc + fveg * cev * destv * dtv;
-    s.tr = s.tr + fveg * ctr * destv * dtv;
-    tv = tv + dtv;
-    h = rhoair * CPAIR * (tah - sfctmp) / rahc;
-    hg = rhoair * CPAIR * (tg - tah) / rahg;
-    s.qsfc = (0.622f * eah) / (s.sfcprs - 0.378f * eah);
-    NMP_TIC(20);   // vege loop1: flux solve
-    if (liter == 1) break;
-    if (iter >= 5 && fabsf(dtv) <= 0.01f && liter == 0) liter = 1;
+  const float sfctmp = L.sfctmp, rhoair = L.rhoair, ur = L.ur, fveg = L.fveg, tg = L.tg;
+  const float z0h = L.z0m, z0hg = L.z0mg, hcan = L.hcan;
+  if (c.O.sfc == 1) {
+    sfcdif1(L.err, iter, sfctmp, rhoair, L.h, L.qair, L.zlvl, L.zpd, L.z0m, z0h, ur, MPE, L.mo, L.cm, L.ch);
+  } else {
+    sfcdif2(iter, L.z0m, L.tah, L.thair, ur, L.czil, L.zlvl, L.cm, L.ch, L.mo.moz, L.wstar, L.mo.fv);
+    L.ch = L.ch / ur;
+    L.cm = L.cm / ur;
   }
+  NMP_TIC(16);   // vege loop1: sfcdif
+  L.rahc = fmaxf(1.f, 1.f / (L.ch * ur));
+  const float rawc = L.rahc;
+  {                                                   // RAGRB lsm:3960-4057
+    float mozg = 0.f, fhgnew;
+    if (!FIRST) {
+      float tmp1 = VKC * (GRAV / L.tah) * L.hg / (rhoair * CPAIR);
+      if (fabsf(tmp1) <= MPE) tmp1 = MPE;
+      float molg = -1.f * powi3(L.mo.fv) / tmp1;
+      mozg = fminf((L.zpd - L.z0mg) / molg, 1.f);
+    }
+    if (mozg < 0.f) fhgnew = pow_neg_quarter(1.f - 15.f * mozg);
+    else fhgnew = 1.f + 4.7f * mozg;
+    if (FIRST) L.fhg = fhgnew;
+    else L.fhg = 0.5f * (L.fhg + fhgnew);
+    float cwpc = pow_half(L.cwp * L.vaie * hcan * L.fhg);
+    float tmp1 = nmp_expf(-cwpc * z0hg / hcan);
+    float tmp2 = nmp_expf(-cwpc * (z0h + L.zpd) / hcan);
+    float tmprah2 = hcan * nmp_expf(cwpc) / cwpc * (tmp1 - tmp2);
+    float kh = fmaxf(VKC * L.mo.fv * (hcan - L.zpd), MPE);
+    L.rahg = tmprah2 / kh;
+    float tmprb = cwpc * 50.f / (1.f - nmp_expf(-cwpc / 2.f));
+    L.rb = tmprb * L.sqrt_dleaf_uc;
+  }
+  const float rawg = L.rahg, rb = L.rb;
+  NMP_TIC(17);   // vege loop1: ragrb
+  float t = tdc(L.tv);
+  esat_sel(t, L.estv, L.destv);
+  const float estv = L.estv, destv = L.destv;
+  NMP_TIC(18);   // vege loop1: esat
+  if (FIRST) {
+#pragma unroll 1
+    for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
+      float par = leaf ? f->parsha : f->parsun, rs_, psn_;
+      if (c.O.crs == 1)
+        stomata(c, f->v, MPE, par, f->foln, L.tv, estv, L.eah, sfctmp, L.sfcprs, f->o2air, f->co2air, f->igs,
+                f->btran, rb, rs_, psn_);
+      else
+        canres(*f->P, par, L.tv, f->btran, L.eah, L.sfcprs, rs_, psn_);
+      if (leaf) { L.rssha = rs_; f->psnsha = psn_; } else { L.rssun = rs_; f->psnsun = psn_; }
+    }
+  }
+  NMP_TIC(19);   // vege loop1: stomata (first iteration only)
+  L.cah = 1.f / L.rahc;
+  L.cvh = 2.f * L.vaie / rb;
+  const float cah = L.cah, cvh = L.cvh;
+  float cgh = 1.f / L.rahg;
+  float cond = cah + cvh + cgh;
+  float ata = (sfctmp * cah + tg * cgh) / cond;
+  float bta = cvh / cond;
+  float csh = (1.f - bta) * rhoair * CPAIR * cvh;
+  float caw = 1.f / rawc;
+  float cew = L.fwet * L.vaie / rb;
+  float ctw = (1.f - L.fwet) * (L.laisune / (rb + L.rssun) + L.laishae / (rb + L.rssha));
+  float cgw = 1.f / (rawg + L.rsurf);
+  cond = caw + cew + ctw + cgw;
+  float aea = (L.eair * caw + L.estg * cgw) / cond;
+  float bea = (cew + ctw) / cond;
+  float cev = (1.f - bea) * cew * rhoair * CPAIR / L.gammav;
+  float ctr = (1.f - bea) * ctw * rhoair * CPAIR / L.gammav;
+  L.tah = ata + bta * L.tv;
+  L.eah = aea + bea * estv;
+  L.irc = fveg * (L.air + L.cir * powi4(L.tv));
+  L.shc = fveg * rhoair * CPAIR * cvh * (L.tv - L.tah);
+  L.evc = fveg * rhoair * CPAIR * cew * (estv - L.eah) / L.gammav;
+  L.tr = fveg * rhoair * CPAIR * ctw * (estv - L.eah) / L.gammav;
+  if (L.tv > TFRZ) L.evc = fminf(L.canliq * L.latheav / c.dt, L.evc);
+  else L.evc = fminf(L.canice * L.latheav / c.dt, L.evc);
+  float b = L.sav - L.irc - L.shc - L.evc - L.tr;
+  float a = fveg * (4.f * L.cir * powi3(L.tv) + csh + (cev + ctr) * destv);
+  L.dtv = b / a;
+  L.irc = L.irc + fveg * 4.f * L.cir * powi3(L.tv) * L.dtv;
+  L.shc = L.shc + fveg * csh * L.dtv;
+  L.evc = L.evc + fveg * cev * destv * L.dtv;
+  L.tr = L.tr + fveg * ctr * destv * L.dtv;
+  L.tv = L.tv + L.dtv;
+  L.h = rhoair * CPAIR * (L.tah - sfctmp) / L.rahc;
+  L.hg = rhoair * CPAIR * (tg - L.tah) / L.rahg;
+  L.qsfc = (0.622f * L.eah) / (L.sfcprs - 0.378f * L.eah);
+  NMP_TIC(20);   // vege loop1: flux solve
+  NMP_CNT(7);    // (host-emulation instrumentation) loop1 iterations
+  // loop control, lsm:3451-3456
+  if (L.liter == 1) L.done = 1;
+  else if (iter >= 5 && fabsf(L.dtv) <= 0.01f && L.liter == 0) L.liter = 1;
+  L.iter = iter + 1;
+  if (L.iter > 20) L.done = 1;                        // NITERC = 20 (lsm:3234)
+}
+
+// iterations 2.. of a column until it exits or `last` has been run
+NMP_DEV void vege_run_until(const Ctx& c, VegLoop& L, int last) {
+#pragma unroll 1
+  while (!L.done && L.iter <= last) vege_iter<false>(c, L, L.iter, nullptr);
+}
+
+// The plain runner: every lane iterates its own column to the end.
+struct SimpleLoop {
+  NMP_DEV void run(const Ctx& c, VegLoop& L, bool active) const {
+    if (active) vege_run_until(c, L, 20);
+  }
+};
+
+// VEGE_FLUX lsm:3018-3589.  All threads call it (the runner may contain workgroup barriers); `canopy` says
+// whether this thread has a vegetated column to work on.
+template <class Runner>
+NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float& cmv, float& psnsun,
+                       float& psnsha, const bool canopy, Runner& runner) {
+  const noahmp_tables* T = c.T;
+  const float MPE = 1E-6f;
+  VegLoop L = {};
+  L.done = 1;
+  if (canopy) {
+    const int v = s.vegtyp - 1;
+    const float fveg = s.fveg, ur = q.ur;
+    L.sfctmp = s.sfctmp; L.rhoair = s.rhoair; L.qair = s.qair; L.zlvl = q.zlvl; L.zpd = q.zpd; L.z0m = q.z0m;
+    L.ur = ur; L.z0mg = q.z0mg; L.cwp = q.cwp; L.fveg = fveg; L.rsurf = q.rsurf; L.eair = s.eair;
+    L.gammav = q.gammav; L.canliq = s.canliq; L.canice = s.canice; L.latheav = s.latheav; L.sav = s.sav;
+    L.fwet = s.fwet; L.sfcprs = s.sfcprs; L.thair = s.thair; L.czil = P.czil;
+    L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
+    L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
+    L.vaie = fminf(6.f, q.vai / fveg);
+    L.laisune = fminf(6.f, q.laisun / fveg);
+    L.laishae = fminf(6.f, q.laisha / fveg);
+    float t = tdc(L.tg), destg_unused;
+    esat_sel(t, L.estg, destg_unused);
+    L.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
+    L.hcan = s.htop;
+    float uc = ur * nmp_logf(L.hcan / q.z0m) / nmp_logf(q.zlvl / q.z0m);
+    if ((L.hcan - q.zpd) <= 0.f) raise(s, NOAHMP_ERR_HCAN_LE_ZPD);
+    L.air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(L.tg);
+    L.cir = (2.f - q.emv * (1.f - q.emg)) * q.emv * SB;
+    L.sqrt_dleaf_uc = sqrtf(T->dleaf[v] / uc);          // loop-invariant factor of RB (lsm:4054)
+    L.irc = s.irc; L.shc = s.shc; L.evc = s.evc; L.tr = s.tr;
+    L.done = 0; L.iter = 1;
+    VegFirst f = {&P, v, q.parsun, q.parsha, s.foln, s.o2air, s.co2air, s.igs, s.btran, 0.f, 0.f};
+    vege_iter<true>(c, L, 1, &f);                       // iteration 1 (with STOMATA / CANRES)
+    psnsun = f.psnsun; psnsha = f.psnsha;
+  }
+  runner.run(c, L, canopy);                             // iterations 2..20
   NMP_TIC(21);
+  if (!canopy) return;
+  if (L.err) raise(s, L.err);
+  float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah;
+  const float rhoair = s.rhoair;
+  tv = L.tv; tah = L.tah; eah = L.eah; cmv = L.cm;
+  s.rssun = L.rssun; s.rssha = L.rssha;
+  s.irc = L.irc; s.shc = L.shc; s.evc = L.evc; s.tr = L.tr; s.qsfc = L.qsfc;
+  const float rahg = L.rahg, rawg = L.rahg, cah = L.cah, cvh = L.cvh, z0h = q.z0m, fveg = s.fveg;
+  float t, estg = L.estg, destg = 0.f;
   // under-canopy ground, lsm:3495-3542
-  air = -q.emg * (1.f - q.emv) * s.lwdn - q.emg * q.emv * SB * powi4(tv);
-  cir = q.emg * SB;
-  csh = rhoair * CPAIR / rahg;
-  cev = rhoair * CPAIR / (q.gammag * (rawg + q.rsurf));
-  cgh = 2.f * q.df_top / q.dz_top;
+  float air = -q.emg * (1.f - q.emv) * s.lwdn - q.emg * q.emv * SB * powi4(tv);
+  float cir = q.emg * SB;
+  float csh = rhoair * CPAIR / rahg;
+  float cev = rhoair * CPAIR / (q.gammag * (rawg + q.rsurf));
+  float cgh = 2.f * q.df_top / q.dz_top;
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop2, NITERG = 5
     t = tdc(tg);
@@ -663,7 +726,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     }
   }
   // 2-m diagnostics lsm:3557-3571 (OPT_SFC 1/2; FH2 is 0 under OPT_SFC=2)
-  float cah2 = mo.fv * VKC / (nmp_logf((2.f + z0h) / z0h) - mo.fh2);
+  float cah2 = L.mo.fv * VKC / (nmp_logf((2.f + z0h) / z0h) - L.mo.fh2);
   s.chv2 = cah2;
   if (cah2 < 1.E-5f) {
     s.t2mv = tah;
@@ -672,7 +735,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     s.t2mv = tah - (s.shg + s.shc / fveg) / (rhoair * CPAIR) * 1.f / cah2;
     s.q2v = s.qsfc - ((s.evc + s.tr) / fveg + s.evg) / (s.latheav * rhoair) * 1.f / cah2;
   }
-  ch = cah;
+  s.chv = cah;
   s.chleaf = cvh;
   s.chuc = 1.f / rahg;
 }
@@ -692,7 +755,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
     if (c.O.sfc == 1) {
-      sfcdif1(s, iter, sfctmp, rhoair, h, s.qair, q.zlvl, zpdg, z0m, z0h, ur, MPE, mo, cm, ch);
+      sfcdif1(s.err, iter, sfctmp, rhoair, h, s.qair, q.zlvl, zpdg, z0m, z0h, ur, MPE, mo, cm, ch);
     } else {
       sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
       ch = ch / ur;
@@ -989,18 +1052,27 @@ NMP_DEV float at_top(const float* a, int isnow) {
 }
 
 // ENERGY lsm:1231-1843
-template <class A>
-NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
+// All threads of the workgroup call it: `live` says whether this thread carries a land column; the canopy
+// iteration runner in the middle may synchronise the workgroup (CompactLoop).
+template <class A, class Runner>
+NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const bool live, Runner& runner) {
   const noahmp_tables* T = c.T;
   const int v = s.vegtyp - 1;
   const float MPE = 1.E-6f, PSIWLT = -150.f, Z0 = 0.01f;
   float psnsun = 0.f, psnsha = 0.f;
+  VegIn q = {};
+  bool veg = false;
+  float zpdg = 0.f;
+  RadOut r = {};
+  float df[NL], hcpct[NL], fact[NL];
+#pragma unroll
+  for (int k = 0; k < NL; k++) { df[k] = 0.f; hcpct[k] = 0.f; fact[k] = 0.f; }
+  if (live) {
   s.irc = 0.f; s.shc = 0.f; s.irg = 0.f; s.shg = 0.f; s.evg = 0.f; s.evc = 0.f; s.tr = 0.f;
   s.ghv = 0.f; s.t2mv = 0.f; s.q2v = 0.f; s.chv = 0.f; s.chleaf = 0.f; s.chuc = 0.f; s.chv2 = 0.f;
-  VegIn q;
   q.ur = fmaxf(sqrtf(s.uu * s.uu + s.vv * s.vv), 1.f);          // UU**2.+VV**2. (lsm:1536)
   q.vai = s.elai + s.esai;
-  const bool veg = (q.vai > 0.f);
+  veg = (q.vai > 0.f);
   s.fsno = 0.f;
   if (s.snowh > 0.f) {
     float bdsno = s.sneqv / s.snowh;
@@ -1008,7 +1080,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
     s.fsno = nmp_tanhf(s.snowh / (2.5f * Z0 * fmelt));
   }
   q.z0mg = Z0 * (1.0f - s.fsno) + s.fsno * Z0SNO;
-  const float zpdg = s.snowh;
+  zpdg = s.snowh;
   if (veg) {
     q.z0m = T->z0mvt[v];
     q.zpd = 0.65f * s.htop;
@@ -1020,13 +1092,10 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   q.zlvl = fmaxf(q.zpd, s.htop) + s.zlvl;
   if (zpdg >= q.zlvl) q.zlvl = zpdg + s.zlvl;
   q.cwp = T->cwpvt[v];
-  float df[NL], hcpct[NL], fact[NL];
-#pragma unroll
-  for (int k = 0; k < NL; k++) { df[k] = 0.f; hcpct[k] = 0.f; fact[k] = 0.f; }
   NMP_TIC(2);    // energy: preamble
   thermoprop(c, P, s, y, df, hcpct, fact);
   NMP_TIC(3);    // thermoprop
-  RadOut r = radiation(c, s, y.smc[L(1)]);
+  r = radiation(c, s, y.smc[L(1)]);
   NMP_TIC(4);    // radiation
   q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
   q.emv = 1.f - nmp_expf(-(s.elai + s.esai) / 1.0f);
@@ -1075,16 +1144,18 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   q.dz_top = y.dzsnso[L(s.isnow + 1)];
   q.stc_top = y.stc[L(s.isnow + 1)];
 
-  float cmv = 0.f, cmb;
-  const bool canopy = veg && s.fveg > 0;
+  }  // live
+  float cmv = 0.f, cmb = 0.f;
+  const bool canopy = live && veg && s.fveg > 0;
   NMP_TIC(5);    // btran, rsurf, psychrometric constants
   if (canopy) {
     s.tgv = s.tg;
     cmv = s.cm;
     s.chv = s.ch;
-    vege_flux(c, P, s, q, cmv, psnsun, psnsha);
   }
+  vege_flux(c, P, s, q, cmv, psnsun, psnsha, canopy, runner);
   NMP_TIC(6);    // vege_flux
+  if (!live) return;
   s.tgb = s.tg;
   cmb = s.cm;
   s.chb = s.ch;

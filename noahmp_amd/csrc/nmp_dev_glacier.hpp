@@ -309,7 +309,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     float& tgb = s.tg;
 #pragma unroll 1
     for (int iter = 1; iter <= 5; iter++) {
-      sfcdif1(s, iter, s.sfctmp, s.rhoair, h, s.qair, zlvl, zpd, z0m, z0m, ur, MPE, mo, s.cm, s.ch);
+      sfcdif1(s.err, iter, s.sfctmp, s.rhoair, h, s.qair, zlvl, zpd, z0m, z0m, ur, MPE, mo, s.cm, s.ch);
       rahb = fmaxf(1.f, 1.f / (s.ch * ur));
       float rawb = rahb;
       t = tdc(tgb);

@@ -174,9 +174,13 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
 
 // NOAHMP_SFLX lsm:518-947 (with ATM lsm:949-1007 and ERROR lsm:1106-1228)
 // Split in two phases so that the caller can store the energy-phase outputs before the water phase.
-template <class A>
-NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float& beg_wb_out) {
+// Called by ALL threads of the workgroup (`live` = this thread carries a land column): see energy().
+template <class A, class Runner>
+NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float& beg_wb_out, const bool live,
+                         Runner& runner) {
   const noahmp_tables* T = c.T;
+  float beg_wb = 0.f;
+  if (live) {
   s.nee = 0.f; s.npp = 0.f; s.gpp = 0.f;
   // ATM
   s.thair = s.sfctmp;                                  // SFCTMP*(SFCPRS/PAIR)**(RAIR/CPAIR), PAIR==SFCPRS
@@ -200,7 +204,7 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
       }
     }
   }
-  float beg_wb = s.canliq + s.canice + s.sneqv + s.wa;
+  beg_wb = s.canliq + s.canice + s.sneqv + s.wa;
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) beg_wb = beg_wb + y.smc[L(iz)] * y.dzsnso[L(iz)] * 1000.f;
   phenology(c, s);
@@ -219,8 +223,10 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
   }
   if (s.vegtyp == c.isurban || s.vegtyp == T->isbarren) s.fveg = 0.0f;
   if (s.elai + s.esai == 0.0f) s.fveg = 0.0f;
+  }  // live
 
-  energy(c, P, s, y);
+  energy(c, P, s, y, live, runner);
+  if (!live) return;
 
   s.sneqvo = s.sneqv;
   beg_wb_out = beg_wb;

@@ -48,7 +48,8 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
     }
   }
   if (cls > 1) return;
-  const int err = column_step<STRIDE>(k, cls, ii, jj, ij, base);
+  SimpleLoop runner;
+  const int err = column_step<STRIDE>(k, cls, ii, jj, ij, base, runner);
   if (err) atomicMin(k.err, ((unsigned long long)(t + 1) << 8) | (unsigned)err);   // first column wins
 }
 

@@ -45,7 +45,8 @@ extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
     if (cls == 2) st->n_skipped++;
     if (cls > 1) continue;
     if (cls == 0) st->n_land++; else st->n_glacier++;
-    int err = column_step<1>(k, cls, ii, jj, ij, base);
+    SimpleLoop runner;
+    int err = column_step<1>(k, cls, ii, jj, ij, base, runner);
     if (err && !st->code) { st->code = err; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
   }
   return st->code;

@@ -59,3 +59,36 @@ def test_fortran_shim_end_to_end(engine, tables):
     for k in via_c.a:
         if FIELD_INFO[k][2] != "in":
             np.testing.assert_array_equal(via_c.a[k], via_f.a[k], err_msg=k)
+
+
+def test_groundwater_shim_signature_matches_reference_order():
+    """Dummy-argument order of the generated WTABLE_mmf_noahmp == gw:14-22 (as recorded in abi_spec)."""
+    from noahmp_amd.abi_spec import WTABLE_FIELDS
+    src = open(os.path.join(os.path.dirname(abi.__file__), "fortran", "module_sf_noahmpdrv_hip.F90")).read().upper()
+    at = src.index("SUBROUTINE WTABLE_MMF_NOAHMP(")
+    head = src[at:src.index("USE ISO_C_BINDING", at)]
+    names = [x.strip() for x in head[head.index("(") + 1:head.rindex(")")].replace("&", "").replace("\n", "").split(",")]
+    assert names == [n.upper() for n, k, l, io, ln in WTABLE_FIELDS]
+    assert names[:4] == ["NSOIL", "XLAND", "XICE", "XICE_THRESHOLD"] and names[-1] == "KTE"
+
+
+@pytest.mark.gpu
+@needs_flang
+def test_fortran_groundwater_shim_end_to_end(engine, tables):
+    """WTABLE_mmf_noahmp called the way hdrv:424-434 calls it gives the bits of the direct C-ABI call."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_groundwater import gw_store, GW_OUT
+    from oracle.reflib import RefLib
+    ref = RefLib("O0")
+    ref.set_tables(tables[0])
+    lib = C.CDLL(build_shim.build())
+    lib.shim_wtable_mmf.argtypes = [C.POINTER(abi.WtableArgs)]
+    s = gw_store(tables, ni=48, nj=24, stress=0.02)
+    via_c, via_f = s.copy(), s.copy()
+    engine.wtable_mmf(via_c)
+    w = via_f.wtable_args()
+    lib.shim_wtable_mmf(C.byref(w))
+    engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))
+    for k in GW_OUT:
+        np.testing.assert_array_equal(via_c.a[k], via_f.a[k], err_msg=k)

@@ -75,18 +75,23 @@ def perf(ni=1024, nj=1024):
     s = synth.config2(tb, ni=ni, nj=nj)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
-    for block in ((64, 128, 256) if not os.environ.get("NMP_QUICK") else (64,)):
-        for lds in ((1, 0) if not os.environ.get("NMP_QUICK") else (1,)):
-            eng.set_option("block", block)
-            eng.set_option("lds", lds)
-            d = s.to_device("cuda:0")
-            ms = []
-            for it in range(1, 6):
-                st = eng.noahmplsm(d, it, 2000, 180.0, check=False)
-                ms.append(st.kernel_ms)
-            best = min(ms[1:])
-            print("block %3d lds %d: kernel %.3f ms  -> %.3e col-steps/s (n_land %d, code %d)"
-                  % (block, lds, best, st.n_land / best * 1e3, st.n_land, st.code))
+    hour = int(os.environ.get("NMP_HOUR", "12"))
+    synth.diurnal_forcing(s, hour, t_offset=s.t_offset)
+    ref = None
+    for block, lds in ((64, 1), (64, 0), (128, 1), (256, 1), (256, 0)):
+        eng.set_option("block", block)
+        eng.set_option("lds", lds)
+        d = s.to_device("cuda:0")
+        ms = []
+        for it in range(1, 6):
+            st = eng.noahmplsm(d, it, 2000, 180.0, check=False)
+            ms.append(st.kernel_ms)
+        best = min(ms[1:])
+        chk = float(d.a["tslb"].double().sum().item()) + float(d.a["hfx"].double().sum().item())
+        ref = chk if ref is None else ref
+        print("block %3d lds %d: kernel %.3f ms  -> %.3e col-steps/s (n_land %d, code %d)%s"
+              % (block, lds, best, st.n_land / best * 1e3, st.n_land, st.code,
+                 "" if chk == ref else "  CHECKSUM DIFFERS"))
 
 
 if __name__ == "__main__":
