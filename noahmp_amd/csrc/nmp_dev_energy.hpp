@@ -437,9 +437,26 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
 }
 
 // STOMATA + CI2CI lsm:5323-5464 (bisection on Ci, <= 20 iterations)
+// The temperature-only part of STOMATA (lsm:5505-5516): the sunlit and the shaded call of an iteration get the
+// same TV, so KC/KO/AWC/CP and the Arrhenius factors of VCMX are evaluated once for both (3 powf + 1 expf each).
+struct StomataT { float awc, cp, vcmx_t; };
+NMP_DEV StomataT stomata_temperature(const Ctx& c, int v, float tv, float o2) {
+  const noahmp_tables* T = c.T;
+  StomataT r;
+  float tc = tv - TFRZ;
+  float kc = T->kc25[v] * nmp_powf(T->akc[v], (tc - 25.0f) / 10.0f);
+  float ko = T->ko25[v] * nmp_powf(T->ako[v], (tc - 25.0f) / 10.0f);
+  r.awc = kc * (1.0f + o2 / ko);
+  r.cp = 0.5f * kc / ko * o2 * 0.21f;
+  // VCMX = VCMX25 / F2(TC) * FNF * BTRAN * AVCMX**((TC-25)/10): the first quotient and the last factor are kept
+  // apart because the products in between (FNF, BTRAN) must be applied in the reference's order
+  r.vcmx_t = nmp_expf((-2.2E05f + 710.0f * (tc + TFRZ)) / (8.314f * (tc + TFRZ)));
+  return r;
+}
+
 NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, float tv, float ei,
                      float ea, float sfctmp, float sfcprs, float o2, float co2, float igs,
-                     float btran, float rb, float& rs, float& psn) {
+                     float btran, float rb, const StomataT& st, float avcmx_pow, float& rs, float& psn) {
   const noahmp_tables* T = c.T;
   const float bpv = T->bp[v];
   float cf = sfcprs / (8.314f * sfctmp) * 1.0e06f;
@@ -448,15 +465,10 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
   if (apar <= 0.0f) return;
   const float c3 = T->c3psn[v], mpv = T->mp[v];
   float fnf = fminf(foln / fmaxf(mpe, T->folnmx[v]), 1.0f);
-  float tc = tv - TFRZ;
   float ppf = 4.6f * apar;
   float j = ppf * T->qe25[v];
-  float kc = T->kc25[v] * nmp_powf(T->akc[v], (tc - 25.0f) / 10.0f);
-  float ko = T->ko25[v] * nmp_powf(T->ako[v], (tc - 25.0f) / 10.0f);
-  float awc = kc * (1.0f + o2 / ko);
-  float cp = 0.5f * kc / ko * o2 * 0.21f;
-  float vcmx = T->vcmx25[v] / (1.0f + nmp_expf((-2.2E05f + 710.0f * (tc + TFRZ)) / (8.314f * (tc + TFRZ)))) *
-               fnf * btran * nmp_powf(T->avcmx[v], (tc - 25.0f) / 10.0f);
+  const float awc = st.awc, cp = st.cp;
+  float vcmx = T->vcmx25[v] / (1.0f + st.vcmx_t) * fnf * btran * avcmx_pow;
   float rlb = rb / cf;
   float cihi = 1.5f * co2, cilow = 0.0f;
 #pragma unroll 1
@@ -576,12 +588,18 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   const float estv = L.estv, destv = L.destv;
   NMP_TIC(18);   // vege loop1: esat
   if (FIRST) {
+    StomataT st = {0.f, 0.f, 0.f};
+    float avcmx_pow = 0.f;
+    if (c.O.crs == 1 && (f->parsun > 0.0f || f->parsha > 0.0f)) {   // STOMATA returns early for APAR <= 0
+      st = stomata_temperature(c, f->v, L.tv, f->o2air);
+      avcmx_pow = nmp_powf(c.T->avcmx[f->v], ((L.tv - TFRZ) - 25.0f) / 10.0f);
+    }
 #pragma unroll 1
     for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
       float par = leaf ? f->parsha : f->parsun, rs_, psn_;
       if (c.O.crs == 1)
         stomata(c, f->v, MPE, par, f->foln, L.tv, estv, L.eah, sfctmp, L.sfcprs, f->o2air, f->co2air, f->igs,
-                f->btran, rb, rs_, psn_);
+                f->btran, rb, st, avcmx_pow, rs_, psn_);
       else
         canres(*f->P, par, L.tv, f->btran, L.eah, L.sfcprs, rs_, psn_);
       if (leaf) { L.rssha = rs_; f->psnsha = psn_; } else { L.rssun = rs_; f->psnsun = psn_; }
