@@ -182,8 +182,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "noahmp_column_kernel", "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * ncol,
-                         "note": "824 B/column-step x columns / HIP-event kernel time; the kernel is "
-                                 "latency/transcendental bound, not HBM bound (SURVEY 8d)"},
+                         "note": "824 B/column-step x columns / HIP-event kernel time; the kernel is VALU-issue and "
+                                 "divergence bound (29 k VALU instructions per column-step wave, 74 % lane utilisation: "
+                                 "profiles/r01_profile.md), not HBM bound (SURVEY 8d)"},
             "kernel_only_column_steps_per_s": (n_land / args.steps) / (k_avg_ms * 1e-3) * world,
         }
         if cpu is not None:

@@ -16,14 +16,15 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 KERN = "noahmp_column_kernel"
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = (glob.glob(os.path.join(src, "trace", "*_kernel_stats.csv")) +
+         glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))[0]
 shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
 krow = [r for r in csv.DictReader(open(stats)) if KERN in r["Name"]][0]
 
 pmc = {}
 meta = {}
 for d in ("fetch", "write", "sq", "sq2"):
-    fs = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    fs = glob.glob(os.path.join(src, d, "*_counter_collection.csv")) + glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
     acc = collections.defaultdict(list)
@@ -82,5 +83,32 @@ L += ["", "## Derived", "",
          100 * out["derived"]["valu_active_share_of_wave_cycles"], 100 * out["derived"]["wait_any_share_of_wave_cycles"]),
       "- the kernel is VALU-issue / divergence bound, not HBM bound (SURVEY.md 8d): ~5 flop-equivalents per byte with long dependent chains",
       "", "## bench.py line of the same build (un-profiled run)", "", "```", json.dumps(bench), "```", ""]
+# ---- MMF groundwater kernels (tools/gw_check.py perf, 4608 x 1536 cells)
+gws = glob.glob(os.path.join(src, "gw", "*_kernel_stats.csv"))
+if gws:
+    shutil.copy(gws[0], os.path.join(dst, "%s_gw_kernel_stats.csv" % tag))
+    ncell = 4608 * 1536
+    gpmc = {}
+    for d in ("gw_fetch", "gw_write"):
+        for f in glob.glob(os.path.join(src, d, "*_counter_collection.csv")):
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if "gw_" in r["Kernel_Name"]:
+                    acc[(r["Kernel_Name"].split("(")[1].split("::")[-1] if "::" in r["Kernel_Name"] else r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            for k, v in acc.items():
+                gpmc[k] = sum(v) / len(v)
+    L += ["## MMF groundwater (`tools/gw_check.py perf`, %d cells; copied: %s_gw_kernel_stats.csv)" % (ncell, tag), "",
+          "| kernel | calls | avg ns | algorithmic B/cell | achieved GB/s | % of 8 TB/s | HBM traffic (2xFETCH+WRITE) |", "|---|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(gws[0])):
+        if "gw_" not in r["Name"]:
+            continue
+        nm = "gw_head_kernel" if "gw_head" in r["Name"] else "gw_column_kernel"
+        bpc = 24 if nm == "gw_head_kernel" else 192
+        ns = float(r["AverageNs"])
+        fk = [v for (kn, cn), v in gpmc.items() if nm in kn and cn == "FETCH_SIZE"]
+        wk = [v for (kn, cn), v in gpmc.items() if nm in kn and cn == "WRITE_SIZE"]
+        tr = "%.0f MB" % ((2 * fk[0] + wk[0]) * 1024 / 1e6) if fk and wk else "n/a"
+        L.append("| %s | %s | %.0f | %d | %.0f | %.1f | %s |" % (nm, r["Calls"], ns, bpc, bpc * ncell / ns, 100 * bpc * ncell / ns / 8000, tr))
+    L.append("")
 open(os.path.join(dst, "%s_profile.md" % tag), "w").write("\n".join(L))
 print("\n".join(L[:40]))
