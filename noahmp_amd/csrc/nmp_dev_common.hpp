@@ -46,7 +46,7 @@ NMP_DEV float powi4(float a) { float b = a * a; return b * b; }
 NMP_DEV float powi5(float a) { float b = a * a; return a * (b * b); }
 
 // Transcendentals.  NMP_EXACT_LIBM=1 (default): the reference libm's own algorithms (nmp_libm.hpp), so that
-// EXP / LOG / ** / LOG10 / ATAN / TANH return the reference's bits on the GPU.  NMP_EXACT_LIBM=0: ocml's
+// EXP / LOG / ** / LOG10 / ATAN / TANH / TAN / ACOS / COS return the reference's bits on the GPU.  NMP_EXACT_LIBM=0: ocml's
 // float32 routines (<= 1-2 ulp, a little faster, statistically equivalent results -- DESIGN.md section 5).
 #ifndef NMP_EXACT_LIBM
 #define NMP_EXACT_LIBM 1
@@ -68,6 +68,9 @@ NMP_DEV float nmp_powf(float x, float y) { NMP_CNT(2); return libm::powf_(x, y);
 NMP_DEV float nmp_log10f(float x) { NMP_CNT(3); return libm::log10f_(x); }
 NMP_DEV float nmp_atanf(float x) { NMP_CNT(4); return libm::atanf_(x); }
 NMP_DEV float nmp_tanhf(float x) { NMP_CNT(5); return libm::tanhf_(x); }
+NMP_DEV float nmp_tanf(float x) { return libm::tanf_(x); }     // OPT_RAD=1 only (lsm:2531-2539)
+NMP_DEV float nmp_acosf(float x) { return libm::acosf_(x); }
+NMP_DEV float nmp_cosf(float x) { return libm::cosf_(x); }
 // x**0.25, x**0.5, x**-0.25 with a literal exponent (SFCDIF1, RAGRB): the reference calls powf
 NMP_DEV float pow_quarter(float x) { NMP_CNT(6); return libm::powf_(x, 0.25f); }
 NMP_DEV float pow_half(float x) { NMP_CNT(6); return libm::powf_(x, 0.5f); }
@@ -79,6 +82,9 @@ NMP_DEV float nmp_powf(float x, float y) { return powf(x, y); }
 NMP_DEV float nmp_log10f(float x) { return log10f(x); }
 NMP_DEV float nmp_atanf(float x) { return atanf(x); }
 NMP_DEV float nmp_tanhf(float x) { return tanhf(x); }
+NMP_DEV float nmp_tanf(float x) { return tanf(x); }
+NMP_DEV float nmp_acosf(float x) { return acosf(x); }
+NMP_DEV float nmp_cosf(float x) { return cosf(x); }
 // IEEE sqrt chains (each step correctly rounded, total <= 0.75 ulp, ~10 VALU ops) instead of ocml powf
 NMP_DEV float pow_quarter(float x) { return sqrtf(sqrtf(x)); }
 NMP_DEV float pow_half(float x) { return sqrtf(x); }

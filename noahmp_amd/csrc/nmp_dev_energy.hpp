@@ -119,8 +119,8 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
       float denfveg = -nmp_logf(fmaxf(1.0f - fveg, 0.01f)) / (PAI * powi2(rc));
       float hd = T->hvt[v] - T->hvb[v];
       float bb = 0.5f * hd;
-      float thetap = nmp_atanf(bb / rc * tanf(acosf(fmaxf(0.01f, cosz))));
-      bgap = nmp_expf(-denfveg * PAI * powi2(rc) / cosf(thetap));
+      float thetap = nmp_atanf(bb / rc * nmp_tanf(nmp_acosf(fmaxf(0.01f, cosz))));
+      bgap = nmp_expf(-denfveg * PAI * powi2(rc) / nmp_cosf(thetap));
       float fa = vai / (1.33f * PAI * nmp_powf(rc, 3.0f) * (bb / rc) * denfveg);
       float newvai = hd * fa;
       wgap = (1.0f - bgap) * nmp_expf(-0.5f * newvai / cosz);

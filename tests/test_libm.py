@@ -1,6 +1,6 @@
 """noahmp_amd/csrc/nmp_libm.hpp against the live libm of the machine, bit for bit.
 
-The reference's EXP / LOG / ** / LOG10 / ATAN / TANH resolve to glibc's float32 routines; the device runs
+The reference's EXP / LOG / ** / LOG10 / ATAN / TANH / TAN / ACOS / COS resolve to glibc's float32 routines; the device runs
 restatements of the same algorithms.  CPU: the host compilation of that header over a stride of the whole
 2^32 argument space (the exhaustive run -- stride 1, ~1 min on 8 cores -- gives expf 2 mismatches, which are
 the arguments where x86 libm's FMA variant rounds the float64 polynomial differently; every other routine 0).
@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "host_emul", "libm_check.hip")
 LIB = os.path.join(HERE, "host_emul", "liblibm_check.so")
-NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f"]
+NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f", "powf", "acosf", "tanf", "cosf"]
+UNARY = [0, 1, 2, 3, 4, 5, 7, 8, 9]      # 6 = powf (binary)
 
 
 def _lib():
@@ -35,7 +36,7 @@ def _lib():
     return lib
 
 
-@pytest.mark.parametrize("fn", range(6), ids=NAMES)
+@pytest.mark.parametrize("fn", UNARY, ids=[NAMES[i] for i in UNARY])
 def test_host_build_matches_libm(fn):
     lib = _lib()
     fb = C.c_uint32(0)
@@ -61,7 +62,7 @@ def test_tables_regenerate_identically(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fn", range(7), ids=NAMES + ["powf"])
+@pytest.mark.parametrize("fn", range(10), ids=NAMES)
 def test_device_code_matches_libm(fn):
     lib = _lib()
     fb = C.c_uint32(0)
@@ -71,5 +72,4 @@ def test_device_code_matches_libm(fn):
     else:
         bad = lib.libm_gpu_check(fn, 12345, 256, n, C.byref(fb))          # every 256th bit pattern, all of 2^32
     assert bad >= 0, "HIP error"
-    assert bad <= (1 if fn == 0 else 0), "%s on the GPU: %d mismatches, first at bits 0x%08x" % (
-        (NAMES + ["powf"])[fn], bad, fb.value)
+    assert bad <= (1 if fn == 0 else 0), "%s on the GPU: %d mismatches, first at bits 0x%08x" % (NAMES[fn], bad, fb.value)

@@ -112,11 +112,9 @@ def test_option_sweep_vs_golden(engine):
         assert st.code == 0, kw
         ref = load_store(g, "opt%02d" % n, 32, 4)
         skip = ("t2mvxy", "t2mbxy", "q2mvxy", "q2mbxy", "chv2xy", "chb2xy") if kw.get("iopt_sfc") == 2 else ()
-        if _exact(engine) and kw.get("iopt_rad") != 1:
+        if _exact(engine):
             ok, lines = exact_check(ref, s, fields=_outs(ref), skip=skip)
         else:
-            # OPT_RAD=1 (gap from 3-D crown geometry, lsm:2531-2539) also calls TAN, ACOS and COS, which the
-            # device still takes from ocml: BGAP/WGAP and what follows are compared with tolerances there.
             ok, lines = parity_check(ref, s, steps=1, fields=_outs(ref), skip=skip, frac=0.05)
         assert ok, "%s\n%s" % (kw, "\n".join(lines))
 
