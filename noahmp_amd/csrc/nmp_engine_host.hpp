@@ -31,6 +31,8 @@ struct Engine {
   // groundwater: host-mode mirrors (one per pointer member of noahmp_wtable_args) + KCELL/HEAD planes
   std::vector<void*> gw_mirror;
   std::vector<size_t> gw_mirror_bytes;
+  std::vector<void*> init_mirror;        // noahmp_hip_init host-mode mirrors (noahmp_init.hip)
+  std::vector<size_t> init_mirror_bytes;
   float* gw_kcell = nullptr;
   float* gw_head = nullptr;
   size_t gw_plane_bytes = 0;

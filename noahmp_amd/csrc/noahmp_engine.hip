@@ -306,6 +306,7 @@ void noahmp_hip_finalize(void) {
   for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& b : g.mirror_bytes) b = 0;
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
+  for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   if (g.gw_kcell) hipFree(g.gw_kcell);
   if (g.gw_head) hipFree(g.gw_head);
   if (g.d_tables) hipFree(g.d_tables);

@@ -55,6 +55,22 @@ class Engine:
             raise NoahMPFatal(rc, st.i, st.j, self.lib.noahmp_hip_error_string(rc).decode())
         return st
 
+    def noahmp_init(self, store, fndsnowh=True, stream=None, check=True):
+        """Cold start on the device: NOAHMP_INIT's per-column part + SNOW_INIT (reference drv:988-1283), in place.
+        ide+1 / jde+1 are passed as the reference driver does (hdrv:291; the routine loops to min(ite, ide-1))."""
+        a = store.step_args(1, 2000, 1.0)
+        a.ide += 1
+        a.jde += 1
+        mem = abi.MEM_DEVICE if isinstance(store, DeviceColumnStore) else abi.MEM_HOST
+        st = abi.Status()
+        rc = self.lib.noahmp_hip_init(C.byref(a), store.cfg.iswater, 1 if fndsnowh else 0, mem, stream, C.byref(st))
+        self.last_status = st
+        if rc < 0:
+            raise RuntimeError("noahmp_hip_init: " + self.lib.noahmp_hip_last_error().decode())
+        if rc > 0 and check:
+            raise NoahMPFatal(rc, st.i, st.j, "lsminit: out of range value of ISLTYP (drv:1018)")
+        return st
+
     def wtable_mmf(self, store, stream=None):
         """WTABLE_mmf_noahmp (reference gw:14): lateral groundwater flow + water-table update, in place.
         A decomposed domain must have exchanged the ZWTXY halo first (parallel.exchange_halo)."""

@@ -23,6 +23,7 @@ class PortLib:
         self.lib = C.CDLL(PORT_PATH)
         self.lib.nmp_oracle_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.nmp_oracle_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
+        self.lib.nmp_oracle_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
         self.lib.nmp_oracle_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, tables):
@@ -40,3 +41,12 @@ class PortLib:
         rc = self.lib.nmp_oracle_wtable_mmf(C.byref(w), C.byref(st))
         assert rc == 0, rc
         return st
+
+    def noahmp_init(self, store, fndsnowh=True):
+        """NOAHMP_INIT + SNOW_INIT (drv:847-1283); ide+1 / jde+1 as hdrv:291 passes them."""
+        a = store.step_args(1, 2000, 1.0)
+        a.ide += 1
+        a.jde += 1
+        st = Status()
+        rc = self.lib.nmp_oracle_init(C.byref(a), store.cfg.iswater, 1 if fndsnowh else 0, C.byref(st))
+        return rc, st

@@ -84,3 +84,26 @@ extern "C" int emul_wtable_mmf(const noahmp_wtable_args* a, noahmp_status* st) {
     }
   return 0;
 }
+
+// ---- cold start (noahmp_init.hip's kernel as a host loop over the same device function)
+#include "nmp_dev_init.hpp"
+extern "C" int emul_init(const noahmp_step_args* a, int iswater, int fndsnowh, noahmp_status* st) {
+  (void)iswater;
+  memset(st, 0, sizeof(*st));
+  InitArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.T = &g_t;
+  k.ni = a->ime - a->ims + 1;
+  k.itf = a->ite < a->ide - 1 ? a->ite : a->ide - 1;
+  k.jtf = a->jte < a->jde - 1 ? a->jte : a->jde - 1;
+  k.fndsnowh = fndsnowh;
+  k.zsoil[0] = -a->dzs[0];
+  for (int l = 1; l < NOAHMP_NSOIL; l++) k.zsoil[l] = k.zsoil[l - 1] - a->dzs[l];
+  for (int j = a->jts; j <= k.jtf; j++)
+    for (int i = a->its; i <= k.itf; i++) {
+      int err = init_column(k, i - a->ims, j - a->jms);
+      if (err && !st->code) { st->code = err; st->i = i; st->j = j; }
+    }
+  return st->code;
+}

@@ -27,6 +27,7 @@ class EmulLib:
         self.lib = C.CDLL(LIB)
         self.lib.emul_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
+        self.lib.emul_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
         self.lib.emul_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, t):
@@ -44,3 +45,11 @@ class EmulLib:
         rc = self.lib.emul_wtable_mmf(C.byref(w), C.byref(st))
         assert rc == 0, rc
         return st
+
+    def noahmp_init(self, store, fndsnowh=True):
+        a = store.step_args(1, 2000, 1.0)
+        a.ide += 1
+        a.jde += 1
+        st = Status()
+        rc = self.lib.emul_init(C.byref(a), store.cfg.iswater, 1 if fndsnowh else 0, C.byref(st))
+        return rc, st
