@@ -119,6 +119,7 @@ def load_library(path=None):
     lib.noahmp_hip_step.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_void_p, C.POINTER(Status)]
     lib.noahmp_hip_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Status)]
     lib.noahmp_hip_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.c_int, C.c_void_p, C.POINTER(Status)]
+    lib.noahmp_hip_groundwater_init.argtypes = [C.POINTER(WtableArgs), C.c_int, C.c_int, C.c_void_p, C.POINTER(Status)]
     lib.noahmp_hip_sizeof_wtable_args.restype = C.c_size_t
     lib.noahmp_hip_set_option.argtypes = [C.c_char_p, C.c_int]
     lib.noahmp_hip_error_string.argtypes = [C.c_int]
@@ -140,7 +141,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "noahmp_hip_abi_version", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
     "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
-    "noahmp_hip_step", "noahmp_hip_init", "noahmp_hip_wtable_mmf", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
+    "noahmp_hip_step", "noahmp_hip_init", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
     "noahmp_hip_last_error", "noahmp_hip_finalize",
 ]
 

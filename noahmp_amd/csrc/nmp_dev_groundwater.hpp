@@ -330,4 +330,132 @@ NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) {
   return land ? 1 : 0;
 }
 
+
+// ---- GROUNDWATER_INIT + EQSMOISTURE (reference phys/module_sf_noahmpdrv.F90:1286-1522, "drv"): the one-time
+// equilibrium set-up of the MMF scheme.  Same two-kernel shape as the time step (KCELL/HEAD first, then one thread
+// per cell); only the land mask differs (IVGTYP /= ISWATER and /= ISICE, drv:1340-1344).
+
+// EQSMOISTURE drv:1477-1522: Newton solve for the equilibrium moisture of each soil layer
+NMP_DEV void gw_eqsmoisture(const float* zsoil /*0..4*/, float smcmax, float dwsat, float dksat, float bexp, Soil4& smceq) {
+#pragma unroll
+  for (int k = 1; k <= NSOIL; k++) {
+    float ddz;
+    if (k == 1) ddz = -zsoil[k + 1] * 0.5f;
+    else if (k < NSOIL) ddz = (zsoil[k - 1] - zsoil[k + 1]) * 0.5f;
+    else ddz = zsoil[k - 1] - zsoil[k];
+    const float expon = bexp + 1.f;
+    const float aa = dwsat / ddz;
+    const float bb = dksat / nmp_powf(smcmax, expon);
+    float smc = 0.5f * smcmax;
+#pragma unroll 1
+    for (int iter = 1; iter <= 100; iter++) {
+      const float func = (smc - smcmax) * aa + bb * nmp_powf(smc, expon);
+      const float dfunc = aa + bb * expon * nmp_powf(smc, bexp);
+      const float dx = func / dfunc;
+      smc = smc - dx;
+      if (fabsf(dx) < 1.E-6f) break;
+    }
+    smceq.v[k - 1] = fmin2(fmax2(smc, 1.E-4f), smcmax * 0.99f);
+  }
+}
+
+// one cell of drv:1340-1470.  (i,j): offsets into the memory tile; (gi,gj): Fortran indices.
+NMP_DEV void gw_init_column(const GwArgs& g, int i, int j, int gi, int gj, int iswater) {
+  const noahmp_wtable_args& a = g.a;
+  const int ni = g.ni;
+  const size_t x = (size_t)j * ni + i;
+  const size_t plane = (size_t)ni, x3 = ((size_t)j * NSOIL) * ni + i;
+  float* smoiseq = const_cast<float*>(a.smoiseq);               // INOUT here (drv:1311), IN for the time step
+  const int ivgtyp = a.ivgtyp[x], sl = a.isltyp[x];
+  const bool land = (ivgtyp != iswater) && (ivgtyp != a.isice);
+  float wtd = a.wtd[x];
+  float qlat = 0.f, qrf = 0.f;
+  if (land) {
+    const float area = a.area[x];
+    if (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1) {             // LATERALFLOW gw:259-292
+      const float SQRT2 = 1.41421354f;
+      const float kc = g.kcell[x], hd = g.head[x];
+      const size_t up = x + ni, dn = x - ni;
+      float q = 0.f;
+      q = q + (g.kcell[up - 1] + kc) * (g.head[up - 1] - hd) / SQRT2;
+      q = q + (g.kcell[x - 1] + kc) * (g.head[x - 1] - hd);
+      q = q + (g.kcell[dn - 1] + kc) * (g.head[dn - 1] - hd) / SQRT2;
+      q = q + (g.kcell[up] + kc) * (g.head[up] - hd);
+      q = q + (g.kcell[dn] + kc) * (g.head[dn] - hd);
+      q = q + (g.kcell[up + 1] + kc) * (g.head[up + 1] - hd) / SQRT2;
+      q = q + (g.kcell[x + 1] + kc) * (g.head[x + 1] - hd);
+      q = q + (g.kcell[dn + 1] + kc) * (g.head[dn + 1] - hd) / SQRT2;
+      qlat = 0.45508986056f * q * g.deltat / area;
+    }
+    const float riverbed = a.riverbed[x], eqwtd = a.eqwtd[x];                  // drv:1356-1370
+    float rcond = a.rivercond[x];
+    if (wtd > riverbed && eqwtd > riverbed) rcond = rcond * nmp_expf(a.pexp[x] * (wtd - eqwtd));
+    qrf = rcond * (wtd - riverbed) * g.deltat / area;
+    qrf = fmax2(qrf, 0.f);
+  }
+  const int sli = (sl >= 1 && sl <= 30) ? sl - 1 : 0;
+  const float bx = g.T->bb[sli], dwsat = g.T->satdw[sli], dksat = g.T->satdk[sli], psisat = -g.T->satpsi[sli];
+  float smcmax = g.T->maxsmc[sli];
+  if (ivgtyp == a.isurban) smcmax = 0.45f;                                     // drv:1378-1381
+  float smcwtd;
+  const float zbot = g.zsoil[NSOIL], dzn = g.dzs[NSOIL - 1];
+  if (bx > 0.0f && smcmax > 0.0f && -psisat > 0.0f) {
+    Soil4 smceq;
+    gw_eqsmoisture(g.zsoil, smcmax, dwsat, dksat, bx, smceq);
+#pragma unroll
+    for (int k = 0; k < NSOIL; k++) smoiseq[x3 + k * plane] = smceq.v[k];
+    if (wtd < zbot - dzn) {                                                    // drv:1393-1417 deep table: Newton
+      const float expon = 2.f * bx + 3.f;
+      const float ddz = zbot - wtd;
+      const float cc = psisat / ddz;
+      const float flux = (qlat - qrf) / g.deltat;
+      float smc = 0.5f * smcmax;
+#pragma unroll 1
+      for (int iter = 1; iter <= 100; iter++) {
+        const float dd = (smc + smcmax) / (2.f * smcmax);
+        const float aa = -dksat * nmp_powf(dd, expon);
+        const float bbb = cc * (nmp_powf(smcmax / smc, bx) - 1.f) + 1.f;
+        const float func = aa * bbb - flux;
+        const float dfunc = -dksat * (expon / (2.f * smcmax)) * nmp_powf(dd, expon - 1.f) * bbb +
+                            aa * cc * (-bx) * nmp_powf(smcmax, bx) * nmp_powf(smc, -bx - 1.f);
+        const float dx = func / dfunc;
+        smc = smc - dx;
+        if (fabsf(dx) < 1.E-6f) break;
+      }
+      smcwtd = fmax2(smc, 1.E-4f);
+    } else if (wtd < zbot) {                                                   // drv:1419-1424
+      float smceqdeep = smcmax * nmp_powf(psisat / (psisat - dzn), 1.f / bx);
+      smceqdeep = fmax2(smceqdeep, 1.E-4f);
+      smcwtd = smcmax * (wtd - (zbot - dzn)) + smceqdeep * (zbot - wtd);
+    } else {                                                                   // drv:1426-1444 table inside the soil column
+      smcwtd = smcmax;
+      bool active = true;
+#pragma unroll
+      for (int k = NSOIL; k >= 2; k--) {
+        if (active) {
+          const float smk = a.smois[x3 + (k - 1) * plane];
+          if (wtd >= g.zsoil[k - 1]) {
+            const float frliq = a.sh2oxy[x3 + (k - 1) * plane] / smk;
+            a.smois[x3 + (k - 1) * plane] = smcmax;
+            a.sh2oxy[x3 + (k - 1) * plane] = smcmax * frliq;
+          } else {
+            if (smk < smceq.v[k - 1]) wtd = g.zsoil[k];
+            else wtd = (smk * g.dzs[k - 1] - smceq.v[k - 1] * g.zsoil[k - 1] + smcmax * g.zsoil[k]) /
+                       (smcmax - smceq.v[k - 1]);
+            active = false;
+          }
+        }
+      }
+    }
+  } else {                                                                     // drv:1446-1450
+#pragma unroll
+    for (int k = 0; k < NSOIL; k++) smoiseq[x3 + k * plane] = smcmax;
+    smcwtd = smcmax;
+    wtd = 0.f;
+  }
+  a.wtd[x] = wtd;
+  a.smcwtd[x] = smcwtd;
+  a.deeprech[x] = 0.f; a.rech[x] = 0.f; a.qslat[x] = 0.f; a.qrfs[x] = 0.f; a.qsprings[x] = 0.f;   // drv:1453-1457
+}
+
 }  // namespace nmp

@@ -47,6 +47,15 @@ __global__ void __launch_bounds__(BX * BY) gw_column_kernel(const GwArgs k) {
   }
 }
 
+// GROUNDWATER_INIT over its..itf x jts..jtf (drv:1330-1331: itf = min(ite, ide-1))
+__global__ void __launch_bounds__(BX * BY) gw_init_kernel(const GwArgs k, int itf, int jtf, int iswater) {
+  libm::libm_stage_tables();
+  const int gi = k.a.its + blockIdx.x * BX + threadIdx.x;
+  const int gj = k.a.jts + blockIdx.y * BY + threadIdx.y;
+  if (gi > itf || gj > jtf) return;
+  gw_init_column(k, gi - k.a.ims, gj - k.a.jms, gi, gj, iswater);
+}
+
 struct WField { const char* name; size_t off; int kind; int lev; int io; };
 #define WF(n, kind, lev, io) {#n, offsetof(noahmp_wtable_args, n), kind, lev, io}
 const WField kW[] = {
@@ -63,7 +72,19 @@ extern "C" {
 
 size_t noahmp_hip_sizeof_wtable_args(void) { return sizeof(noahmp_wtable_args); }
 
+static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater);
+
 int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st) {
+  return gw_call(a, mem, stream, st, false, 0);
+}
+
+int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int mem, void* stream, noahmp_status* st) {
+  return gw_call(a, mem, stream, st, true, iswater);
+}
+
+}  // extern "C"
+
+static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater) {
   if (st) memset(st, 0, sizeof(*st));
   int rc = nmp_host::ensure_init();
   if (rc) return rc;
@@ -127,14 +148,20 @@ int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, no
   const int tni = a->ite - a->its + 1, tnj = a->jte - a->jts + 1;
   if (hni > 0 && hnj > 0)
     hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX - 1) / BX, (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
-  if (tni > 0 && tnj > 0)
+  if (init) {
+    const int itf = imin(a->ite, a->ide - 1), jtf = imin(a->jte, a->jde - 1);
+    const int ini_ = itf - a->its + 1, inj_ = jtf - a->jts + 1;
+    if (ini_ > 0 && inj_ > 0)
+      hipLaunchKernelGGL(gw_init_kernel, dim3((ini_ + BX - 1) / BX, (inj_ + BY - 1) / BY), dim3(BX, BY), 0, s, k, itf, jtf,
+                         iswater);
+  } else if (tni > 0 && tnj > 0)
     hipLaunchKernelGGL(gw_column_kernel, dim3((tni + BX - 1) / BX, (tnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
   if (mem == NOAHMP_MEM_HOST) {
     for (int f = 0; f < kNW; f++) {
-      if (kW[f].io == 0) continue;
+      if (kW[f].io == 0 && !(init && !strcmp(kW[f].name, "smoiseq"))) continue;   // GROUNDWATER_INIT writes SMOISEQ
       const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);
       void* host = *(void* const*)((const char*)a + kW[f].off);
       HIPCHK(hipMemcpyAsync(host, g.gw_mirror[f], bytes, hipMemcpyDeviceToHost, s));
@@ -152,5 +179,3 @@ int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, no
   }
   return 0;
 }
-
-}  // extern "C"

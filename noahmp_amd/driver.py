@@ -83,5 +83,19 @@ class Engine:
             raise RuntimeError("noahmp_hip_wtable_mmf: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return st
 
+    def groundwater_init(self, store, stream=None):
+        """GROUNDWATER_INIT + EQSMOISTURE (reference drv:1286-1522): equilibrium soil moisture, deep-layer moisture
+        and water-table adjustment for OPT_RUN=5, in place.  ide+1 / jde+1 as NOAHMP_INIT receives them (hdrv:291)."""
+        w = store.wtable_args()
+        w.ide += 1
+        w.jde += 1
+        mem = abi.MEM_DEVICE if isinstance(store, DeviceColumnStore) else abi.MEM_HOST
+        st = abi.Status()
+        rc = self.lib.noahmp_hip_groundwater_init(C.byref(w), store.cfg.iswater, mem, stream, C.byref(st))
+        self.last_status = st
+        if rc:
+            raise RuntimeError("noahmp_hip_groundwater_init: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        return st
+
     def finalize(self):
         self.lib.noahmp_hip_finalize()

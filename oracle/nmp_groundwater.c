@@ -330,3 +330,153 @@ int nmp_oracle_wtable_mmf(const noahmp_wtable_args* a, noahmp_status* st) {
   free(qlat); free(kcell); free(head); free(landmask);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * GROUNDWATER_INIT + EQSMOISTURE, reference phys/module_sf_noahmpdrv.F90:1286-1522 ("drv").
+ * Same argument block as the time step; SMOISEQ is written.  Caller passes ide+1 / jde+1 (hdrv:291). */
+static void eqsmoisture(int nsoil, const real* zsoil /*1-based view: zsoil[k]*/, real smcmax, real dwsat, real dksat,
+                        real bexp, real* smceq /*1-based*/) {
+  for (int k = 1; k <= nsoil; k++) {                                               /* drv:1491-1519 */
+    real ddz;
+    if (k == 1) ddz = -zsoil[k + 1] * 0.5f;
+    else if (k < nsoil) ddz = (zsoil[k - 1] - zsoil[k + 1]) * 0.5f;
+    else ddz = zsoil[k - 1] - zsoil[k];
+    real expon = bexp + 1.f;
+    real aa = dwsat / ddz;
+    real bb = dksat / powf(smcmax, expon);
+    real smc = 0.5f * smcmax;
+    for (int iter = 1; iter <= 100; iter++) {
+      real func = (smc - smcmax) * aa + bb * powf(smc, expon);
+      real dfunc = aa + bb * expon * powf(smc, bexp);
+      real dx = func / dfunc;
+      smc = smc - dx;
+      if (fabsf(dx) < 1.E-6f) break;
+    }
+    smceq[k] = MINF(MAXF(smc, 1.E-4f), smcmax * 0.99f);
+  }
+}
+
+int nmp_oracle_groundwater_init(const noahmp_wtable_args* a, int iswater, noahmp_status* st) {
+  static const real KLATFACTOR[19] = {2.f, 3.f, 4.f, 10.f, 10.f, 12.f, 14.f, 20.f, 24.f, 28.f, 40.f,
+                                      48.f, 2.f, 0.f, 10.f, 0.f, 20.f, 2.f, 2.f};
+  const real FANGLE = 0.45508986056f;
+  const noahmp_tables* T = nmp_oracle_tables();
+  int ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1, ns = a->nsoil;
+  size_t n2 = (size_t)ni * nj;
+  if (st) memset(st, 0, sizeof(*st));
+  if (!T) return -1;
+  real* smoiseq = (real*)a->smoiseq;
+  real* qlat = (real*)calloc(n2, sizeof(real));
+  real* qrf = (real*)calloc(n2, sizeof(real));
+  real* kcell = (real*)calloc(n2, sizeof(real));
+  real* head = (real*)calloc(n2, sizeof(real));
+  signed char* landmask = (signed char*)malloc(n2);
+  int itf = a->ite < a->ide - 1 ? a->ite : a->ide - 1, jtf = a->jte < a->jde - 1 ? a->jte : a->jde - 1;   /* drv:1330 */
+  real deltat = a->wtddt * 60.f;
+  real zsoil[NOAHMP_NSOIL + 1];                                                     /* ZSOIL(1:NSOIL), argument of the reference */
+  zsoil[0] = 0.f; zsoil[1] = -a->dzs[0];
+  for (int k = 2; k <= ns; k++) zsoil[k] = zsoil[k - 1] - a->dzs[k - 1];            /* drv:1139-1142 */
+  for (size_t x = 0; x < n2; x++) landmask[x] = (a->ivgtyp[x] != iswater && a->ivgtyp[x] != a->isice) ? 1 : -1;
+  /* LATERALFLOW gw:201-295 with this land mask */
+  int itsh = a->its - 1 > a->ids ? a->its - 1 : a->ids, iteh = a->ite + 1 < a->ide - 1 ? a->ite + 1 : a->ide - 1;
+  int jtsh = a->jts - 1 > a->jds ? a->jts - 1 : a->jds, jteh = a->jte + 1 < a->jde - 1 ? a->jte + 1 : a->jde - 1;
+  for (int j = jtsh; j <= jteh; j++)
+    for (int i = itsh; i <= iteh; i++) {
+      size_t x = IX(i, j);
+      if (a->fdepth[x] > 0.f) {
+        int s_ = a->isltyp[x];
+        real klat = T->satdk[s_ - 1] * KLATFACTOR[s_ - 1];
+        if (a->wtd[x] < -1.5f) kcell[x] = a->fdepth[x] * klat * expf((a->wtd[x] + 1.5f) / a->fdepth[x]);
+        else kcell[x] = klat * (a->wtd[x] + 1.5f + a->fdepth[x]);
+      } else kcell[x] = 0.f;
+      head[x] = a->topo[x] + a->wtd[x];
+    }
+  itsh = a->its > a->ids + 1 ? a->its : a->ids + 1; iteh = a->ite < a->ide - 2 ? a->ite : a->ide - 2;
+  jtsh = a->jts > a->jds + 1 ? a->jts : a->jds + 1; jteh = a->jte < a->jde - 2 ? a->jte : a->jde - 2;
+  const real SQRT2 = sqrtf(2.f);
+  for (int j = jtsh; j <= jteh; j++)
+    for (int i = itsh; i <= iteh; i++) {
+      size_t x = IX(i, j);
+      if (landmask[x] > 0) {
+        real q = 0.f, kc = kcell[x], hd = head[x];
+        q = q + (kcell[IX(i - 1, j + 1)] + kc) * (head[IX(i - 1, j + 1)] - hd) / SQRT2;
+        q = q + (kcell[IX(i - 1, j)] + kc) * (head[IX(i - 1, j)] - hd);
+        q = q + (kcell[IX(i - 1, j - 1)] + kc) * (head[IX(i - 1, j - 1)] - hd) / SQRT2;
+        q = q + (kcell[IX(i, j + 1)] + kc) * (head[IX(i, j + 1)] - hd);
+        q = q + (kcell[IX(i, j - 1)] + kc) * (head[IX(i, j - 1)] - hd);
+        q = q + (kcell[IX(i + 1, j + 1)] + kc) * (head[IX(i + 1, j + 1)] - hd) / SQRT2;
+        q = q + (kcell[IX(i + 1, j)] + kc) * (head[IX(i + 1, j)] - hd);
+        q = q + (kcell[IX(i + 1, j - 1)] + kc) * (head[IX(i + 1, j - 1)] - hd) / SQRT2;
+        qlat[x] = FANGLE * q * deltat / a->area[x];
+      }
+    }
+  for (int j = a->jts; j <= jtf; j++)                                               /* drv:1356-1370 */
+    for (int i = a->its; i <= itf; i++) {
+      size_t x = IX(i, j);
+      if (landmask[x] > 0) {
+        real rcond;
+        if (a->wtd[x] > a->riverbed[x] && a->eqwtd[x] > a->riverbed[x])
+          rcond = a->rivercond[x] * expf(a->pexp[x] * (a->wtd[x] - a->eqwtd[x]));
+        else rcond = a->rivercond[x];
+        qrf[x] = rcond * (a->wtd[x] - a->riverbed[x]) * deltat / a->area[x];
+        qrf[x] = MAXF(qrf[x], 0.f);
+      } else qrf[x] = 0.f;
+    }
+  for (int j = a->jts; j <= jtf; j++)                                               /* drv:1373-1461 */
+    for (int i = a->its; i <= itf; i++) {
+      size_t x = IX(i, j);
+      int sl = a->isltyp[x];
+      real bx = T->bb[sl - 1], smcmax = T->maxsmc[sl - 1];
+      if (a->ivgtyp[x] == a->isurban) smcmax = 0.45f;
+      real dwsat = T->satdw[sl - 1], dksat = T->satdk[sl - 1], psisat = -T->satpsi[sl - 1];
+      if (bx > 0.0f && smcmax > 0.0f && -psisat > 0.0f) {
+        real smceq[NOAHMP_NSOIL + 1];
+        eqsmoisture(ns, zsoil, smcmax, dwsat, dksat, bx, smceq);
+        for (int k = 1; k <= ns; k++) smoiseq[IX3(i, k, j)] = smceq[k];
+        if (a->wtd[x] < zsoil[ns] - a->dzs[ns - 1]) {
+          real expon = 2.f * bx + 3.f;
+          real ddz = zsoil[ns] - a->wtd[x];
+          real cc = psisat / ddz;
+          real flux = (qlat[x] - qrf[x]) / deltat;
+          real smc = 0.5f * smcmax;
+          for (int iter = 1; iter <= 100; iter++) {
+            real dd = (smc + smcmax) / (2.f * smcmax);
+            real aa = -dksat * powf(dd, expon);
+            real bbb = cc * (powf(smcmax / smc, bx) - 1.f) + 1.f;
+            real func = aa * bbb - flux;
+            real dfunc = -dksat * (expon / (2.f * smcmax)) * powf(dd, expon - 1.f) * bbb +
+                         aa * cc * (-bx) * powf(smcmax, bx) * powf(smc, -bx - 1.f);
+            real dx = func / dfunc;
+            smc = smc - dx;
+            if (fabsf(dx) < 1.E-6f) break;
+          }
+          a->smcwtd[x] = MAXF(smc, 1.E-4f);
+        } else if (a->wtd[x] < zsoil[ns]) {
+          real smceqdeep = smcmax * powf(psisat / (psisat - a->dzs[ns - 1]), 1.f / bx);
+          smceqdeep = MAXF(smceqdeep, 1.E-4f);
+          a->smcwtd[x] = smcmax * (a->wtd[x] - (zsoil[ns] - a->dzs[ns - 1])) + smceqdeep * (zsoil[ns] - a->wtd[x]);
+        } else {
+          a->smcwtd[x] = smcmax;
+          for (int k = ns; k >= 2; k--) {
+            if (a->wtd[x] >= zsoil[k - 1]) {
+              real frliq = a->sh2oxy[IX3(i, k, j)] / a->smois[IX3(i, k, j)];
+              a->smois[IX3(i, k, j)] = smcmax;
+              a->sh2oxy[IX3(i, k, j)] = smcmax * frliq;
+            } else {
+              if (a->smois[IX3(i, k, j)] < smceq[k]) a->wtd[x] = zsoil[k];
+              else a->wtd[x] = (a->smois[IX3(i, k, j)] * a->dzs[k - 1] - smceq[k] * zsoil[k - 1] + smcmax * zsoil[k]) /
+                               (smcmax - smceq[k]);
+              break;
+            }
+          }
+        }
+      } else {
+        for (int k = 1; k <= ns; k++) smoiseq[IX3(i, k, j)] = smcmax;
+        a->smcwtd[x] = smcmax;
+        a->wtd[x] = 0.f;
+      }
+      a->deeprech[x] = 0.f; a->rech[x] = 0.f; a->qslat[x] = 0.f; a->qrfs[x] = 0.f; a->qsprings[x] = 0.f;
+    }
+  free(qlat); free(qrf); free(kcell); free(head); free(landmask);
+  return 0;
+}

@@ -24,6 +24,7 @@ class PortLib:
         self.lib.nmp_oracle_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.nmp_oracle_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
         self.lib.nmp_oracle_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
+        self.lib.nmp_oracle_groundwater_init.argtypes = [C.POINTER(WtableArgs), C.c_int, C.POINTER(Status)]
         self.lib.nmp_oracle_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, tables):
@@ -50,3 +51,13 @@ class PortLib:
         st = Status()
         rc = self.lib.nmp_oracle_init(C.byref(a), store.cfg.iswater, 1 if fndsnowh else 0, C.byref(st))
         return rc, st
+
+    def groundwater_init(self, store):
+        """GROUNDWATER_INIT (drv:1286-1522); ide+1 / jde+1 as NOAHMP_INIT receives them (hdrv:291)."""
+        w = store.wtable_args()
+        w.ide += 1
+        w.jde += 1
+        st = Status()
+        rc = self.lib.nmp_oracle_groundwater_init(C.byref(w), store.cfg.iswater, C.byref(st))
+        assert rc == 0, rc
+        return st

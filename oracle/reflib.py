@@ -36,6 +36,8 @@ class RefLib:
         self.lib.ref_get_tables.argtypes = [C.POINTER(Tables)]
         self.lib.ref_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.ref_wtable_mmf.argtypes = [C.POINTER(WtableArgs)]
+        self.lib.ref_noahmp_init_mmf.argtypes = [C.POINTER(StepArgs), C.POINTER(WtableArgs), C.c_int, C.c_int,
+                                                 C.c_float, C.c_float, C.c_float]
         self.tables_loaded = False
 
     def read_tables(self, run_dir=REF_RUN_DIR, modis=False):
@@ -85,3 +87,17 @@ class RefLib:
         assert self.tables_loaded
         w = store.wtable_args()
         self.lib.ref_wtable_mmf(C.byref(w))
+
+    def noahmp_init_mmf(self, store, fndsnowh=True, run_dir=REF_RUN_DIR):
+        """NOAHMP_INIT with OPT_RUN=5 and the optional MMF arguments: standard cold start + GROUNDWATER_INIT.
+        AREAXY is overwritten with DX*DY (drv:1117)."""
+        a = store.step_args(1, 2000, 1.0)
+        w = store.wtable_args()
+        cwd = os.getcwd()
+        os.chdir(run_dir)
+        try:
+            self.lib.ref_noahmp_init_mmf(C.byref(a), C.byref(w), store.cfg.iswater, 1 if fndsnowh else 0,
+                                         store.cfg.dx, store.cfg.dx, store.cfg.dt)
+        finally:
+            os.chdir(cwd)
+        self.tables_loaded = True

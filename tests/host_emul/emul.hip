@@ -107,3 +107,33 @@ extern "C" int emul_init(const noahmp_step_args* a, int iswater, int fndsnowh, n
     }
   return st->code;
 }
+
+extern "C" int emul_groundwater_init(const noahmp_wtable_args* a, int iswater, noahmp_status* st) {
+  memset(st, 0, sizeof(*st));
+  GwArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.T = &g_t;
+  k.ni = a->ime - a->ims + 1;
+  const int nj = a->jme - a->jms + 1;
+  k.deltat = a->wtddt * 60.f;
+  k.zsoil[0] = 0.f;
+  k.zsoil[1] = -a->dzs[0];
+  for (int l = 2; l <= NOAHMP_NSOIL; l++) k.zsoil[l] = -a->dzs[l - 1] + k.zsoil[l - 1];
+  for (int l = 0; l < NOAHMP_NSOIL; l++) k.dzs[l] = a->dzs[l];
+  auto imax = [](int x, int y) { return x > y ? x : y; };
+  auto imin = [](int x, int y) { return x < y ? x : y; };
+  k.hi0 = imax(a->its - 1, a->ids); k.hi1 = imin(a->ite + 1, a->ide - 1);
+  k.hj0 = imax(a->jts - 1, a->jds); k.hj1 = imin(a->jte + 1, a->jde - 1);
+  k.qi0 = imax(a->its, a->ids + 1); k.qi1 = imin(a->ite, a->ide - 2);
+  k.qj0 = imax(a->jts, a->jds + 1); k.qj1 = imin(a->jte, a->jde - 2);
+  std::vector<float> kcell((size_t)k.ni * nj, 0.f), head((size_t)k.ni * nj, 0.f);
+  k.kcell = kcell.data();
+  k.head = head.data();
+  for (int gj = k.hj0; gj <= k.hj1; gj++)
+    for (int gi = k.hi0; gi <= k.hi1; gi++) gw_cell_head(k, (size_t)(gj - a->jms) * k.ni + (gi - a->ims));
+  const int itf = imin(a->ite, a->ide - 1), jtf = imin(a->jte, a->jde - 1);
+  for (int gj = a->jts; gj <= jtf; gj++)
+    for (int gi = a->its; gi <= itf; gi++) gw_init_column(k, gi - a->ims, gj - a->jms, gi, gj, iswater);
+  return 0;
+}

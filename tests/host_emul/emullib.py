@@ -28,6 +28,7 @@ class EmulLib:
         self.lib.emul_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
         self.lib.emul_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
+        self.lib.emul_groundwater_init.argtypes = [C.POINTER(WtableArgs), C.c_int, C.POINTER(Status)]
         self.lib.emul_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, t):
@@ -53,3 +54,12 @@ class EmulLib:
         st = Status()
         rc = self.lib.emul_init(C.byref(a), store.cfg.iswater, 1 if fndsnowh else 0, C.byref(st))
         return rc, st
+
+    def groundwater_init(self, store):
+        w = store.wtable_args()
+        w.ide += 1
+        w.jde += 1
+        st = Status()
+        rc = self.lib.emul_groundwater_init(C.byref(w), store.cfg.iswater, C.byref(st))
+        assert rc == 0, rc
+        return st

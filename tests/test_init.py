@@ -177,3 +177,92 @@ def test_gpu_cold_start_then_steps_match_oracle(engine, port, tables):
         engine.noahmplsm(d, it, 2000, 180.0)
     ok, lines = exact_check(o, d.to_host())
     assert ok or not engine.exact_libm, "\n".join(lines)
+
+
+# ------------------------------------------------------------------------------------------------
+# GROUNDWATER_INIT + EQSMOISTURE (drv:1286-1522), the OPT_RUN=5 half of the cold start
+GWI_OUT = ["smois", "sh2o", "smoiseq", "smcwtdxy", "zwtxy", "deeprechxy", "rechxy", "qslat", "qrfs", "qsprings"]
+
+
+def gwi_store(tables, ni=48, nj=24, seed=21):
+    """Raw cold-start inputs + MMF planes; AREA = DX*DY as NOAHMP_INIT sets it (drv:1117)."""
+    s = raw_store(tables, ni=ni, nj=nj, seed=seed)
+    s.cfg = ModelConfig(iopt_run=5)
+    synth.groundwater_fields(s, tables[1], seed=seed + 1, area=s.cfg.dx * s.cfg.dx)
+    r = np.random.default_rng(seed)
+    s["ivgtyp"][r.random(size=(nj, ni)) < 0.03] = s.cfg.iswater          # the init's land mask uses ISWATER
+    s["smoiseq"][...] = -777.0
+    for k in ("smcwtdxy", "deeprechxy", "rechxy", "qslat", "qrfs", "qsprings"):
+        s.a[k][...] = -777.0
+    return s
+
+
+def test_groundwater_init_port_matches_reference(tables, port, reflib):
+    reflib.set_tables(tables[0])
+    s = gwi_store(tables)
+    a, b = s.copy(), s.copy()
+    reflib.noahmp_init_mmf(a)                       # NOAHMP_INIT(OPT_RUN=5, MMF arguments present)
+    rc, _ = port.noahmp_init(b)
+    assert rc == 0
+    port.groundwater_init(b)
+    same(a, b, "mmf init")
+    w0, w1 = s["zwtxy"], b["zwtxy"]
+    deep = w0 < -3.0
+    assert deep.any() and ((w0 >= -2.0) & (w1 != w0)).any()       # Newton branch and in-column adjustment both hit
+    assert (b["smoiseq"] != -777.0).all()
+
+
+def test_groundwater_init_device_source_on_host(tables, port):
+    from host_emul.emullib import EmulLib
+    em = EmulLib()
+    em.set_tables(tables[0])
+    s = gwi_store(tables, seed=23)
+    port.noahmp_init(s)
+    a, b = s.copy(), s.copy()
+    port.groundwater_init(a)
+    em.groundwater_init(b)
+    same(a, b, "emul gw init")
+
+
+@pytest.mark.gpu
+def test_gpu_groundwater_init_bit_identical(engine, port, tables):
+    s = gwi_store(tables, ni=192, nj=64, seed=25)
+    port.noahmp_init(s)
+    a, h = s.copy(), s.copy()
+    d = s.to_device("cuda:0")
+    port.groundwater_init(a)
+    engine.groundwater_init(h)
+    engine.groundwater_init(d)
+    if engine.exact_libm:
+        same(a, h, "host path")
+        same(a, d.to_host(), "device path")
+    else:
+        for k in GWI_OUT:
+            np.testing.assert_allclose(h.a[k], a.a[k], rtol=2e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_gpu_mmf_cold_start_to_first_groundwater_call(engine, port, tables):
+    """OPT_RUN=5 entirely on the device: init, groundwater init, one step, one WTABLE call; vs the oracle."""
+    from tools.compare import exact_check
+    if not engine.exact_libm:
+        pytest.skip("ocml build")
+    s = gwi_store(tables, ni=96, nj=32, seed=27)
+    synth.diurnal_forcing(s, 10, t_offset=getattr(s, "t_offset", None))
+    o, d = s.copy(), s.to_device("cuda:0")
+    port.noahmp_init(o); port.groundwater_init(o)
+    engine.noahmp_init(d); engine.groundwater_init(d)
+    h = d.to_host()
+    for st_ in (o, h):
+        synth.first_step_fixups(st_)
+    d = h.to_device("cuda:0")
+    so = port.noahmplsm(o, 1, 2000, 180.0)
+    sd = engine.noahmplsm(d, 1, 2000, 180.0, check=False)
+    assert so.code == sd.code
+    port.wtable_mmf(o)
+    engine.wtable_mmf(d)
+    ok, lines = exact_check(o, d.to_host())
+    assert ok, "\n".join(lines)
+    hh = d.to_host()
+    for k in ("qrf", "qspring", "qslat", "qrfs", "qsprings", "smoiseq"):
+        np.testing.assert_array_equal(o.a[k], hh.a[k], err_msg=k)
