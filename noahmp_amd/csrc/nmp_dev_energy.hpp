@@ -700,8 +700,10 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     vege_iter<true>(c, L, 1, &f);                       // iteration 1 (with STOMATA / CANRES)
     psnsun = f.psnsun; psnsha = f.psnsha;
   }
+  if (NMP_TRUNC == 4) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.qsfc + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch; s.err = 99; return; }
   runner.run(c, L, canopy);                             // iterations 2..20
   NMP_TIC(21);
+  if (NMP_TRUNC == 5) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.qsfc + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch + L.mo.fv + L.mo.fh2; s.err = 99; return; }
   if (!canopy) return;
   if (L.err) raise(s, L.err);
   float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah;
@@ -1166,6 +1168,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   float cmv = 0.f, cmb = 0.f;
   const bool canopy = live && veg && s.fveg > 0;
   NMP_TIC(5);    // btran, rsurf, psychrometric constants
+  if (NMP_TRUNC == 3) { s.tv = s.tv + q.rsurf + q.rhsur + q.gammav + q.gammag + q.df_top + q.dz_top + q.stc_top + q.emv + q.emg + q.laisun + q.laisha + q.parsun + q.parsha + q.zlvl + q.zpd + q.z0m + q.cwp + df[3] + hcpct[3] + fact[3] + df[6] + hcpct[6] + fact[6] + r.laisun; s.err = 99; return; }
   if (canopy) {
     s.tgv = s.tg;
     cmv = s.cm;
@@ -1174,11 +1177,14 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   vege_flux(c, P, s, q, cmv, psnsun, psnsha, canopy, runner);
   NMP_TIC(6);    // vege_flux
   if (!live) return;
+  NMP_TRUNC_CHK();
+  if (NMP_TRUNC == 6) { s.tv = s.tv + cmv + psnsun + psnsha; s.err = 99; return; }
   s.tgb = s.tg;
   cmb = s.cm;
   s.chb = s.ch;
   bare_flux(c, P, s, q, zpdg, cmb);
   NMP_TIC(7);    // bare_flux
+  if (NMP_TRUNC == 7) { s.tv = s.tv + cmv + cmb + psnsun + psnsha; s.err = 99; return; }
   if (canopy) {
     s.fira = s.fveg * s.irg + (1.0f - s.fveg) * s.irb + s.irc;
     s.fsh = s.fveg * s.shg + (1.0f - s.fveg) * s.shb + s.shc;
@@ -1215,6 +1221,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   }
   phasechange(c, P, s, y, fact);
   NMP_TIC(10);   // phasechange
+  NMP_TRUNC_AT(8);
 }
 
 }  // namespace nmp
