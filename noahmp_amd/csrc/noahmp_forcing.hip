@@ -1,0 +1,86 @@
+// Forcing preparation on the device: C-ABI entry noahmp_hip_forcing_prep(), the device-resident replacement of
+// driver/module_hrldas_noahmp_driver.F90:336-354 (+ CALC_DECLIN, hdrv:813-863).  The uniform part of CALC_DECLIN
+// (Julian day, solar declination: four libm calls per step) is evaluated here on the host with the host's libm,
+// exactly as the reference does; the per-cell part runs in the kernel with the same libm algorithms (nmp_libm.hpp).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "noahmp_hip.h"
+#include "nmp_dev_forcing.hpp"
+#include "nmp_engine_host.hpp"
+
+using namespace nmp;
+using nmp_host::g;
+
+namespace {
+__global__ void __launch_bounds__(256) noahmp_forcing_kernel(const ForcingArgs k, int nti, int ntj) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)nti * ntj) return;
+  const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
+  forcing_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
+}
+}  // namespace
+
+extern "C" {
+
+// hdrv:826-854: JULIAN and the solar declination; returns JULIAN, fills sin/cos of the declination
+float noahmp_hip_declination(int iday, int ihour, float* sin_declin, float* cos_declin) {
+  const float DEGRAD = 3.14159265f / 180.f, DPD = 360.f / 365.f;
+  const float julian = (float)iday + (float)ihour / 24.f;
+  const float obecl = 23.5f * DEGRAD;
+  const float sinob = sinf(obecl);
+  float sxlong;
+  if (julian >= 80.f) sxlong = DPD * (julian - 80.f) * DEGRAD;
+  else sxlong = DPD * (julian + 285.f) * DEGRAD;
+  const float arg = sinob * sinf(sxlong);
+  const float declin = asinf(arg);
+  if (sin_declin) *sin_declin = sinf(declin);
+  if (cos_declin) *cos_declin = cosf(declin);
+  return julian;
+}
+
+int noahmp_hip_forcing_prep(const noahmp_step_args* a, const float* lon2d, const float* rain_rate, int iday, int ihour,
+                            int iminute, int isecond, float zlvl, int scale_vegfra, float* julian_out, int mem,
+                            void* stream, noahmp_status* st) {
+  if (st) memset(st, 0, sizeof(*st));
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (mem != NOAHMP_MEM_DEVICE) {
+    g.last_error = "noahmp_hip_forcing_prep works on device-resident arrays only (a host caller keeps hdrv:336-354)";
+    return -104;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  ForcingArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.lon = lon2d;
+  k.rain_rate = rain_rate;
+  const float julian = noahmp_hip_declination(iday, ihour, &k.sin_declin, &k.cos_declin);
+  if (julian_out) *julian_out = julian;
+  k.hour_utc = (float)ihour + (float)iminute / 60.0f + (float)isecond / 3600.0f;   // hdrv:856, left to right
+  k.dt = a->dt;
+  k.dz8w = 2.0f * zlvl;
+  k.scale_vegfra = scale_vegfra;
+  k.ni = a->ime - a->ims + 1;
+  k.nka = a->kme - a->kms + 1;
+  k.k1 = 1 - a->kms;
+  if (k.nka < 2) { g.last_error = "forcing_prep needs two atmospheric levels (kms:kme)"; return -105; }
+  const int nti = a->ite - a->its + 1, ntj = a->jte - a->jts + 1;
+  HIPCHK(hipEventRecord(g.ev0, s));
+  if (nti > 0 && ntj > 0) {
+    const long n = (long)nti * ntj;
+    hipLaunchKernelGGL(noahmp_forcing_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (st) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    st->kernel_ms = ms;
+    st->n_land = nti > 0 && ntj > 0 ? nti * ntj : 0;
+  }
+  return 0;
+}
+
+}  // extern "C"

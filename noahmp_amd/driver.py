@@ -83,6 +83,22 @@ class Engine:
             raise RuntimeError("noahmp_hip_wtable_mmf: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return st
 
+    def forcing_prep(self, store, lon, rain_rate, iday, ihour, iminute=0, isecond=0, scale_vegfra=False, stream=None):
+        """Device-resident forcing preparation (reference hdrv:336-354 + CALC_DECLIN): `lon` and `rain_rate` are
+        device tensors shaped like a 2-D field; level 1 of t3d/qv3d/u_phy/v_phy/p8w3d holds the new forcing.
+        Returns JULIAN."""
+        assert isinstance(store, DeviceColumnStore), "forcing_prep works on device-resident arrays"
+        a = store.step_args(1, 2000, 1.0)
+        jul = C.c_float(0)
+        st = abi.Status()
+        rc = self.lib.noahmp_hip_forcing_prep(C.byref(a), lon.data_ptr(), rain_rate.data_ptr(), iday, ihour, iminute,
+                                              isecond, store.cfg.zlvl, 1 if scale_vegfra else 0, C.byref(jul),
+                                              abi.MEM_DEVICE, stream, C.byref(st))
+        self.last_status = st
+        if rc:
+            raise RuntimeError("noahmp_hip_forcing_prep: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        return jul.value
+
     def groundwater_init(self, store, stream=None):
         """GROUNDWATER_INIT + EQSMOISTURE (reference drv:1286-1522): equilibrium soil moisture, deep-layer moisture
         and water-table adjustment for OPT_RUN=5, in place.  ide+1 / jde+1 as NOAHMP_INIT receives them (hdrv:291)."""

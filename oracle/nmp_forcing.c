@@ -1,0 +1,40 @@
+/* TEST INFRASTRUCTURE (oracle) -- CPU restatement of the driver-side forcing preparation:
+ * driver/module_hrldas_noahmp_driver.F90:336-354 ("hdrv") and CALC_DECLIN (hdrv:813-863).
+ * PARITY UNPINNED against a reference build: CALC_DECLIN lives in the driver file, which needs the NetCDF modules to
+ * compile (unbuildable here).  It is a 15-line formula; this file restates it in float32 in source
+ * order with the same libm, and tests/test_forcing.py additionally checks it against an independent float64 evaluation. */
+#include <math.h>
+#include <string.h>
+#include "noahmp_oracle.h"
+
+int nmp_oracle_forcing_prep(const noahmp_step_args* a, const float* lon2d, const float* rain_rate, int iday, int ihour,
+                            int iminute, int isecond, float zlvl, int scale_vegfra, float* julian_out) {
+  const real DEGRAD = 3.14159265f / 180.f, DPD = 360.f / 365.f;                      /* hdrv:815-816 */
+  const int ni = a->ime - a->ims + 1, nka = a->kme - a->kms + 1, k1 = 1 - a->kms;
+  real* t3d = (real*)a->t3d; real* qv = (real*)a->qv3d; real* u = (real*)a->u_phy; real* v = (real*)a->v_phy;
+  real* p = (real*)a->p8w3d; real* dz = (real*)a->dz8w; real* rainbl = (real*)a->rainbl; real* vegfra = (real*)a->vegfra;
+  real* cosz = (real*)a->coszin;
+  real julian = (real)iday + (real)ihour / 24.f;                                      /* hdrv:830 */
+  real obecl = 23.5f * DEGRAD;
+  real sinob = sinf(obecl);
+  real sxlong = 0.f;
+  if (julian >= 80.f) sxlong = DPD * (julian - 80.f) * DEGRAD;
+  if (julian < 80.f) sxlong = DPD * (julian + 285.f) * DEGRAD;
+  real arg = sinob * sinf(sxlong);
+  real declin = asinf(arg);
+  if (julian_out) *julian_out = julian;
+  for (int j = a->jts; j <= a->jte; j++)
+    for (int i = a->its; i <= a->ite; i++) {
+      size_t ij = (size_t)(j - a->jms) * ni + (i - a->ims);
+      size_t l1 = ((size_t)(j - a->jms) * nka + k1) * ni + (i - a->ims), l2 = l1 + ni;
+      if (scale_vegfra) vegfra[ij] = vegfra[ij] * 100.0f;                             /* hdrv:337 */
+      p[l2] = p[l1]; t3d[l2] = t3d[l1]; u[l2] = u[l1]; v[l2] = v[l1]; qv[l2] = qv[l1]; /* hdrv:339-343 */
+      rainbl[ij] = rain_rate[ij] * a->dt;                                             /* hdrv:344 */
+      dz[l1] = 2.0f * zlvl; dz[l2] = 2.0f * zlvl;                                     /* hdrv:345 */
+      real tloctim = (real)ihour + (real)iminute / 60.0f + (real)isecond / 3600.0f + lon2d[ij] / 15.0f;
+      tloctim = fmodf(tloctim + 24.0f, 24.0f);
+      real hrang = 15.f * (tloctim - 12.f) * DEGRAD;
+      cosz[ij] = sinf(a->xlatin[ij] * DEGRAD) * sinf(declin) + cosf(a->xlatin[ij] * DEGRAD) * cosf(declin) * cosf(hrang);
+    }
+  return 0;
+}

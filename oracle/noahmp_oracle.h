@@ -97,6 +97,8 @@ void nmp_sflx(nmp_ctx* c, nmp_column* s);
 int nmp_oracle_set_tables(const noahmp_tables* t);
 int nmp_oracle_step(const noahmp_step_args* a, noahmp_status* st);
 int nmp_oracle_init(const noahmp_step_args* a, int iswater, int fndsnowh, noahmp_status* st);   /* drv:847-1283 */
+int nmp_oracle_forcing_prep(const noahmp_step_args* a, const float* lon2d, const float* rain_rate, int iday, int ihour,
+                            int iminute, int isecond, float zlvl, int scale_vegfra, float* julian_out);   /* hdrv:336-354, 813-863 */
 int nmp_oracle_wtable_mmf(const noahmp_wtable_args* a, noahmp_status* st);
 int nmp_oracle_groundwater_init(const noahmp_wtable_args* a, int iswater, noahmp_status* st);   /* drv:1286-1522 */   /* gw:14-198 */
 

@@ -25,6 +25,8 @@ class PortLib:
         self.lib.nmp_oracle_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
         self.lib.nmp_oracle_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
         self.lib.nmp_oracle_groundwater_init.argtypes = [C.POINTER(WtableArgs), C.c_int, C.POINTER(Status)]
+        self.lib.nmp_oracle_forcing_prep.argtypes = [C.POINTER(StepArgs), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_float, C.c_int, C.POINTER(C.c_float)]
         self.lib.nmp_oracle_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, tables):
@@ -61,3 +63,10 @@ class PortLib:
         rc = self.lib.nmp_oracle_groundwater_init(C.byref(w), store.cfg.iswater, C.byref(st))
         assert rc == 0, rc
         return st
+
+    def forcing_prep(self, store, lon, rain_rate, iday, ihour, iminute=0, isecond=0, scale_vegfra=False):
+        a = store.step_args(1, 2000, 1.0)
+        jul = C.c_float(0)
+        self.lib.nmp_oracle_forcing_prep(C.byref(a), lon.ctypes.data, rain_rate.ctypes.data, iday, ihour, iminute, isecond,
+                                         store.cfg.zlvl, 1 if scale_vegfra else 0, C.byref(jul))
+        return jul.value

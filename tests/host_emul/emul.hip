@@ -137,3 +137,17 @@ extern "C" int emul_groundwater_init(const noahmp_wtable_args* a, int iswater, n
     for (int gi = a->its; gi <= itf; gi++) gw_init_column(k, gi - a->ims, gj - a->jms, gi, gj, iswater);
   return 0;
 }
+
+// ---- forcing preparation (noahmp_forcing.hip's kernel as a host loop; the uniform declination comes from the caller)
+#include "nmp_dev_forcing.hpp"
+extern "C" int emul_forcing_prep(const noahmp_step_args* a, const float* lon2d, const float* rain_rate, float hour_utc,
+                                 float sin_declin, float cos_declin, float zlvl, int scale_vegfra) {
+  ForcingArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a; k.lon = lon2d; k.rain_rate = rain_rate; k.hour_utc = hour_utc; k.sin_declin = sin_declin; k.cos_declin = cos_declin;
+  k.dt = a->dt; k.dz8w = 2.0f * zlvl; k.scale_vegfra = scale_vegfra;
+  k.ni = a->ime - a->ims + 1; k.nka = a->kme - a->kms + 1; k.k1 = 1 - a->kms;
+  for (int j = a->jts; j <= a->jte; j++)
+    for (int i = a->its; i <= a->ite; i++) forcing_cell(k, i - a->ims, j - a->jms);
+  return 0;
+}

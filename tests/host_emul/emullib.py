@@ -29,6 +29,8 @@ class EmulLib:
         self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
         self.lib.emul_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
         self.lib.emul_groundwater_init.argtypes = [C.POINTER(WtableArgs), C.c_int, C.POINTER(Status)]
+        self.lib.emul_forcing_prep.argtypes = [C.POINTER(StepArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                               C.c_float, C.c_int]
         self.lib.emul_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
 
     def set_tables(self, t):
@@ -63,3 +65,8 @@ class EmulLib:
         rc = self.lib.emul_groundwater_init(C.byref(w), store.cfg.iswater, C.byref(st))
         assert rc == 0, rc
         return st
+
+    def forcing_prep(self, store, lon, rain_rate, hour_utc, sin_declin, cos_declin, scale_vegfra=False):
+        a = store.step_args(1, 2000, 1.0)
+        return self.lib.emul_forcing_prep(C.byref(a), lon.ctypes.data, rain_rate.ctypes.data, hour_utc, sin_declin,
+                                          cos_declin, store.cfg.zlvl, 1 if scale_vegfra else 0)

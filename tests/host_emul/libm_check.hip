@@ -16,7 +16,7 @@ static inline bool same(float a, float b) {
   return asuint(a) == asuint(b);
 }
 
-// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f, 7 acosf, 8 tanf, 9 cosf (both |x| < 120).  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
+// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f, 7 acosf, 8 tanf, 9 cosf, 10 sinf (|x| < 120).  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
 extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t* first_bad) {
   std::vector<long> bad(nthreads, 0);
   std::vector<uint32_t> fb(nthreads, 0);
@@ -36,6 +36,7 @@ extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t
           case 7: a = acosf_(x); b = ::acosf(x); break;
           case 8: a = tanf_(x); b = (fabsf(x) < 120.0f) ? ::tanf(x) : a; break;
           case 9: a = cosf_(x); b = (fabsf(x) < 120.0f) ? ::cosf(x) : a; break;
+          case 10: a = sinf_(x); b = (fabsf(x) < 120.0f) ? ::sinf(x) : a; break;
           default: a = expm1f_(x); b = ::expm1f(x); break;
         }
         if (!same(a, b)) { if (!bad[t]) fb[t] = (uint32_t)u; bad[t]++; }
@@ -111,6 +112,7 @@ __global__ void libm_eval_kernel(int fn, uint32_t start, uint32_t stride, long n
     case 7: r = acosf_(x); break;
     case 8: r = tanf_(x); break;
     case 9: r = cosf_(x); break;
+    case 10: r = sinf_(x); break;
     default: r = powf_(x, y[i]); break;
   }
   out[i] = r;
@@ -146,6 +148,7 @@ extern "C" long libm_gpu_check(int fn, uint32_t start, uint32_t stride, long n, 
       case 7: b = ::acosf(x); break;
       case 8: b = (fabsf(x) < 120.0f) ? ::tanf(x) : out[i]; break;
       case 9: b = (fabsf(x) < 120.0f) ? ::cosf(x) : out[i]; break;
+      case 10: b = (fabsf(x) < 120.0f) ? ::sinf(x) : out[i]; break;
       default: b = ::powf(x, y[i]); break;
     }
     if (!same(out[i], b)) { if (!bad) *first_bad = start + (uint32_t)i * stride; bad++; }

@@ -16,8 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "host_emul", "libm_check.hip")
 LIB = os.path.join(HERE, "host_emul", "liblibm_check.so")
-NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f", "powf", "acosf", "tanf", "cosf"]
-UNARY = [0, 1, 2, 3, 4, 5, 7, 8, 9]      # 6 = powf (binary)
+NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f", "powf", "acosf", "tanf", "cosf", "sinf"]
+UNARY = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10]      # 6 = powf (binary)
 
 
 def _lib():
@@ -62,7 +62,7 @@ def test_tables_regenerate_identically(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fn", range(10), ids=NAMES)
+@pytest.mark.parametrize("fn", range(11), ids=NAMES)
 def test_device_code_matches_libm(fn):
     lib = _lib()
     fb = C.c_uint32(0)
