@@ -116,14 +116,22 @@ def main():
     d = s.to_device("cuda:%d" % local_rank)
     ncol = s.ncol
 
+    # One argument block, built once; a step only swaps the five forcing pointers and the step number, then enqueues the
+    # kernel (noahmp_hip_step_async: device-resident state, nothing to wait for until output is due).
+    sargs = d.step_args(1, 2000, 180.0)
+    fptr = [{k: f[k].data_ptr() for k in fkeys} for f in forcing]
+
     def step(it):
-        d.a.update(forcing[(it + 5) % 24])
-        return eng.noahmplsm(d, it, 2000, 180.0)
+        for k_, p_ in fptr[(it + 5) % 24].items():
+            setattr(sargs, k_, p_)
+        sargs.itimestep = it
+        eng.noahmplsm_async(sargs)
 
     it = 0
     for _ in range(args.warmup):
         it += 1
         step(it)
+    st, _ = eng.sync()
 
     def barrier():
         comm.barrier()
@@ -131,20 +139,14 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
-    n_land = 0
-    walls = []
     for _ in range(args.steps):
         it += 1
-        tw = time.perf_counter()
-        st = step(it)
-        walls.append((time.perf_counter() - tw) * 1e3 - st.kernel_ms)
-        kernel_ms += st.kernel_ms
-        n_land += st.n_land
+        step(it)
+    st, bad_step = eng.sync()                   # waits for the K steps; tallies and device time summed over them
     barrier()
-    if os.environ.get("NMP_BENCH_DEBUG"):
-        print("per-step host overhead ms:", ["%.2f" % w for w in walls], file=sys.stderr)
     dt = time.perf_counter() - t0
+    kernel_ms = st.kernel_ms
+    n_land = st.n_land
     dt = comm.reduce_max(dt)                    # MAX over ranks
     n_land_all = comm.reduce_sum(n_land)        # columns advanced by the whole job
 

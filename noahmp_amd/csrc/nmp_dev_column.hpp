@@ -18,6 +18,7 @@ struct KArgs {
   int yearlen;
   unsigned long long* err;   // min over columns of ((linear index + 1) << 8 | code)
   int* counts;               // [0]=land [1]=glacier [2]=skipped
+  unsigned long long err_base;   // step ordinal << 40 for asynchronous stepping (0 otherwise)
 };
 
 constexpr int LAY_SLOTS = 4 * 7 + 5 * 4 + 3 * 3;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
   if (cls > 1) return;
   SimpleLoop runner;
   const int err = column_step<STRIDE>(k, cls, ii, jj, ij, base, runner);
-  if (err) atomicMin(k.err, ((unsigned long long)(t + 1) << 8) | (unsigned)err);   // first column wins
+  if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + 1) << 8) | (unsigned)err);   // first column wins
 }
 
 // --------------------------------------------------------------------------------------------
@@ -167,19 +167,10 @@ int noahmp_hip_set_option(const char* key, int value) {
   return prev;
 }
 
-int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
-  if (st) memset(st, 0, sizeof(*st));
-  int rc = ensure_init();
-  if (rc) return rc;
-  if (!g.have_tables) { g.last_error = "noahmp_hip_set_tables() has not been called"; return -102; }
-  if (a->nsoil != NOAHMP_NSOIL) { if (st) st->code = NOAHMP_ERR_NSOIL_UNSUPPORTED; return NOAHMP_ERR_NSOIL_UNSUPPORTED; }
-  if (a->iopt_sfc != 1 && a->iopt_sfc != 2) {
-    if (st) st->code = NOAHMP_ERR_OPT_SFC_UNSUPPORTED;
-    return NOAHMP_ERR_OPT_SFC_UNSUPPORTED;
-  }
-  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+}  // extern "C" (helpers follow)
 
-  KArgs k;
+// launch-uniform kernel arguments of one noahmplsm call
+static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
   memset(&k, 0, sizeof(k));
   k.a = *a;
   k.ni = a->ime - a->ims + 1;
@@ -201,6 +192,39 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   k.err = g.d_err;
   k.counts = g.d_counts;
   k.a.dzs = nullptr;
+}
+
+static void launch_any(const KArgs& k, hipStream_t s) {
+  const long ncol = (long)k.nti * k.ntj;
+  if (ncol <= 0) return;
+  if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
+  else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
+  else launch<64>(k, ncol, g.use_lds, s);
+}
+
+static int check_step_args(const noahmp_step_args* a, noahmp_status* st) {
+  if (!g.have_tables) { g.last_error = "noahmp_hip_set_tables() has not been called"; return -102; }
+  if (a->nsoil != NOAHMP_NSOIL) { if (st) st->code = NOAHMP_ERR_NSOIL_UNSUPPORTED; return NOAHMP_ERR_NSOIL_UNSUPPORTED; }
+  if (a->iopt_sfc != 1 && a->iopt_sfc != 2) {
+    if (st) st->code = NOAHMP_ERR_OPT_SFC_UNSUPPORTED;
+    return NOAHMP_ERR_OPT_SFC_UNSUPPORTED;
+  }
+  return 0;
+}
+
+extern "C" {
+
+int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
+  if (st) memset(st, 0, sizeof(*st));
+  int rc = ensure_init();
+  if (rc) return rc;
+  rc = check_step_args(a, st);
+  if (rc) return rc;
+  if (g.async_pending) { g.last_error = "noahmp_hip_step: asynchronous steps are pending, call noahmp_hip_sync() first"; return -106; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+
+  KArgs k;
+  fill_kargs(k, a);
 
   if (mem == NOAHMP_MEM_HOST) {
     // stage every array H2D into persistent device mirrors (caller's arrays stay the source of truth)
@@ -224,13 +248,8 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
   HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
-  const long ncol = (long)k.nti * k.ntj;
   HIPCHK(hipEventRecord(g.ev0, s));
-  if (ncol > 0) {
-    if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
-    else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
-    else launch<64>(k, ncol, g.use_lds, s);
-  }
+  launch_any(k, s);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -258,6 +277,62 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
     code = (int)(*g.h_err & 0xFF);
     long t = (long)(*g.h_err >> 8) - 1;
     if (st) { st->code = code; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
+  }
+  return code;
+}
+
+// ---- asynchronous stepping for device-resident state: enqueue and return.  Fatal columns and tallies
+// accumulate on the device until noahmp_hip_sync(); the error word carries the step ordinal above the column index,
+// so the earliest step wins, then the first column in loop order -- the column the reference would have STOPped at.
+int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  rc = check_step_args(a, nullptr);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  if (!g.async_pending) {
+    HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
+    HIPCHK(hipEventRecord(g.ev0, s));
+    g.async_nti = a->ite - a->its + 1; g.async_its = a->its; g.async_jts = a->jts;
+  }
+  KArgs k;
+  fill_kargs(k, a);
+  k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
+  launch_any(k, s);
+  HIPCHK(hipGetLastError());
+  g.async_pending++;
+  g.async_stream = s;
+  return 0;
+}
+
+// Wait for the pending asynchronous steps.  st: tallies summed over them, kernel_ms = device time from the first to
+// the last of them, code/i/j = the first fatal column (0 if none); returns that code.  st->n_skipped is reused for
+// nothing else; the ordinal of the failing step (0-based since the previous sync) is returned through *step_out.
+int noahmp_hip_sync(noahmp_status* st, int* step_out) {
+  if (st) memset(st, 0, sizeof(*st));
+  if (step_out) *step_out = -1;
+  if (!g.async_pending) return 0;
+  hipStream_t s = g.async_stream;
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  g.async_pending = 0;
+  int code = 0;
+  if (st) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    st->kernel_ms = ms;
+    int cnt[4];
+    nmp_host::sum_counts(cnt);
+    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+  }
+  if (*g.h_err != ~0ULL) {
+    code = (int)(*g.h_err & 0xFF);
+    const long t = (long)((*g.h_err >> 8) & 0xFFFFFFFFull) - 1;
+    if (step_out) *step_out = (int)(*g.h_err >> 40);
+    if (st) { st->code = code; st->i = g.async_its + (int)(t % g.async_nti); st->j = g.async_jts + (int)(t / g.async_nti); }
   }
   return code;
 }

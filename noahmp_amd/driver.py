@@ -113,5 +113,24 @@ class Engine:
             raise RuntimeError("noahmp_hip_groundwater_init: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return st
 
+    # ---- asynchronous stepping (device-resident state only)
+    def noahmplsm_async(self, args, stream=None):
+        """Enqueue one step described by a prepared StepArgs block (store.step_args(...), device pointers)."""
+        rc = self.lib.noahmp_hip_step_async(C.byref(args), stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_step_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+
+    def sync(self, check=True):
+        """Wait for the pending asynchronous steps; returns (Status, ordinal of the failing step or -1)."""
+        st = abi.Status()
+        step = C.c_int(-1)
+        rc = self.lib.noahmp_hip_sync(C.byref(st), C.byref(step))
+        self.last_status = st
+        if rc < 0:
+            raise RuntimeError("noahmp_hip_sync: " + self.lib.noahmp_hip_last_error().decode())
+        if rc > 0 and check:
+            raise NoahMPFatal(rc, st.i, st.j, "step +%d: %s" % (step.value, self.lib.noahmp_hip_error_string(rc).decode()))
+        return st, step.value
+
     def finalize(self):
         self.lib.noahmp_hip_finalize()

@@ -1,0 +1,71 @@
+"""Asynchronous stepping of device-resident state (noahmp_hip_step_async / noahmp_hip_sync)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from noahmp_amd import abi, synth
+from noahmp_amd.abi import FIELD_INFO
+
+pytestmark = pytest.mark.gpu
+
+
+def _outs(store):
+    return [k for k in store.a if FIELD_INFO[k][2] != "in"]
+
+
+def test_async_steps_equal_synchronous_steps(engine, tables):
+    import torch
+    s = synth.mixed_small(tables[1], ni=128, nj=16)
+    synth.first_step_fixups(s)
+    a, b = s.to_device("cuda:0"), s.to_device("cuda:0")
+    forc = []
+    for it in range(1, 9):
+        synth.diurnal_forcing(s, 8 + it, t_offset=s.t_offset)
+        forc.append({k: torch.from_numpy(s.a[k].copy()).cuda() for k in ("coszin", "swdown", "glw", "t3d", "rainbl")})
+    n = 0
+    for it in range(1, 9):
+        a.a.update(forc[it - 1])
+        st = engine.noahmplsm(a, it, 2000, 180.0)
+        n += st.n_land + st.n_glacier
+    args = b.step_args(1, 2000, 180.0)
+    for it in range(1, 9):
+        for k, v in forc[it - 1].items():
+            setattr(args, k, v.data_ptr())
+        args.itimestep = it
+        engine.noahmplsm_async(args)
+    st, step = engine.sync()
+    assert st.code == 0 and step == -1 and st.n_land + st.n_glacier == n and st.kernel_ms > 0
+    ha, hb = a.to_host(), b.to_host()
+    for k in _outs(ha):
+        if k in ("coszin", "swdown", "glw", "t3d", "rainbl"):
+            continue
+        np.testing.assert_array_equal(ha.a[k], hb.a[k], err_msg=k)
+
+
+def test_async_reports_earliest_failing_step_and_first_column(engine, tables):
+    from noahmp_amd.driver import NoahMPFatal
+    import torch
+    s = synth.mixed_small(tables[1], ni=64, nj=4)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+    d = s.to_device("cuda:0")
+    good = d.a["isltyp"]
+    bad1 = good.clone(); bad1[3, 40] = 25            # REDPRM: too many input soil types (lsm:9266)
+    bad2 = good.clone(); bad2[1, 5] = 25; bad2[3, 40] = 25
+    args = d.step_args(1, 2000, 180.0)
+    engine.noahmplsm_async(args)                      # step 0: fine
+    args.isltyp = bad1.data_ptr()
+    engine.noahmplsm_async(args)                      # step 1: one bad column
+    args.isltyp = bad2.data_ptr()
+    engine.noahmplsm_async(args)                      # step 2: an earlier bad column as well
+    with pytest.raises(NoahMPFatal) as e:
+        engine.sync()
+    assert (e.value.code, e.value.i, e.value.j) == (1, 41, 4) and "step +1" in str(e.value)
+    # a synchronous call while asynchronous steps are pending is refused
+    engine.noahmplsm_async(d.step_args(1, 2000, 180.0))
+    st = abi.Status()
+    rc = engine.lib.noahmp_hip_step(C.byref(d.step_args(1, 2000, 180.0)), abi.MEM_DEVICE, None, C.byref(st))
+    assert rc == -106
+    engine.sync()
+    assert engine.sync()[0].n_land == 0               # nothing pending: empty status
