@@ -73,6 +73,7 @@ NMP_DEV float nmp_acosf(float x) { return libm::acosf_(x); }
 NMP_DEV float nmp_cosf(float x) { return libm::cosf_(x); }
 // x**0.25, x**0.5, x**-0.25 with a literal exponent (SFCDIF1, RAGRB): the reference calls powf
 NMP_DEV float pow_quarter(float x) { NMP_CNT(6); return libm::powf_(x, 0.25f); }
+NMP_DEV void pow_quarter2(float x1, float x2, float& r1, float& r2) { NMP_CNT(6); NMP_CNT(6); libm::powf2_(x1, 0.25f, x2, 0.25f, r1, r2); }
 NMP_DEV float pow_half(float x) { NMP_CNT(6); return libm::powf_(x, 0.5f); }
 NMP_DEV float pow_neg_quarter(float x) { NMP_CNT(6); return libm::powf_(x, -0.25f); }
 #else
@@ -87,6 +88,7 @@ NMP_DEV float nmp_acosf(float x) { return acosf(x); }
 NMP_DEV float nmp_cosf(float x) { return cosf(x); }
 // IEEE sqrt chains (each step correctly rounded, total <= 0.75 ulp, ~10 VALU ops) instead of ocml powf
 NMP_DEV float pow_quarter(float x) { return sqrtf(sqrtf(x)); }
+NMP_DEV void pow_quarter2(float x1, float x2, float& r1, float& r2) { r1 = sqrtf(sqrtf(x1)); r2 = sqrtf(sqrtf(x2)); }
 NMP_DEV float pow_half(float x) { return sqrtf(x); }
 NMP_DEV float pow_neg_quarter(float x) { return 1.0f / sqrtf(sqrtf(x)); }
 #endif

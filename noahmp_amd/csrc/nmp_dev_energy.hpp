@@ -341,12 +341,12 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, float rhoair, float h, fl
   if (mozold * m.moz < 0.f) m.mozsgn = m.mozsgn + 1;
   if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
   if (m.moz < 0.f) {
-    float tmp1 = pow_quarter(1.f - 16.f * m.moz);
+    float tmp1, tmp12;                       // the two X = (1-16 MOZ)**0.25 are independent: evaluate them interleaved
+    pow_quarter2(1.f - 16.f * m.moz, 1.f - 16.f * moz2, tmp1, tmp12);
     float tmp2 = nmp_logf((1.f + tmp1 * tmp1) / 2.f);
     float tmp3 = nmp_logf((1.f + tmp1) / 2.f);
     fmnew = 2.f * tmp3 + tmp2 - 2.f * nmp_atanf(tmp1) + 1.5707963f;
     fhnew = 2 * tmp2;
-    float tmp12 = pow_quarter(1.f - 16.f * moz2);
     float tmp22 = nmp_logf((1.f + tmp12 * tmp12) / 2.f);
     float tmp32 = nmp_logf((1.f + tmp12) / 2.f);
     fm2new = 2.f * tmp32 + tmp22 - 2.f * nmp_atanf(tmp12) + 1.5707963f;
