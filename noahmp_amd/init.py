@@ -1,4 +1,7 @@
-"""Cold-start initialisation of a ColumnStore: host-side mirror of NOAHMP_INIT + SNOW_INIT.
+"""Synthetic-state helper: numpy mirror of NOAHMP_INIT + SNOW_INIT used by noahmp_amd/synth.py to BUILD TEST AND
+BENCH INPUTS on machines without a GPU.  It is not the product's cold start and nothing falls back to it: the
+product entry is ``noahmp_hip_init`` (noahmp_amd/csrc/noahmp_init.hip, ``Engine.noahmp_init``), which
+tests/test_init.py holds bit-identical to the reference; this mirror is checked against the same oracle there.
 
 Reference: phys/module_sf_noahmpdrv.F90:847-1177 (NOAHMP_INIT, ``restart=.false.``,
 ``iopt_run /= 5`` branch) and :1182-1283 (SNOW_INIT).  float32 arithmetic throughout
