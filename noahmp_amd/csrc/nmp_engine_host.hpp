@@ -38,6 +38,7 @@ struct Engine {
   size_t gw_plane_bytes = 0;
   int async_pending = 0;        // noahmp_hip_step_async calls since the last noahmp_hip_sync
   hipStream_t async_stream = nullptr;
+  std::vector<hipStream_t> async_streams;   // every stream that carries pending asynchronous steps
   int async_nti = 1, async_its = 1, async_jts = 1;
   int block = 64;
   int use_lds = 1;

@@ -303,6 +303,9 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   HIPCHK(hipGetLastError());
   g.async_pending++;
   g.async_stream = s;
+  bool known = false;
+  for (hipStream_t q : g.async_streams) known = known || (q == s);
+  if (!known) g.async_streams.push_back(s);
   return 0;
 }
 
@@ -314,6 +317,8 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   if (step_out) *step_out = -1;
   if (!g.async_pending) return 0;
   hipStream_t s = g.async_stream;
+  for (hipStream_t q : g.async_streams) if (q != s) HIPCHK(hipStreamSynchronize(q));   // steps may sit on several streams
+  g.async_streams.clear();
   HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
