@@ -1,3 +1,5 @@
+"""Host overhead of the synchronous entry point (wall time per step minus kernel time) at three tile sizes, and the
+PCIe-inclusive rate of the host-memory path (what the Fortran shim pays).  Run on the GPU box."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from noahmp_amd import synth
