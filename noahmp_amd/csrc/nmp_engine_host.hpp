@@ -38,7 +38,8 @@ struct Engine {
   size_t gw_plane_bytes = 0;
   int async_pending = 0;        // noahmp_hip_step_async calls since the last noahmp_hip_sync
   hipStream_t async_stream = nullptr;
-  std::vector<hipStream_t> async_streams;   // every stream that carries pending asynchronous steps
+  std::vector<hipStream_t> async_streams;
+  std::vector<hipEvent_t> async_events;     // start/end of each pending step's kernel   // every stream that carries pending asynchronous steps
   int async_nti = 1, async_its = 1, async_jts = 1;
   int block = 64;
   int use_lds = 1;

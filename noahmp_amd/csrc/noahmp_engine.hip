@@ -293,14 +293,22 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   if (!g.async_pending) {
     HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
     HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
-    HIPCHK(hipEventRecord(g.ev0, s));
     g.async_nti = a->ite - a->its + 1; g.async_its = a->its; g.async_jts = a->jts;
   }
   KArgs k;
   fill_kargs(k, a);
   k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
+  // one event pair per step: kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
+  // else the caller puts on the stream between them
+  while ((int)g.async_events.size() < 2 * (g.async_pending + 1)) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    g.async_events.push_back(e);
+  }
+  HIPCHK(hipEventRecord(g.async_events[2 * g.async_pending], s));
   launch_any(k, s);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.async_events[2 * g.async_pending + 1], s));
   g.async_pending++;
   g.async_stream = s;
   bool known = false;
@@ -319,15 +327,19 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   hipStream_t s = g.async_stream;
   for (hipStream_t q : g.async_streams) if (q != s) HIPCHK(hipStreamSynchronize(q));   // steps may sit on several streams
   g.async_streams.clear();
-  HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  const int nsteps = g.async_pending;
   g.async_pending = 0;
   int code = 0;
   if (st) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    for (int i = 0; i < nsteps; i++) {
+      float one = 0.f;
+      hipEventElapsedTime(&one, g.async_events[2 * i], g.async_events[2 * i + 1]);
+      ms += one;
+    }
     st->kernel_ms = ms;
     int cnt[4];
     nmp_host::sum_counts(cnt);
@@ -387,6 +399,7 @@ void noahmp_hip_finalize(void) {
   for (auto& b : g.mirror_bytes) b = 0;
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
+  for (auto e : g.async_events) hipEventDestroy(e);
   if (g.gw_kcell) hipFree(g.gw_kcell);
   if (g.gw_head) hipFree(g.gw_head);
   if (g.d_tables) hipFree(g.d_tables);

@@ -21,7 +21,53 @@ __global__ void __launch_bounds__(256) noahmp_forcing_kernel(const ForcingArgs k
 }
 }  // namespace
 
+// ---- column permutation of fields (sorted device-resident layout) ---------------------------
+// dst column p <- src column perm[p], for up to 32 fields of 1..8 levels each, one thread per destination column:
+// writes are coalesced, reads gather.  Used per step for the forcing of a run whose state is kept sorted by
+// (class, vegetation type), and once for the state itself.
+namespace {
+constexpr int kMaxGather = 32;
+struct GatherArgs {
+  void* dst[kMaxGather];
+  const void* src[kMaxGather];
+  int nlev[kMaxGather];
+  const int* perm;
+  int n, ni, nj;
+};
+__global__ void __launch_bounds__(256) noahmp_gather_kernel(const GatherArgs k) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long ncol = (long)k.ni * k.nj;
+  if (p >= ncol) return;
+  const long gsrc = k.perm[p];
+  const int pj = (int)(p / k.ni), pi = (int)(p - (long)pj * k.ni);
+  const int gj = (int)(gsrc / k.ni), gi = (int)(gsrc - (long)gj * k.ni);
+  for (int f = 0; f < k.n; f++) {
+    const int nk = k.nlev[f];
+    const uint32_t* s = (const uint32_t*)k.src[f];
+    uint32_t* d = (uint32_t*)k.dst[f];
+    for (int l = 0; l < nk; l++) d[((size_t)pj * nk + l) * k.ni + pi] = s[((size_t)gj * nk + l) * k.ni + gi];
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int noahmp_hip_gather_fields(int n, void* const* dst, const void* const* src, const int* nlev, const int32_t* perm, int ni,
+                             int nj, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (n < 0 || n > kMaxGather) { g.last_error = "noahmp_hip_gather_fields: at most 32 fields per call"; return -107; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  GatherArgs k;
+  memset(&k, 0, sizeof(k));
+  for (int f = 0; f < n; f++) { k.dst[f] = dst[f]; k.src[f] = src[f]; k.nlev[f] = nlev[f]; }
+  k.perm = perm; k.n = n; k.ni = ni; k.nj = nj;
+  const long ncol = (long)ni * nj;
+  if (ncol > 0 && n > 0)
+    hipLaunchKernelGGL(noahmp_gather_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, s, k);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 // hdrv:826-854: JULIAN and the solar declination; returns JULIAN, fills sin/cos of the declination
 float noahmp_hip_declination(int iday, int ihour, float* sin_declin, float* cos_declin) {

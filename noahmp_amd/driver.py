@@ -99,6 +99,57 @@ class Engine:
             raise RuntimeError("noahmp_hip_forcing_prep: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return jul.value
 
+    # ---- sorted device-resident layout
+    class Gather:
+        """A prepared noahmp_hip_gather_fields call: dst tensors <- src tensors through a column permutation."""
+
+        def __init__(self, lib, dst, src, perm, ni, nj):
+            n = len(dst)
+            self.lib, self.n, self.ni, self.nj, self.perm = lib, n, ni, nj, perm
+            self.keep = (dst, src)
+            self.dst = (C.c_void_p * n)(*[t.data_ptr() for t in dst])
+            self.src = (C.c_void_p * n)(*[t.data_ptr() for t in src])
+            self.nlev = (C.c_int * n)(*[(t.shape[1] if t.dim() == 3 else 1) for t in dst])
+
+        def set_sources(self, src):
+            for i, t in enumerate(src):
+                self.src[i] = t.data_ptr()
+
+        def __call__(self, stream=None):
+            rc = self.lib.noahmp_hip_gather_fields(self.n, self.dst, self.src, self.nlev, self.perm.data_ptr(), self.ni,
+                                                   self.nj, stream)
+            if rc:
+                raise RuntimeError("noahmp_hip_gather_fields: rc=%d" % rc)
+
+    def sort_store(self, store, keys=("class", "ivgtyp")):
+        """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type) are adjacent
+        (stable, so tile order is kept inside a group) and return the permutation as an int32 device tensor:
+        sorted position p holds the column that was at linear tile index perm[p].  Columns are independent (every
+        option except the MMF lateral flow), so this only changes which lane computes which column; wavefronts then
+        hold columns that take the same branches.  Forcing that arrives in tile order goes through `gather`."""
+        import numpy as np
+        import torch
+        assert isinstance(store, DeviceColumnStore)
+        ivg = store.a["ivgtyp"].cpu().numpy().ravel().astype(np.int64)
+        xland = store.a["xland"].cpu().numpy().ravel()
+        xice = store.a["xice"].cpu().numpy().ravel()
+        cls = np.where((xland - 1.5 >= 0) | (xice >= store.cfg.xice_thres), 2, np.where(ivg == store.cfg.isice, 1, 0))
+        key = cls * 64 + np.where(cls == 0, np.clip(ivg, 0, 63), 0)
+        perm = torch.from_numpy(np.argsort(key, kind="stable").astype(np.int32)).to(store.device)
+        names = [k for k, v in store.a.items() if not isinstance(v, np.ndarray)]
+        for i in range(0, len(names), 32):
+            chunk = names[i:i + 32]
+            src = [store.a[k] for k in chunk]
+            dst = [torch.empty_like(t) for t in src]
+            Engine.Gather(self.lib, dst, src, perm, store.ni, store.nj)()
+            torch.cuda.synchronize()
+            for k, t in zip(chunk, dst):
+                store.a[k] = t
+        return perm
+
+    def gather(self, dst, src, perm, ni, nj):
+        return Engine.Gather(self.lib, dst, src, perm, ni, nj)
+
     def groundwater_init(self, store, stream=None):
         """GROUNDWATER_INIT + EQSMOISTURE (reference drv:1286-1522): equilibrium soil moisture, deep-layer moisture
         and water-table adjustment for OPT_RUN=5, in place.  ide+1 / jde+1 as NOAHMP_INIT receives them (hdrv:291)."""

@@ -69,3 +69,48 @@ def test_async_reports_earliest_failing_step_and_first_column(engine, tables):
     assert rc == -106
     engine.sync()
     assert engine.sync()[0].n_land == 0               # nothing pending: empty status
+
+
+def test_sorted_layout_gives_the_same_columns(engine, tables):
+    """Engine.sort_store + noahmp_hip_gather_fields: a run on the state sorted by (class, vegetation type), with the
+    forcing permuted per step, equals the run in tile order once un-permuted -- bit for bit."""
+    import torch
+    s = synth.mixed_small(tables[1], ni=96, nj=24, glacier_frac=0.05)
+    synth.first_step_fixups(s)
+    fkeys = ("coszin", "swdown", "glw", "t3d", "rainbl")
+    forc = []
+    for it in range(1, 6):
+        synth.diurnal_forcing(s, 9 + it, t_offset=s.t_offset)
+        forc.append({k: torch.from_numpy(s.a[k].copy()).cuda() for k in fkeys})
+    plain, srt = s.to_device("cuda:0"), s.to_device("cuda:0")
+    perm = engine.sort_store(srt)
+    p = perm.cpu().numpy()
+    assert sorted(p.tolist()) == list(range(s.ncol))
+    vt = srt.a["ivgtyp"].cpu().numpy().ravel()
+    ice = vt == s.cfg.isice
+    assert (np.diff(vt[~ice]) >= 0).all() and ice[ice.argmax():].all()         # land by type, then land ice
+    work = {k: torch.empty_like(forc[0][k]) for k in fkeys}
+    srt.a.update(work)
+    g = engine.gather([work[k] for k in fkeys], [forc[0][k] for k in fkeys], perm, s.ni, s.nj)
+    args = srt.step_args(1, 2000, 180.0)
+    for it in range(1, 6):
+        plain.a.update(forc[it - 1])
+        engine.noahmplsm(plain, it, 2000, 180.0)
+    for it in range(1, 6):
+        g.set_sources([forc[it - 1][k] for k in fkeys])
+        g()
+        args.itimestep = it
+        engine.noahmplsm_async(args)
+    st, _ = engine.sync()
+    assert st.code == 0
+    hp, hs = plain.to_host(), srt.to_host()
+    for k in _outs(hp):
+        if k in fkeys:
+            continue
+        a, b = hp.a[k], hs.a[k]
+        if a.ndim == 2:
+            np.testing.assert_array_equal(a.ravel()[p], b.ravel(), err_msg=k)
+        else:
+            nj, nk, ni = a.shape
+            np.testing.assert_array_equal(a.transpose(1, 0, 2).reshape(nk, -1)[:, p], b.transpose(1, 0, 2).reshape(nk, -1),
+                                          err_msg=k)
