@@ -55,3 +55,9 @@ run(permuted(s, glacier * 10 + bare), "sorted by class, vegetated | bare")
 run(permuted(s, glacier * 1000 + veg), "sorted by class, vegetation type")
 run(permuted(s, glacier * 1000 + isn * 100 + bare), "sorted by class, snow layers, veg | bare")
 run(permuted(s, glacier * 10000 + veg * 10 + isn), "sorted by class, vegetation type, snow layers")
+tp = os.path.join(ROOT, "trips_tmp.npy")
+if which == "config2" and os.path.exists(tp):      # oracle experiment: canopy-loop trip counts of THIS step (host emulation)
+    trips = np.load(tp).reshape(veg.shape).astype(np.int64)
+    run(permuted(s, trips), "sorted by this step's canopy trip count")
+    run(permuted(s, veg * 32 + trips), "sorted by vegetation type, then trip count")
+    run(permuted(s, trips * 32 + veg), "sorted by trip count, then vegetation type")
