@@ -20,12 +20,22 @@ NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f", "powf", "acosf", 
 UNARY = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10]      # 6 = powf (binary)
 
 
-def _lib():
+def build():
+    """Compile the checker library (no dlopen: it links the system HIP runtime, which must not be mapped before
+    PyTorch's own copy in a process that later uses the GPU through torch)."""
     csrc = os.path.join(ROOT, "noahmp_amd", "csrc")
     deps = [SRC, os.path.join(csrc, "nmp_libm.hpp"), os.path.join(csrc, "nmp_libm_tables.inc")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-fPIC", "-shared", "-std=c++17",
                                "-ffp-contract=off", "-mfma", "-I" + csrc, SRC, "-o", LIB, "-lpthread"])
+
+
+def _lib():
+    build()
+    try:
+        import torch  # noqa: F401  (see noahmp_amd/abi.py::load_library: map torch's HIP runtime first)
+    except ImportError:
+        pass
     lib = C.CDLL(LIB)
     lib.libm_check_unary.restype = C.c_long
     lib.libm_check_unary.argtypes = [C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
