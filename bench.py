@@ -116,7 +116,7 @@ def main():
     d = s.to_device("cuda:%d" % local_rank)
     ncol = s.ncol
 
-    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type) so that a
+    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type, 1-K skin-temperature bin) so that a
     # wavefront holds columns that take the same branches.  Forcing arrives in tile order (as a driver would deliver it)
     # and is permuted into the sorted working set every step, INSIDE the timed region.
     perm = eng.sort_store(d)
@@ -184,7 +184,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic land columns per GPU (%dx%d tile), "
                                    "4 soil / 0 snow layers, DVEG=1 (dynamic_veg off), opt_run=1, hourly "
-                                   "diurnal forcing, state resident in HBM sorted by vegetation type, forcing permuted "
+                                   "diurnal forcing, state resident in HBM sorted by (vegetation type, skin-temperature bin), forcing permuted "
                                    "per step inside the timed region" % (ncol, args.ni, args.nj),
                        "columns_per_gpu": ncol, "parallelism": "columns split %d-way, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

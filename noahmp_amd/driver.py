@@ -121,12 +121,14 @@ class Engine:
             if rc:
                 raise RuntimeError("noahmp_hip_gather_fields: rc=%d" % rc)
 
-    def sort_store(self, store, keys=("class", "ivgtyp")):
-        """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type) are adjacent
-        (stable, so tile order is kept inside a group) and return the permutation as an int32 device tensor:
-        sorted position p holds the column that was at linear tile index perm[p].  Columns are independent (every
-        option except the MMF lateral flow), so this only changes which lane computes which column; wavefronts then
-        hold columns that take the same branches.  Forcing that arrives in tile order goes through `gather`."""
+    def sort_store(self, store, tsk_bin=1.0):
+        """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, skin-temperature
+        bin) are adjacent (stable, so tile order is kept inside a group) and return the permutation as an int32
+        device tensor: sorted position p holds the column that was at linear tile index perm[p].  Columns are
+        independent (every option except the MMF lateral flow), so this only changes which lane computes which
+        column; wavefronts then hold columns that take the same branches: class and vegetation type select code
+        paths and are static, the skin temperature (`tsk_bin` K wide bins, 0 = off) is a cheap proxy for the
+        stability / freezing regime a column is in.  Forcing that arrives in tile order goes through `gather`."""
         import numpy as np
         import torch
         assert isinstance(store, DeviceColumnStore)
@@ -135,6 +137,9 @@ class Engine:
         xice = store.a["xice"].cpu().numpy().ravel()
         cls = np.where((xland - 1.5 >= 0) | (xice >= store.cfg.xice_thres), 2, np.where(ivg == store.cfg.isice, 1, 0))
         key = cls * 64 + np.where(cls == 0, np.clip(ivg, 0, 63), 0)
+        if tsk_bin:
+            tsk = np.nan_to_num(store.a["tsk"].cpu().numpy().ravel().astype(np.float64), nan=250.0)
+            key = key * 256 + np.clip(((tsk - 230.0) / tsk_bin).astype(np.int64), 0, 255)
         perm = torch.from_numpy(np.argsort(key, kind="stable").astype(np.int32)).to(store.device)
         names = [k for k, v in store.a.items() if not isinstance(v, np.ndarray)]
         for i in range(0, len(names), 32):

@@ -83,7 +83,7 @@ def test_sorted_layout_gives_the_same_columns(engine, tables):
         synth.diurnal_forcing(s, 9 + it, t_offset=s.t_offset)
         forc.append({k: torch.from_numpy(s.a[k].copy()).cuda() for k in fkeys})
     plain, srt = s.to_device("cuda:0"), s.to_device("cuda:0")
-    perm = engine.sort_store(srt)
+    perm = engine.sort_store(srt, tsk_bin=0)
     p = perm.cpu().numpy()
     assert sorted(p.tolist()) == list(range(s.ncol))
     vt = srt.a["ivgtyp"].cpu().numpy().ravel()
@@ -103,6 +103,8 @@ def test_sorted_layout_gives_the_same_columns(engine, tables):
         engine.noahmplsm_async(args)
     st, _ = engine.sync()
     assert st.code == 0
+    p2 = engine.sort_store(s.to_device("cuda:0")).cpu().numpy()          # default keys incl. the TSK bin: a permutation too
+    assert sorted(p2.tolist()) == list(range(s.ncol))
     hp, hs = plain.to_host(), srt.to_host()
     for k in _outs(hp):
         if k in fkeys:

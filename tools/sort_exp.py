@@ -55,6 +55,17 @@ run(permuted(s, glacier * 10 + bare), "sorted by class, vegetated | bare")
 run(permuted(s, glacier * 1000 + veg), "sorted by class, vegetation type")
 run(permuted(s, glacier * 1000 + isn * 100 + bare), "sorted by class, snow layers, veg | bare")
 run(permuted(s, glacier * 10000 + veg * 10 + isn), "sorted by class, vegetation type, snow layers")
+soil = a["isltyp"].astype(np.int64)
+vfb = np.clip((a["vegfra"] / 10.0).astype(np.int64), 0, 9)
+tsb = np.clip(((a["tsk"] - 270.0) / 3.0).astype(np.int64), 0, 15)
+run(permuted(s, glacier * 100000 + veg * 64 + soil), "sorted by class, vegetation type, soil type")
+run(permuted(s, glacier * 100000 + veg * 16 + vfb), "sorted by class, vegetation type, VEGFRA decile")
+run(permuted(s, glacier * 100000 + veg * 16 + tsb), "sorted by class, vegetation type, TSK 3-K bin")
+run(permuted(s, glacier * 100000 + tsb * 64 + veg), "sorted by class, TSK 3-K bin, vegetation type")
+run(permuted(s, glacier * 1000000 + veg * 256 + tsb * 16 + vfb), "sorted by class, veg type, TSK bin, VEGFRA decile")
+tsb1 = np.clip(((a["tsk"] - 270.0) / 1.0).astype(np.int64), 0, 47)
+run(permuted(s, glacier * 1000000 + veg * 64 + tsb1), "sorted by class, vegetation type, TSK 1-K bin")
+run(permuted(s, glacier * 1000000 + veg * 100000 + (a["tsk"] * 100).astype(np.int64) % 100000), "sorted by class, vegetation type, TSK")
 tp = os.path.join(ROOT, "trips_tmp.npy")
 if which == "config2" and os.path.exists(tp):      # oracle experiment: canopy-loop trip counts of THIS step (host emulation)
     trips = np.load(tp).reshape(veg.shape).astype(np.int64)
