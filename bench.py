@@ -116,10 +116,10 @@ def main():
     d = s.to_device("cuda:%d" % local_rank)
     ncol = s.ncol
 
-    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type, 1-K skin-temperature bin) so that a
+    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type, 3-K skin-temperature bin) so that a
     # wavefront holds columns that take the same branches.  Forcing arrives in tile order (as a driver would deliver it)
     # and is permuted into the sorted working set every step, INSIDE the timed region.
-    perm = eng.sort_store(d)
+    perm = eng.sort_store(d, tsk_bin=3.0)
     work = {k: torch.empty_like(forcing[0][k]) for k in fkeys}
     d.a.update(work)
     gather = eng.gather([work[k] for k in fkeys], [forcing[0][k] for k in fkeys], perm, s.ni, s.nj)

@@ -121,7 +121,7 @@ class Engine:
             if rc:
                 raise RuntimeError("noahmp_hip_gather_fields: rc=%d" % rc)
 
-    def sort_store(self, store, tsk_bin=1.0):
+    def sort_store(self, store, tsk_bin=3.0):
         """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, skin-temperature
         bin) are adjacent (stable, so tile order is kept inside a group) and return the permutation as an int32
         device tensor: sorted position p holds the column that was at linear tile index perm[p].  Columns are
