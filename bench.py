@@ -103,7 +103,7 @@ def main():
     torch.cuda.set_device(local_rank)
     comm = Comm()                                           # one process per GPU; "nccl" = RCCL when world > 1
 
-    eng = Engine(T, device=local_rank)
+    eng = Engine(T, device=local_rank, lib_path=os.environ.get("NMP_LIB"))
     cfg = ModelConfig(idveg=1)                              # "dynamic_veg off", config 2
     s = synth.config2(tb, ni=args.ni, nj=args.nj, seed=2 + rank, cfg=cfg)
     synth.first_step_fixups(s)
@@ -116,13 +116,13 @@ def main():
     d = s.to_device("cuda:%d" % local_rank)
     ncol = s.ncol
 
-    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type, 3-K skin-temperature bin) so that a
+    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type, 1-K skin-temperature bin) so that a
     # wavefront holds columns that take the same branches.  Forcing arrives in tile order (as a driver would deliver it)
     # and is permuted into the sorted working set every step, INSIDE the timed region.
-    perm = eng.sort_store(d, tsk_bin=3.0)
+    perm = eng.sort_store(d)
     work = {k: torch.empty_like(forcing[0][k]) for k in fkeys}
     d.a.update(work)
-    gather = eng.gather([work[k] for k in fkeys], [forcing[0][k] for k in fkeys], perm, s.ni, s.nj)
+    gather = eng.scatter([work[k] for k in fkeys], [forcing[0][k] for k in fkeys], perm, s.ni, s.nj)
     # One argument block, built once; a step swaps the forcing record, permutes it and enqueues the kernel
     # (noahmp_hip_step_async: device-resident state, nothing to wait for until output is due).
     sargs = d.step_args(1, 2000, 180.0)

@@ -50,7 +50,79 @@ __global__ void __launch_bounds__(256) noahmp_gather_kernel(const GatherArgs k) 
 }
 }  // namespace
 
+// The same permutation as a chunked scatter with sorted write order: a workgroup loads CHUNK consecutive source columns
+// of a field (coalesced) into LDS and writes them in ascending order of their destination, so that the columns that go
+// to the same group leave as one contiguous run instead of 4 bytes at a time.  `order[c*CHUNK+q]` = offset inside chunk c
+// of the column with the q-th smallest destination, `dpos[...]` = that destination (both prepared once per sort).
+namespace {
+constexpr int kChunk = 1024;
+struct ScatterArgs {
+  void* dst[kMaxGather];
+  const void* src[kMaxGather];
+  int nlev[kMaxGather];
+  const unsigned short* order;
+  const int* dpos;
+  int n, ni, nj;
+};
+__global__ void __launch_bounds__(256) noahmp_scatter_kernel(const ScatterArgs k) {
+  __shared__ uint32_t buf[kChunk];
+  const long ncol = (long)k.ni * k.nj;
+  const long base = (long)blockIdx.x * kChunk;
+  unsigned short ord[kChunk / 256];
+  int dp[kChunk / 256];
+#pragma unroll
+  for (int r = 0; r < kChunk / 256; r++) {
+    const long q = base + r * 256 + threadIdx.x;
+    ord[r] = q < ncol ? k.order[q] : 0;
+    dp[r] = q < ncol ? k.dpos[q] : -1;
+  }
+  for (int f = 0; f < k.n; f++) {
+    const int nk = k.nlev[f];
+    const uint32_t* s = (const uint32_t*)k.src[f];
+    uint32_t* d = (uint32_t*)k.dst[f];
+    for (int l = 0; l < nk; l++) {
+#pragma unroll
+      for (int r = 0; r < kChunk / 256; r++) {
+        const long g = base + r * 256 + threadIdx.x;
+        if (g < ncol) {
+          const int gj = (int)(g / k.ni), gi = (int)(g - (long)gj * k.ni);
+          buf[r * 256 + threadIdx.x] = s[((size_t)gj * nk + l) * k.ni + gi];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < kChunk / 256; r++) {
+        if (dp[r] >= 0) {
+          const int pj = dp[r] / k.ni, pi = dp[r] - pj * k.ni;
+          d[((size_t)pj * nk + l) * k.ni + pi] = buf[ord[r]];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int noahmp_hip_scatter_fields(int n, void* const* dst, const void* const* src, const int* nlev, const uint16_t* order,
+                              const int32_t* dpos, int ni, int nj, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (n < 0 || n > kMaxGather) { g.last_error = "noahmp_hip_scatter_fields: at most 32 fields per call"; return -107; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  ScatterArgs k;
+  memset(&k, 0, sizeof(k));
+  for (int f = 0; f < n; f++) { k.dst[f] = dst[f]; k.src[f] = src[f]; k.nlev[f] = nlev[f]; }
+  k.order = order; k.dpos = dpos; k.n = n; k.ni = ni; k.nj = nj;
+  const long ncol = (long)ni * nj;
+  if (ncol > 0 && n > 0)
+    hipLaunchKernelGGL(noahmp_scatter_kernel, dim3((unsigned)((ncol + kChunk - 1) / kChunk)), dim3(256), 0, s, k);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int noahmp_hip_scatter_chunk(void) { return kChunk; }
 
 int noahmp_hip_gather_fields(int n, void* const* dst, const void* const* src, const int* nlev, const int32_t* perm, int ni,
                              int nj, void* stream) {

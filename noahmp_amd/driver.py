@@ -121,7 +121,7 @@ class Engine:
             if rc:
                 raise RuntimeError("noahmp_hip_gather_fields: rc=%d" % rc)
 
-    def sort_store(self, store, tsk_bin=3.0):
+    def sort_store(self, store, tsk_bin=1.0):
         """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, skin-temperature
         bin) are adjacent (stable, so tile order is kept inside a group) and return the permutation as an int32
         device tensor: sorted position p holds the column that was at linear tile index perm[p].  Columns are
@@ -154,6 +154,38 @@ class Engine:
 
     def gather(self, dst, src, perm, ni, nj):
         return Engine.Gather(self.lib, dst, src, perm, ni, nj)
+
+    class Scatter(Gather):
+        """The same permutation through noahmp_hip_scatter_fields (chunked, LDS-staged, sorted write order): the form
+        to use for records that arrive every step."""
+
+        def __init__(self, lib, dst, src, perm, ni, nj):
+            import numpy as np
+            import torch
+            Engine.Gather.__init__(self, lib, dst, src, perm, ni, nj)
+            chunk = lib.noahmp_hip_scatter_chunk()
+            p = perm.cpu().numpy().astype(np.int64)
+            n = p.size
+            inv = np.empty(n, dtype=np.int64)
+            inv[p] = np.arange(n)                                   # inv[g] = sorted position of tile column g
+            npad = (n + chunk - 1) // chunk * chunk
+            invp = np.full(npad, np.iinfo(np.int64).max, dtype=np.int64)
+            invp[:n] = inv
+            invp = invp.reshape(-1, chunk)
+            order = np.argsort(invp, axis=1, kind="stable")
+            dpos = np.take_along_axis(invp, order, axis=1)
+            dpos[dpos == np.iinfo(np.int64).max] = -1
+            self.order = torch.from_numpy(order.astype(np.uint16).view(np.int16).ravel()[:n].copy()).to(perm.device)
+            self.dpos = torch.from_numpy(dpos.astype(np.int32).ravel()[:n].copy()).to(perm.device)
+
+        def __call__(self, stream=None):
+            rc = self.lib.noahmp_hip_scatter_fields(self.n, self.dst, self.src, self.nlev, self.order.data_ptr(),
+                                                    self.dpos.data_ptr(), self.ni, self.nj, stream)
+            if rc:
+                raise RuntimeError("noahmp_hip_scatter_fields: rc=%d" % rc)
+
+    def scatter(self, dst, src, perm, ni, nj):
+        return Engine.Scatter(self.lib, dst, src, perm, ni, nj)
 
     def groundwater_init(self, store, stream=None):
         """GROUNDWATER_INIT + EQSMOISTURE (reference drv:1286-1522): equilibrium soil moisture, deep-layer moisture

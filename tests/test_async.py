@@ -91,7 +91,12 @@ def test_sorted_layout_gives_the_same_columns(engine, tables):
     assert (np.diff(vt[~ice]) >= 0).all() and ice[ice.argmax():].all()         # land by type, then land ice
     work = {k: torch.empty_like(forc[0][k]) for k in fkeys}
     srt.a.update(work)
-    g = engine.gather([work[k] for k in fkeys], [forc[0][k] for k in fkeys], perm, s.ni, s.nj)
+    g = engine.scatter([work[k] for k in fkeys], [forc[0][k] for k in fkeys], perm, s.ni, s.nj)
+    chk = {k: torch.empty_like(forc[0][k]) for k in fkeys}
+    g2 = engine.gather([chk[k] for k in fkeys], [forc[2][k] for k in fkeys], perm, s.ni, s.nj)
+    g.set_sources([forc[2][k] for k in fkeys]); g(); g2(); torch.cuda.synchronize()
+    for k in fkeys:                                   # both permutation kernels agree
+        assert torch.equal(work[k], chk[k]), k
     args = srt.step_args(1, 2000, 180.0)
     for it in range(1, 6):
         plain.a.update(forc[it - 1])
