@@ -65,39 +65,35 @@ struct ScatterArgs {
   int n, ni, nj;
 };
 __global__ void __launch_bounds__(256) noahmp_scatter_kernel(const ScatterArgs k) {
-  __shared__ uint32_t buf[kChunk];
+  constexpr int R = kChunk / 256;
+  __shared__ uint32_t buf[2][kChunk];                 // double-buffered: one barrier per field level
   const long ncol = (long)k.ni * k.nj;
   const long base = (long)blockIdx.x * kChunk;
-  unsigned short ord[kChunk / 256];
-  int dp[kChunk / 256];
+  int ord[R], sj[R], si[R], pj[R], pi[R];
 #pragma unroll
-  for (int r = 0; r < kChunk / 256; r++) {
+  for (int r = 0; r < R; r++) {
     const long q = base + r * 256 + threadIdx.x;
-    ord[r] = q < ncol ? k.order[q] : 0;
-    dp[r] = q < ncol ? k.dpos[q] : -1;
+    const bool in = q < ncol;
+    ord[r] = in ? k.order[q] : 0;
+    const int dp = in ? k.dpos[q] : -1;
+    pj[r] = dp >= 0 ? dp / k.ni : -1;
+    pi[r] = dp >= 0 ? dp - pj[r] * k.ni : 0;
+    sj[r] = in ? (int)(q / k.ni) : -1;
+    si[r] = in ? (int)(q - (long)sj[r] * k.ni) : 0;
   }
+  int phase = 0;
   for (int f = 0; f < k.n; f++) {
     const int nk = k.nlev[f];
     const uint32_t* s = (const uint32_t*)k.src[f];
     uint32_t* d = (uint32_t*)k.dst[f];
-    for (int l = 0; l < nk; l++) {
+    for (int l = 0; l < nk; l++, phase ^= 1) {
 #pragma unroll
-      for (int r = 0; r < kChunk / 256; r++) {
-        const long g = base + r * 256 + threadIdx.x;
-        if (g < ncol) {
-          const int gj = (int)(g / k.ni), gi = (int)(g - (long)gj * k.ni);
-          buf[r * 256 + threadIdx.x] = s[((size_t)gj * nk + l) * k.ni + gi];
-        }
-      }
+      for (int r = 0; r < R; r++)
+        if (sj[r] >= 0) buf[phase][r * 256 + threadIdx.x] = s[((size_t)sj[r] * nk + l) * k.ni + si[r]];
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < kChunk / 256; r++) {
-        if (dp[r] >= 0) {
-          const int pj = dp[r] / k.ni, pi = dp[r] - pj * k.ni;
-          d[((size_t)pj * nk + l) * k.ni + pi] = buf[ord[r]];
-        }
-      }
-      __syncthreads();
+      for (int r = 0; r < R; r++)
+        if (pj[r] >= 0) d[((size_t)pj[r] * nk + l) * k.ni + pi[r]] = buf[phase][ord[r]];
     }
   }
 }
