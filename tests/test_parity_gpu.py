@@ -439,3 +439,31 @@ def test_groundwater_full_size_config4(engine, port, tables):
     out = _run_tiles(engine, s, 8)
     for k in GW_OUT:
         np.testing.assert_array_equal(g.a[k], out.a[k], err_msg=k)
+
+
+MIXES = [dict(), dict(idveg=2, iopt_run=3, iopt_stc=2),
+         dict(iopt_sfc=2, iopt_crs=2, iopt_btr=2, iopt_frz=2, iopt_inf=2),
+         dict(iopt_rad=1, iopt_alb=1, iopt_snf=3, iopt_tbot=1, idveg=5)]
+
+
+@pytest.mark.parametrize("kw", MIXES, ids=[repr(k) for k in MIXES])
+def test_free_run_option_mixes_bit_identical(engine, port, tables, kw):
+    """36 free-running hourly steps of a 4096-column mixed tile under combined non-default options, device-resident,
+    against the oracle advanced from the same start: every output, every step (tools/long_parity.py runs 96)."""
+    if not _exact(engine):
+        pytest.skip("ocml build: statistical parity only")
+    import torch
+    s = synth.mixed_small(tables[1], ni=128, nj=32, seed=31, cfg=ModelConfig(**kw))
+    synth.first_step_fixups(s)
+    o, d = s.copy(), s.to_device("cuda:0")
+    for it in range(1, 37):
+        synth.diurnal_forcing(o, (it - 1) % 24, t_offset=s.t_offset)
+        for k in ("coszin", "swdown", "glw", "t3d", "rainbl"):
+            d.a[k].copy_(torch.from_numpy(o.a[k]))
+        so = port.noahmplsm(o, it, 2000, 180.0 + it / 24.0)
+        sd = engine.noahmplsm(d, it, 2000, 180.0 + it / 24.0, check=False)
+        assert so.code == sd.code == 0, (it, so.code, sd.code)
+        if it % 6 == 0:
+            ok, lines = exact_check(o, d.to_host())
+            assert ok, "step %d\n%s" % (it, "\n".join(lines))
+    assert set(np.unique(o.a["isnowxy"]).tolist()) == {0, -1, -2, -3}
