@@ -192,7 +192,7 @@ def main():
                          "kernel": "noahmp_column_kernel", "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * ncol,
                          "note": "824 B/column-step x columns / HIP-event kernel time; the kernel is VALU-issue and "
-                                 "divergence bound (26 k VALU instructions per column-step wave, 82 % lane utilisation: "
+                                 "divergence bound (24 k VALU instructions per column-step wave, 90 % lane utilisation: "
                                  "profiles/r01_profile.md), not HBM bound (SURVEY 8d)"},
             "kernel_only_column_steps_per_s": (n_land / args.steps) / (k_avg_ms * 1e-3) * world,
         }
