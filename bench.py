@@ -104,6 +104,8 @@ def main():
     comm = Comm()                                           # one process per GPU; "nccl" = RCCL when world > 1
 
     eng = Engine(T, device=local_rank, lib_path=os.environ.get("NMP_LIB"))
+    if os.environ.get("NMP_BLOCK"):
+        eng.set_option("block", int(os.environ["NMP_BLOCK"]))
     cfg = ModelConfig(idveg=1)                              # "dynamic_veg off", config 2
     s = synth.config2(tb, ni=args.ni, nj=args.nj, seed=2 + rank, cfg=cfg)
     synth.first_step_fixups(s)

@@ -146,7 +146,7 @@ def test_launch_variants_bit_identical(engine, tables):
             engine.noahmplsm(x, 1, 2000, 180.0)
             outs.append(x)
     finally:
-        engine.set_option("block", 64)
+        engine.set_option("block", 256)
         engine.set_option("lds", 1)
     for x in outs[1:]:
         for k in _outs(x):
