@@ -176,7 +176,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                prof = json.load(open(tpath))
+                # PMC counters come from a separate rocprofv3 --pmc pass of this very workload (tools/run_profile.sh)
+                traffic = prof.get("hbm_bytes_per_launch") if prof.get("columns_per_launch") == ncol else None
             except Exception:
                 traffic = None
         out = {

@@ -21,7 +21,7 @@ class Comm:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = backend or os.environ.get("NMP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
