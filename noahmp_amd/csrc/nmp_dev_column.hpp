@@ -19,6 +19,7 @@ struct KArgs {
   unsigned long long* err;   // min over columns of ((linear index + 1) << 8 | code)
   int* counts;               // [0]=land [1]=glacier [2]=skipped
   unsigned long long err_base;   // step ordinal << 40 for asynchronous stepping (0 otherwise)
+  long t_offset;                 // tile index of this launch's first column when a tile is advanced in row chunks
 };
 
 constexpr int LAY_SLOTS = 4 * 7 + 5 * 4 + 3 * 3;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "noahmp_hip.h"
 
@@ -41,6 +42,15 @@ struct Engine {
   std::vector<hipStream_t> async_streams;
   std::vector<hipEvent_t> async_events;     // start/end of each pending step's kernel   // every stream that carries pending asynchronous steps
   int async_nti = 1, async_its = 1, async_jts = 1;
+  // host-memory path: row-chunk pipeline H2D | kernel | D2H on three streams, optional pinning of the caller's arrays
+  hipStream_t s_up = nullptr, s_dn = nullptr;
+  std::vector<hipEvent_t> pipe_events;
+  struct HostReg { size_t bytes; int seen; int state; };     // state 0 pageable, 1 registered, -1 registration refused
+  std::unordered_map<const void*, HostReg> host_regs;
+  int host_chunks = 3;          // 0/1: single-shot staging (3 measured best at 1 M columns: fewer, larger copies)
+  int pin_host_arrays = 0;      // hipHostRegister arrays seen twice at the same address (caller guarantees their lifetime)
+  int trust_out_mirror = 0;     // do not re-upload OUT arrays after the first call (caller leaves them alone between calls)
+  bool out_mirror_valid = false;
   int block = 256;             // 4 waves per workgroup: ~1 % faster than 64 at 1 M columns (bench); 64 and 128 selectable
   int use_lds = 1;
   std::string last_error;

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
   if (cls > 1) return;
   SimpleLoop runner;
   const int err = column_step<STRIDE>(k, cls, ii, jj, ij, base, runner);
-  if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + 1) << 8) | (unsigned)err);   // first column wins
+  if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)err);   // first column wins
 }
 
 // --------------------------------------------------------------------------------------------
@@ -163,6 +163,23 @@ int noahmp_hip_set_option(const char* key, int value) {
   int prev = -1;
   if (!strcmp(key, "block")) { prev = g.block; if (value == 64 || value == 128 || value == 256) g.block = value; }
   else if (!strcmp(key, "lds")) { prev = g.use_lds; g.use_lds = value ? 1 : 0; }
+  else if (!strcmp(key, "host_chunks")) { prev = g.host_chunks; if (value >= 0 && value <= 32) g.host_chunks = value; }
+  else if (!strcmp(key, "pin_host_arrays")) {
+    prev = g.pin_host_arrays;
+    if (value == 0 || value == 1) {
+      g.pin_host_arrays = value;
+      if (!value) {                               // leaving the mode: drop every registration (the arrays may be freed now)
+        hipDeviceSynchronize();
+        for (auto& kv : g.host_regs) if (kv.second.state == 1) hipHostUnregister(const_cast<void*>(kv.first));
+        g.host_regs.clear();
+        (void)hipGetLastError();
+      }
+    }
+  }
+  else if (!strcmp(key, "trust_out_mirror")) {
+    prev = g.trust_out_mirror;
+    if (value == 0 || value == 1) { g.trust_out_mirror = value; g.out_mirror_valid = false; }
+  }
   else if (!strcmp(key, "exact_libm")) prev = NMP_EXACT_LIBM;   // read-only: how this library was built
   return prev;
 }
@@ -212,6 +229,112 @@ static int check_step_args(const noahmp_step_args* a, noahmp_status* st) {
   return 0;
 }
 
+// hipHostRegister an array of the caller the second time it shows up at the same address (opt-in: the caller guarantees
+// that such arrays outlive the engine or calls noahmp_hip_finalize() first)
+static void maybe_pin(const void* host, size_t bytes) {
+  if (!g.pin_host_arrays) return;
+  auto it = g.host_regs.find(host);
+  if (it == g.host_regs.end()) { g.host_regs[host] = nmp_host::Engine::HostReg{bytes, 1, 0}; return; }
+  nmp_host::Engine::HostReg& r = it->second;
+  if (r.bytes != bytes) {
+    if (r.state == 1) hipHostUnregister(const_cast<void*>(host));
+    r = nmp_host::Engine::HostReg{bytes, 1, 0};
+    return;
+  }
+  r.seen++;
+  if (r.state == 0 && r.seen >= 2)
+    r.state = hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault) == hipSuccess ? 1 : -1;
+  (void)hipGetLastError();
+}
+
+// Host-memory path for large tiles: the tile is advanced in row chunks, chunk c+1 uploading while chunk c computes and
+// chunk c-1 downloads (three streams).  Results are those of the single launch: columns are independent, the tallies
+// accumulate, and the error word orders columns by their index in the whole tile (KArgs::t_offset).
+static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_status* st) {
+  KArgs k;
+  fill_kargs(k, a);
+  const int nj_mem = a->jme - a->jms + 1;
+  if (!g.s_up) { HIPCHK(hipStreamCreateWithFlags(&g.s_up, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&g.s_dn, hipStreamNonBlocking)); }
+  const int nchunk = g.host_chunks < nj_mem ? g.host_chunks : nj_mem;
+  while ((int)g.pipe_events.size() < 3 * nchunk) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); g.pipe_events.push_back(e); }
+  const bool upload_out = !(g.trust_out_mirror && g.out_mirror_valid);
+  size_t rowbytes[kNumFields];
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    const size_t bytes = field_elems(fd, a) * 4;
+    rowbytes[f] = bytes / nj_mem;
+    if (g.mirror_bytes[f] < bytes) {
+      if (g.mirror[f]) HIPCHK(hipFree(g.mirror[f]));
+      HIPCHK(hipMalloc(&g.mirror[f], bytes));
+      g.mirror_bytes[f] = bytes;
+      g.out_mirror_valid = false;
+    }
+    maybe_pin(*(void* const*)((const char*)a + fd.off), bytes);
+    *(void**)((char*)&k.a + fd.off) = g.mirror[f];
+  }
+  const bool up_out = upload_out || !g.out_mirror_valid;
+  *g.h_err = ~0ULL;
+  HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
+  // uploads, in row order
+  for (int c = 0; c < nchunk; c++) {
+    const int r0 = (int)((long)nj_mem * c / nchunk), r1 = (int)((long)nj_mem * (c + 1) / nchunk);
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      if (fd.io == 2 && !up_out) continue;
+      const char* host = (const char*)*(void* const*)((const char*)a + fd.off);
+      HIPCHK(hipMemcpyAsync((char*)g.mirror[f] + rowbytes[f] * r0, host + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
+                            hipMemcpyHostToDevice, g.s_up));
+    }
+    HIPCHK(hipEventRecord(g.pipe_events[3 * c], g.s_up));
+  }
+  // kernels and downloads
+  for (int c = 0; c < nchunk; c++) {
+    const int r0 = (int)((long)nj_mem * c / nchunk), r1 = (int)((long)nj_mem * (c + 1) / nchunk);
+    HIPCHK(hipStreamWaitEvent(s, g.pipe_events[3 * c], 0));
+    KArgs kc = k;
+    const int j0 = a->jms + r0 > a->jts ? a->jms + r0 : a->jts;
+    const int j1 = a->jms + r1 - 1 < a->jte ? a->jms + r1 - 1 : a->jte;
+    HIPCHK(hipEventRecord(g.pipe_events[3 * c + 1], s));
+    if (j1 >= j0) {
+      kc.a.jts = j0; kc.a.jte = j1;
+      kc.ntj = j1 - j0 + 1;
+      kc.t_offset = (long)(j0 - a->jts) * k.nti;
+      launch_any(kc, s);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(g.pipe_events[3 * c + 2], s));
+    HIPCHK(hipStreamWaitEvent(g.s_dn, g.pipe_events[3 * c + 2], 0));
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      if (fd.io == 0) continue;
+      char* host = (char*)*(void* const*)((const char*)a + fd.off);
+      HIPCHK(hipMemcpyAsync(host + rowbytes[f] * r0, (char*)g.mirror[f] + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
+                            hipMemcpyDeviceToHost, g.s_dn));
+    }
+  }
+  HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipStreamSynchronize(g.s_dn));
+  g.out_mirror_valid = true;
+  int code = 0;
+  if (st) {
+    float ms = 0.f;
+    for (int c = 0; c < nchunk; c++) { float one = 0.f; hipEventElapsedTime(&one, g.pipe_events[3 * c + 1], g.pipe_events[3 * c + 2]); ms += one; }
+    st->kernel_ms = ms;
+    int cnt[4];
+    nmp_host::sum_counts(cnt);
+    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+  }
+  if (*g.h_err != ~0ULL) {
+    code = (int)(*g.h_err & 0xFF);
+    const long t = (long)(*g.h_err >> 8) - 1;
+    if (st) { st->code = code; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
+  }
+  return code;
+}
+
 extern "C" {
 
 int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
@@ -222,11 +345,17 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   if (rc) return rc;
   if (g.async_pending) { g.last_error = "noahmp_hip_step: asynchronous steps are pending, call noahmp_hip_sync() first"; return -106; }
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  // the row-chunk pipeline only pays with pinned arrays (pageable asynchronous copies are staged and serialise)
+  if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && g.host_chunks > 1 &&
+      (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) >= 32768 &&
+      a->jme - a->jms + 1 >= 2 * g.host_chunks)
+    return step_host_pipelined(a, s, st);
 
   KArgs k;
   fill_kargs(k, a);
 
   if (mem == NOAHMP_MEM_HOST) {
+    g.out_mirror_valid = false;
     // stage every array H2D into persistent device mirrors (caller's arrays stay the source of truth)
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
@@ -237,6 +366,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
         g.mirror_bytes[f] = bytes;
       }
       void* host = *(void* const*)((const char*)a + fd.off);
+      maybe_pin(host, bytes);
       // OUT arrays are uploaded too: columns the call does not touch (open water, sea ice, cells
       // outside its:ite/jts:jte, a column that raised a fatal) must come back unchanged, exactly
       // as the reference leaves them.
@@ -400,6 +530,10 @@ void noahmp_hip_finalize(void) {
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto e : g.async_events) hipEventDestroy(e);
+  for (auto e : g.pipe_events) hipEventDestroy(e);
+  for (auto& kv : g.host_regs) if (kv.second.state == 1) hipHostUnregister(const_cast<void*>(kv.first));
+  if (g.s_up) hipStreamDestroy(g.s_up);
+  if (g.s_dn) hipStreamDestroy(g.s_dn);
   if (g.gw_kcell) hipFree(g.gw_kcell);
   if (g.gw_head) hipFree(g.gw_head);
   if (g.d_tables) hipFree(g.d_tables);

@@ -467,3 +467,46 @@ def test_free_run_option_mixes_bit_identical(engine, port, tables, kw):
             ok, lines = exact_check(o, d.to_host())
             assert ok, "step %d\n%s" % (it, "\n".join(lines))
     assert set(np.unique(o.a["isnowxy"]).tolist()) == {0, -1, -2, -3}
+
+
+def test_pipelined_host_path_bit_identical(engine, tables):
+    """Large tiles on the host-memory path are advanced in row chunks (H2D | kernel | D2H on three streams): same bits as
+    the device-resident path, untouched cells preserved, fatal column reported with its index in the whole tile."""
+    from noahmp_amd.driver import NoahMPFatal
+    s = synth.mixed_small(tables[1], ni=512, nj=96, seed=13)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
+    r = np.random.default_rng(3)
+    s["xland"][r.random(size=(96, 512)) < 0.05] = 2.0            # open water: every output must come back as it went in
+    for k in ("hfx", "t2mvxy", "chb2xy", "bgapxy"):
+        s.a[k][...] = r.normal(size=s.a[k].shape).astype(np.float32)
+    h, d = s.copy(), s.to_device("cuda:0")
+    prev = {k: engine.set_option(k, v) for k, v in (("host_chunks", 6), ("pin_host_arrays", 1), ("trust_out_mirror", 0))}
+    try:
+        for it in (1, 2, 3):                                       # 2nd call pins the arrays, 3rd runs pinned
+            sh = engine.noahmplsm(h, it, 2000, 180.0)
+            sd = engine.noahmplsm(d, it, 2000, 180.0)
+            assert (sh.n_land, sh.n_glacier, sh.n_skipped) == (sd.n_land, sd.n_glacier, sd.n_skipped) and sh.n_skipped > 0
+            dh = d.to_host()
+            for k in _outs(h):
+                np.testing.assert_array_equal(h.a[k], dh.a[k], err_msg="%s step %d" % (k, it))
+        water = s["xland"] > 1.5
+        for k in ("hfx", "t2mvxy", "chb2xy", "bgapxy"):
+            np.testing.assert_array_equal(h.a[k][water], s.a[k][water], err_msg=k)
+        bad = s.copy()
+        bad["isltyp"][70, 300] = 25                               # a row that lives in a late chunk
+        bad["isltyp"][80, 5] = 25
+        with pytest.raises(NoahMPFatal) as e:
+            engine.noahmplsm(bad, 1, 2000, 180.0)
+        assert (e.value.code, e.value.i, e.value.j) == (1, 301, 71)
+        engine.set_option("trust_out_mirror", 1)                   # OUT arrays not re-uploaded after the first call
+        t1, t2 = s.copy(), s.copy()
+        engine.set_option("host_chunks", 0)
+        engine.noahmplsm(t1, 1, 2000, 180.0); engine.noahmplsm(t1, 2, 2000, 180.0)
+        engine.set_option("host_chunks", 6)
+        engine.noahmplsm(t2, 1, 2000, 180.0); engine.noahmplsm(t2, 2, 2000, 180.0)
+        for k in _outs(t1):
+            np.testing.assert_array_equal(t1.a[k], t2.a[k], err_msg=k)
+    finally:
+        for k, v in prev.items():
+            engine.set_option(k, v)

@@ -22,7 +22,25 @@ for ni, nj in ((8, 1), (1024, 64), (1024, 1024)):
     w = (time.perf_counter() - t) / n * 1e3
     print("tile %dx%d: wall %.3f ms/step, kernel %.3f ms, overhead %.3f ms" % (ni, nj, w, km / n, w - km / n))
 
-# host-memory path (what the Fortran shim pays): H2D of all arrays + kernel + D2H, 1M columns
+# host-memory path (what the Fortran shim pays): single-shot staging, then the row-chunk pipeline, pinned, OUT mirror trusted
+def host_path(label, **opts):
+    s = synth.config2(tb, ni=1024, nj=1024)
+    synth.first_step_fixups(s); synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+    prev = {k: eng.set_option(k, v) for k, v in opts.items()}
+    for it in range(3): eng.noahmplsm(s, it + 1, 2000, 180.0)
+    t = time.perf_counter(); n = 6
+    for it in range(n): st = eng.noahmplsm(s, it + 4, 2000, 180.0)
+    w = (time.perf_counter() - t) / n
+    for k, v in prev.items(): eng.set_option(k, v)
+    print("host-memory path 1024x1024 %-44s %.1f ms/step (kernel %.2f ms) -> %.3e col-steps/s PCIe-inclusive" % (label, w * 1e3, st.kernel_ms, s.ncol / w))
+host_path("single shot, pageable:", host_chunks=0)
+host_path("single shot, pinned:", host_chunks=0, pin_host_arrays=1)
+for nc in (2, 3, 4, 6):
+    host_path("%d row chunks, pinned:" % nc, host_chunks=nc, pin_host_arrays=1)
+for nc in (2, 3, 4):
+    host_path("%d row chunks, pinned, OUT mirror trusted:" % nc, host_chunks=nc, pin_host_arrays=1, trust_out_mirror=1)
+sys.exit(0)
+# (old single measurement): H2D of all arrays + kernel + D2H, 1M columns
 s = synth.config2(tb, ni=1024, nj=1024)
 synth.first_step_fixups(s); synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
 for it in range(2): eng.noahmplsm(s, it + 1, 2000, 180.0)
