@@ -36,6 +36,14 @@ WTABLE_INFO = {n: (k, lev, io) for n, k, lev, io, ln in WTABLE_FIELDS}
 WTABLE_ARRAYS = [n for n, k, lev, io, ln in WTABLE_FIELDS if k in ("pf", "pi")]
 
 
+FORCING_RECORD_FIELDS = ("t", "q", "u", "v", "p", "lw", "sw", "pcp", "fpar", "lai")
+
+
+class ForcingRecord(C.Structure):
+    """noahmp_forcing_record: one forcing file's planes as hrldas_input_read keeps them (netcdf_io:1228-1252)."""
+    _fields_ = [(n, C.c_void_p) for n in FORCING_RECORD_FIELDS]
+
+
 def _tbl_ctype(kind, shape):
     t = C.c_int32 if kind == "i" else C.c_float
     for d in shape:           # Fortran (a,b) -> C [b][a]: wrap fastest dim first
@@ -122,6 +130,8 @@ def load_library(path=None):
     lib.noahmp_hip_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Status)]
     lib.noahmp_hip_forcing_prep.argtypes = [C.POINTER(StepArgs), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p, C.POINTER(Status)]
+    lib.noahmp_hip_forcing_interpolate.argtypes = [C.POINTER(StepArgs), C.POINTER(ForcingRecord), C.POINTER(ForcingRecord),
+                                                   C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Status)]
     lib.noahmp_hip_gather_fields.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                              C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.noahmp_hip_scatter_fields.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
@@ -151,7 +161,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "noahmp_hip_abi_version", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
     "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
-    "noahmp_hip_step", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
+    "noahmp_hip_step", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
     "noahmp_hip_last_error", "noahmp_hip_finalize",
 ]
 

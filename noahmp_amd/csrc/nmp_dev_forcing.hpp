@@ -16,6 +16,7 @@ struct ForcingArgs {
   float sin_declin, cos_declin;    // of the solar declination (uniform over the grid, hdrv:839-854)
   float dt, dz8w;                  // model time step [s]; 2*ZLVL (hdrv:345-346)
   int scale_vegfra;                // VEGFRA arrives as a fraction and is stored in percent (hdrv:337)
+  int first_step;                  // itime == 1 of a cold start: first guesses of EAH, TAH, CH, CM (hdrv:374-384)
   int ni, nka, k1;                 // memory extents and the slot of level 1, as in the column kernel
 };
 
@@ -40,7 +41,48 @@ NMP_DEV void forcing_cell(const ForcingArgs& k, int ii, int jj) {
   const_cast<float*>(a.rainbl)[ij] = k.rain_rate[ij] * k.dt;                              // hdrv:344
   dz[l1] = k.dz8w; dz[l2] = k.dz8w;                                                       // hdrv:345
   if (k.scale_vegfra) const_cast<float*>(a.vegfra)[ij] = a.vegfra[ij] * 100.0f;           // hdrv:337
+  if (k.first_step) {                                                                     // hdrv:376-383
+    const_cast<float*>(a.eahxy)[ij] = (p[l1] * qv3d[l1]) / (0.622f + qv3d[l1]);
+    const_cast<float*>(a.tahxy)[ij] = t3d[l1];
+    const_cast<float*>(a.chxy)[ij] = 0.1f;
+    const_cast<float*>(a.cmxy)[ij] = 0.1f;
+  }
   const_cast<float*>(a.coszin)[ij] = forcing_cosz(a.xlatin[ij], k.lon[ij], k.hour_utc, k.sin_declin, k.cos_declin);
+}
+
+// Temporal interpolation between two forcing records (driver/module_hrldas_netcdf_io.F90:1369-1403, hrldas_input_interpolate;
+// has_b = 0: hrldas_input_copy, netcdf_io:1351-1366).  Targets are the arrays hrldas_input_read fills (hdrv:331-335).
+struct InterpArgs {
+  noahmp_step_args a;              // device pointers: t3d qv3d u_phy v_phy p8w3d (level 1 is written), glw, swdown, vegfra, xlaixy (the driver's LAI, hdrv:403)
+  noahmp_forcing_record ra, rb;
+  float* __restrict__ rain_rate;   // RAINBL_tmp
+  float fraction, one_minus;       // netcdf_io:1390 and (1.0-fraction), both float32
+  int has_b;
+  int ni, nka, k1;
+};
+
+NMP_DEV float interp2(float xa, float xb, float f, float g) { return (xa * f) + (xb * g); }   // netcdf_io:1391-1397
+
+NMP_DEV void interp_cell(const InterpArgs& k, int ii, int jj) {
+  const noahmp_step_args& a = k.a;
+  const size_t ij = (size_t)jj * k.ni + ii;
+  const size_t l1 = ((size_t)jj * k.nka + k.k1) * k.ni + ii;
+  float t = k.ra.t[ij], q = k.ra.q[ij], u = k.ra.u[ij], v = k.ra.v[ij], p = k.ra.p[ij], lw = k.ra.lw[ij], sw = k.ra.sw[ij];
+  if (k.has_b) {
+    t = interp2(t, k.rb.t[ij], k.fraction, k.one_minus);
+    q = interp2(q, k.rb.q[ij], k.fraction, k.one_minus);
+    u = interp2(u, k.rb.u[ij], k.fraction, k.one_minus);
+    v = interp2(v, k.rb.v[ij], k.fraction, k.one_minus);
+    p = interp2(p, k.rb.p[ij], k.fraction, k.one_minus);
+    lw = interp2(lw, k.rb.lw[ij], k.fraction, k.one_minus);
+    sw = interp2(sw, k.rb.sw[ij], k.fraction, k.one_minus);
+  }
+  const_cast<float*>(a.t3d)[l1] = t; const_cast<float*>(a.qv3d)[l1] = q;
+  const_cast<float*>(a.u_phy)[l1] = u; const_cast<float*>(a.v_phy)[l1] = v; const_cast<float*>(a.p8w3d)[l1] = p;
+  const_cast<float*>(a.glw)[ij] = lw; const_cast<float*>(a.swdown)[ij] = sw;
+  k.rain_rate[ij] = k.ra.pcp[ij];                                                    // netcdf_io:1398: not interpolated
+  if (k.ra.fpar) const_cast<float*>(a.vegfra)[ij] = k.ra.fpar[ij];                   // netcdf_io:1399
+  if (k.ra.lai) const_cast<float*>(a.xlaixy)[ij] = k.ra.lai[ij];                      // netcdf_io:1400
 }
 
 }  // namespace nmp

@@ -19,6 +19,12 @@ __global__ void __launch_bounds__(256) noahmp_forcing_kernel(const ForcingArgs k
   const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
   forcing_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
 }
+__global__ void __launch_bounds__(256) noahmp_interp_kernel(const InterpArgs k, int nti, int ntj) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)nti * ntj) return;
+  const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
+  interp_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
+}
 }  // namespace
 
 // ---- column permutation of fields (sorted device-resident layout) ---------------------------
@@ -154,7 +160,7 @@ float noahmp_hip_declination(int iday, int ihour, float* sin_declin, float* cos_
 }
 
 int noahmp_hip_forcing_prep(const noahmp_step_args* a, const float* lon2d, const float* rain_rate, int iday, int ihour,
-                            int iminute, int isecond, float zlvl, int scale_vegfra, float* julian_out, int mem,
+                            int iminute, int isecond, float zlvl, int flags, float* julian_out, int mem,
                             void* stream, noahmp_status* st) {
   if (st) memset(st, 0, sizeof(*st));
   int rc = nmp_host::ensure_init();
@@ -174,7 +180,8 @@ int noahmp_hip_forcing_prep(const noahmp_step_args* a, const float* lon2d, const
   k.hour_utc = (float)ihour + (float)iminute / 60.0f + (float)isecond / 3600.0f;   // hdrv:856, left to right
   k.dt = a->dt;
   k.dz8w = 2.0f * zlvl;
-  k.scale_vegfra = scale_vegfra;
+  k.scale_vegfra = (flags & NOAHMP_PREP_SCALE_VEGFRA) ? 1 : 0;
+  k.first_step = (flags & NOAHMP_PREP_FIRST_STEP) ? 1 : 0;
   k.ni = a->ime - a->ims + 1;
   k.nka = a->kme - a->kms + 1;
   k.k1 = 1 - a->kms;
@@ -184,6 +191,60 @@ int noahmp_hip_forcing_prep(const noahmp_step_args* a, const float* lon2d, const
   if (nti > 0 && ntj > 0) {
     const long n = (long)nti * ntj;
     hipLaunchKernelGGL(noahmp_forcing_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (st) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    st->kernel_ms = ms;
+    st->n_land = nti > 0 && ntj > 0 ? nti * ntj : 0;
+  }
+  return 0;
+}
+
+int noahmp_hip_forcing_interpolate(const noahmp_step_args* a, const noahmp_forcing_record* ra, const noahmp_forcing_record* rb,
+                                   int idts, int idts2, float* rain_rate_out, int mem, void* stream, noahmp_status* st) {
+  if (st) memset(st, 0, sizeof(*st));
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (mem != NOAHMP_MEM_DEVICE) {
+    g.last_error = "noahmp_hip_forcing_interpolate works on device-resident arrays only (a host caller keeps hrldas_input_read)";
+    return -104;
+  }
+  if (!ra || !ra->t || !ra->q || !ra->u || !ra->v || !ra->p || !ra->lw || !ra->sw || !ra->pcp || !rain_rate_out) {
+    g.last_error = "forcing_interpolate: record A needs t q u v p lw sw pcp, and rain_rate_out must be given";
+    return -105;
+  }
+  if (rb && (!rb->t || !rb->q || !rb->u || !rb->v || !rb->p || !rb->lw || !rb->sw)) {
+    g.last_error = "forcing_interpolate: record B needs t q u v p lw sw";
+    return -105;
+  }
+  if (rb && (idts2 <= 0 || idts < 0 || idts > idts2)) {
+    // hrldas_input_read stops unless lastread < target < nextread (netcdf_io:1286, 1297-1301); the end points are
+    // accepted here (fraction 1 and 0).
+    g.last_error = "forcing_interpolate: target date outside the bracketing records";
+    return -105;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  InterpArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a;
+  k.ra = *ra;
+  if (rb) k.rb = *rb;
+  k.has_b = rb ? 1 : 0;
+  k.rain_rate = rain_rate_out;
+  k.fraction = rb ? (float)(idts2 - idts) / (float)idts2 : 1.0f;      // netcdf_io:1390
+  k.one_minus = 1.0f - k.fraction;
+  k.ni = a->ime - a->ims + 1;
+  k.nka = a->kme - a->kms + 1;
+  k.k1 = 1 - a->kms;
+  const int nti = a->ite - a->its + 1, ntj = a->jte - a->jts + 1;
+  HIPCHK(hipEventRecord(g.ev0, s));
+  if (nti > 0 && ntj > 0) {
+    const long n = (long)nti * ntj;
+    hipLaunchKernelGGL(noahmp_interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g.ev1, s));

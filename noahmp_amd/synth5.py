@@ -1,0 +1,117 @@
+"""a global lat/lon grid (0.1 degree = 3600 x 1800 at full size) with a land mask, glaciers in the
+polar caps, 1 % urban, latitude-dependent climate, run from a cold start for 30 days x 24 steps with forcing records
+every 3 hours that are interpolated to the model step and a solar zenith angle from CALC_DECLIN.
+
+This is a WORKLOAD GENERATOR (seeded, synthetic): static fields come from numpy (Philox), the 3-hourly forcing records
+are evaluated on the device with float32 torch elementwise ops.  The product path it drives is
+noahmp_hip_init -> [noahmp_hip_forcing_interpolate -> noahmp_hip_forcing_prep -> noahmp_hip_step_async] x nsteps.
+"""
+import math
+
+import numpy as np
+
+from .state import ColumnStore, ModelConfig
+from .synth import CONUS_VEG, _base_store, _rng
+
+F = np.float32
+TROPIC_VEG = np.array([2, 7, 10, 13], dtype=np.int32)          # cropland, grassland, savanna, evergreen broadleaf
+BOREAL_VEG = np.array([7, 14, 15, 21], dtype=np.int32)         # grassland, evergreen needleleaf, mixed forest, wooded tundra
+POLAR_VEG = np.array([20, 22, 23], dtype=np.int32)             # herbaceous / mixed / bare-ground tundra
+DAY0 = 171                                                     # 20 June: days since 1 January (GETH_IDTS convention)
+RECORD_HOURS = 3
+
+
+def config5_raw(ni=3600, nj=1800, seed=5, cfg=None, water_frac=0.03, urban_frac=0.01, polar_glacier=0.30):
+    """The state handed to NOAHMP_INIT (nothing the cold start computes is set) + lon + the static forcing factors."""
+    cfg = cfg or ModelConfig(idveg=1)
+    r = _rng(seed)
+    s = _base_store(ni, nj, cfg)
+    a = s.a
+    shp = (nj, ni)
+    lat1 = (np.arange(nj, dtype=np.float64) + 0.5) * (180.0 / nj) - 90.0
+    lon1 = (np.arange(ni, dtype=np.float64) + 0.5) * (360.0 / ni) - 180.0
+    lat = np.broadcast_to(lat1[:, None], shp).astype(F)
+    lon = np.broadcast_to(lon1[None, :], shp).astype(F).copy()
+    a["xlatin"][...] = lat
+    alat = np.abs(lat)
+    u = r.random(size=shp)
+    pick = lambda pool: pool[r.integers(0, len(pool), size=shp)]
+    veg = np.where(alat < 23.0, pick(TROPIC_VEG), np.where(alat < 50.0, pick(CONUS_VEG),
+                                                            np.where(alat < 66.0, pick(BOREAL_VEG), pick(POLAR_VEG))))
+    a["ivgtyp"][...] = veg.astype(np.int32)
+    a["isltyp"][...] = r.integers(1, 13, size=shp).astype(np.int32)
+    a["ivgtyp"][u < urban_frac] = cfg.isurban
+    glacier = (alat > 66.0) & (r.random(size=shp) < polar_glacier)
+    a["ivgtyp"][glacier] = cfg.isice
+    a["isltyp"][glacier] = 16
+    water = (u >= urban_frac) & (u < urban_frac + water_frac)
+    a["ivgtyp"][water] = cfg.iswater
+    a["isltyp"][water] = 14
+    a["xland"][water] = 2.0
+    a["vegfra"][...] = r.uniform(20.0, 90.0, size=shp).astype(F)
+    a["vegmax"][...] = np.maximum(a["vegfra"], F(90.0))
+    sin2 = np.sin(np.deg2rad(lat.astype(np.float64))) ** 2
+    tbase = (300.0 - 50.0 * sin2 + np.clip(r.normal(0.0, 3.0, size=shp), -8.0, 8.0)).astype(F)
+    tbase[glacier] = np.minimum(tbase[glacier], F(262.0))
+    a["tmn"][...] = (tbase - F(1.0)).astype(F)
+    a["tsk"][...] = tbase
+    cold = (tbase < F(272.0)) | glacier
+    swe = r.uniform(5.0, 300.0, size=shp).astype(F)
+    rho = r.uniform(100.0, 350.0, size=shp).astype(F)
+    a["snow"][...] = np.where(cold, swe, F(0.0))
+    a["snowh"][...] = np.where(cold, swe / rho, F(0.0))
+    for k, (dt_, sm) in enumerate(zip((0.0, 0.3, 0.6, 0.9), (0.25, 0.27, 0.30, 0.31))):
+        a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
+        a["smois"][:, k, :] = F(sm) + r.uniform(-0.05, 0.05, size=shp).astype(F)
+    static = dict(
+        tbase=tbase,
+        cloud=r.uniform(0.4, 0.9, size=shp).astype(F),             # transmissivity of the column's sky
+        rh=r.uniform(0.4, 0.9, size=shp).astype(F),
+        psfc=(101325.0 * np.exp(-r.uniform(0.0, 2500.0, size=shp) / 8000.0)).astype(F),
+        uwind=r.uniform(1.0, 8.0, size=shp).astype(F),
+        vwind=r.uniform(-3.0, 3.0, size=shp).astype(F),
+        phase=r.integers(0, 16, size=shp).astype(F),               # when this column's rain events come
+    )
+    return s, lon, static
+
+
+def declination(iday, ihour):
+    """Float64 restatement of the uniform part of CALC_DECLIN (hdrv:826-854), used only to shape the synthetic records."""
+    julian = iday + ihour / 24.0
+    d2r = math.pi / 180.0
+    sx = (360.0 / 365.0) * ((julian - 80.0) if julian >= 80.0 else (julian + 285.0)) * d2r
+    return math.asin(math.sin(23.5 * d2r) * math.sin(sx))
+
+
+class Records:
+    """3-hourly forcing records on the device (torch float32), functions of position and record time only."""
+
+    def __init__(self, lat, lon, static):
+        import torch
+        self.t = torch
+        self.lat, self.lon, self.s = lat, lon, static
+        d2r = math.pi / 180.0
+        self.sinlat, self.coslat = torch.sin(lat * d2r), torch.cos(lat * d2r)
+
+    def at(self, rec_index):
+        """Record number `rec_index` (valid at hour RECORD_HOURS * rec_index since the start of the run)."""
+        t = self.t
+        hours = RECORD_HOURS * rec_index
+        iday, ihour = DAY0 + hours // 24, hours % 24
+        decl = declination(iday, ihour)
+        loc = t.remainder(ihour + self.lon / 15.0 + 24.0, 24.0)
+        cosz = t.clamp(self.sinlat * math.sin(decl) + self.coslat * math.cos(decl)
+                       * t.cos((loc - 12.0) * (15.0 * math.pi / 180.0)), min=0.0)
+        s = self.s
+        tair = s["tbase"] + 5.0 * t.cos((loc - 15.0) * (2.0 * math.pi / 24.0)) * s["cloud"]
+        es = 611.2 * t.exp(17.67 * (tair - 273.15) / (tair - 29.65))
+        q = s["rh"] * 0.622 * es / (s["psfc"] - es)
+        lw = (0.65 + 0.3 * (1.0 - s["cloud"])) * 5.67e-8 * tair ** 4
+        raining = t.remainder(s["phase"] + float(rec_index), 16.0) < 1.0
+        return dict(t=tair, q=q, u=s["uwind"], v=s["vwind"], p=s["psfc"], lw=lw, sw=1000.0 * cosz * s["cloud"],
+                    pcp=t.where(raining, t.full_like(tair, 5.0e-4), t.zeros_like(tair)), fpar=None, lai=None)
+
+
+def step_time(n):
+    """(iday, ihour) of 0-based model step n (one-hour steps from DAY0 00 UTC)."""
+    return DAY0 + n // 24, n % 24

@@ -141,13 +141,27 @@ extern "C" int emul_groundwater_init(const noahmp_wtable_args* a, int iswater, n
 // ---- forcing preparation (noahmp_forcing.hip's kernel as a host loop; the uniform declination comes from the caller)
 #include "nmp_dev_forcing.hpp"
 extern "C" int emul_forcing_prep(const noahmp_step_args* a, const float* lon2d, const float* rain_rate, float hour_utc,
-                                 float sin_declin, float cos_declin, float zlvl, int scale_vegfra) {
+                                 float sin_declin, float cos_declin, float zlvl, int flags) {
   ForcingArgs k;
   memset(&k, 0, sizeof(k));
   k.a = *a; k.lon = lon2d; k.rain_rate = rain_rate; k.hour_utc = hour_utc; k.sin_declin = sin_declin; k.cos_declin = cos_declin;
-  k.dt = a->dt; k.dz8w = 2.0f * zlvl; k.scale_vegfra = scale_vegfra;
+  k.dt = a->dt; k.dz8w = 2.0f * zlvl; k.scale_vegfra = flags & 1; k.first_step = (flags & 2) ? 1 : 0;
   k.ni = a->ime - a->ims + 1; k.nka = a->kme - a->kms + 1; k.k1 = 1 - a->kms;
   for (int j = a->jts; j <= a->jte; j++)
     for (int i = a->its; i <= a->ite; i++) forcing_cell(k, i - a->ims, j - a->jms);
+  return 0;
+}
+
+extern "C" int emul_forcing_interpolate(const noahmp_step_args* a, const noahmp_forcing_record* ra, const noahmp_forcing_record* rb,
+                                        int idts, int idts2, float* rain_rate_out) {
+  InterpArgs k;
+  memset(&k, 0, sizeof(k));
+  k.a = *a; k.ra = *ra; if (rb) k.rb = *rb;
+  k.has_b = rb ? 1 : 0; k.rain_rate = rain_rate_out;
+  k.fraction = rb ? (float)(idts2 - idts) / (float)idts2 : 1.0f;
+  k.one_minus = 1.0f - k.fraction;
+  k.ni = a->ime - a->ims + 1; k.nka = a->kme - a->kms + 1; k.k1 = 1 - a->kms;
+  for (int j = a->jts; j <= a->jte; j++)
+    for (int i = a->its; i <= a->ite; i++) interp_cell(k, i - a->ims, j - a->jms);
   return 0;
 }

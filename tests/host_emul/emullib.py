@@ -3,7 +3,7 @@ import ctypes as C
 import os
 import subprocess
 
-from noahmp_amd.abi import StepArgs, Tables, Status, WtableArgs
+from noahmp_amd.abi import StepArgs, Tables, Status, WtableArgs, ForcingRecord, FORCING_RECORD_FIELDS
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(_HERE))
@@ -29,6 +29,8 @@ class EmulLib:
         self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
         self.lib.emul_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
         self.lib.emul_groundwater_init.argtypes = [C.POINTER(WtableArgs), C.c_int, C.POINTER(Status)]
+        self.lib.emul_forcing_interpolate.argtypes = [C.POINTER(StepArgs), C.POINTER(ForcingRecord), C.POINTER(ForcingRecord),
+                                                      C.c_int, C.c_int, C.c_void_p]
         self.lib.emul_forcing_prep.argtypes = [C.POINTER(StepArgs), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                                C.c_float, C.c_int]
         self.lib.emul_wtable_mmf.argtypes = [C.POINTER(WtableArgs), C.POINTER(Status)]
@@ -66,7 +68,20 @@ class EmulLib:
         assert rc == 0, rc
         return st
 
-    def forcing_prep(self, store, lon, rain_rate, hour_utc, sin_declin, cos_declin, scale_vegfra=False):
+    def forcing_interpolate(self, store, rec_a, rec_b, idts, idts2, rain_rate):
+        a = store.step_args(1, 2000, 1.0)
+
+        def rec(d):
+            r = ForcingRecord()
+            for n in FORCING_RECORD_FIELDS:
+                if d.get(n) is not None:
+                    setattr(r, n, d[n].ctypes.data)
+            return r
+        ra, rb = rec(rec_a), (rec(rec_b) if rec_b is not None else None)
+        return self.lib.emul_forcing_interpolate(C.byref(a), C.byref(ra), C.byref(rb) if rb is not None else None,
+                                                 idts, idts2, rain_rate.ctypes.data)
+
+    def forcing_prep(self, store, lon, rain_rate, hour_utc, sin_declin, cos_declin, scale_vegfra=False, first_step=False):
         a = store.step_args(1, 2000, 1.0)
         return self.lib.emul_forcing_prep(C.byref(a), lon.ctypes.data, rain_rate.ctypes.data, hour_utc, sin_declin,
-                                          cos_declin, store.cfg.zlvl, 1 if scale_vegfra else 0)
+                                          cos_declin, store.cfg.zlvl, (1 if scale_vegfra else 0) | (2 if first_step else 0))

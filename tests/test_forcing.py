@@ -10,7 +10,7 @@ import pytest
 from noahmp_amd import abi
 from noahmp_amd.state import ColumnStore, ModelConfig
 
-OUT = ["t3d", "qv3d", "u_phy", "v_phy", "p8w3d", "rainbl", "vegfra", "dz8w", "coszin"]
+OUT = ["t3d", "qv3d", "u_phy", "v_phy", "p8w3d", "rainbl", "vegfra", "dz8w", "coszin", "eahxy", "tahxy", "chxy", "cmxy"]
 
 
 def case(ni=96, nj=40, seed=3):
@@ -23,9 +23,8 @@ def case(ni=96, nj=40, seed=3):
         s.a[k][:, 0, :] = r.uniform(lo, hi, size=(nj, ni)).astype(np.float32)
         s.a[k][:, 1, :] = -777.0
     s["vegfra"] = r.uniform(0.0, 1.0, size=(nj, ni)).astype(np.float32)
-    s["coszin"] = -777.0
-    s["dz8w"] = -777.0
-    s["rainbl"] = -777.0
+    for k in ("coszin", "dz8w", "rainbl", "eahxy", "tahxy", "chxy", "cmxy"):
+        s[k] = -777.0
     return s, lon, rain
 
 
@@ -49,6 +48,17 @@ def test_oracle_against_float64_formula(port, when):
         np.testing.assert_array_equal(s.a[k][:, 1, :], s.a[k][:, 0, :])
     np.testing.assert_array_equal(s["rainbl"], rain * np.float32(s.cfg.dt))
     assert (s["dz8w"] == np.float32(2.0 * s.cfg.zlvl)).all() and s["vegfra"].max() > 1.0
+    assert (s["eahxy"] == -777.0).all() and (s["chxy"] == -777.0).all()          # only with first_step
+
+
+def test_first_step_guesses(port):
+    from noahmp_amd import synth
+    s, lon, rain = case()
+    want = s.copy()
+    port.forcing_prep(s, lon, rain, 171, 0, first_step=True)
+    synth.first_step_fixups(want)                                                # numpy float32 statement of hdrv:374-384
+    for k in ("eahxy", "tahxy", "chxy", "cmxy"):
+        np.testing.assert_array_equal(s[k], want[k], err_msg=k)
 
 
 @pytest.mark.parametrize("when", TIMES)
@@ -59,11 +69,12 @@ def test_device_source_on_host_matches_oracle(port, when):
     iday, h, m, sec = when
     s, lon, rain = case(seed=5)
     a, b = s.copy(), s.copy()
-    port.forcing_prep(a, lon, rain, iday, h, m, sec, scale_vegfra=True)
+    first = iday % 2 == 1
+    port.forcing_prep(a, lon, rain, iday, h, m, sec, scale_vegfra=True, first_step=first)
     sd, cd = C.c_float(0), C.c_float(0)
     jul = lib.noahmp_hip_declination(iday, h, C.byref(sd), C.byref(cd))
     hour = np.float32(np.float32(np.float32(h) + np.float32(m) / np.float32(60.0)) + np.float32(sec) / np.float32(3600.0))
-    em.forcing_prep(b, lon, rain, float(hour), sd.value, cd.value, scale_vegfra=True)
+    em.forcing_prep(b, lon, rain, float(hour), sd.value, cd.value, scale_vegfra=True, first_step=first)
     assert jul == np.float32(iday) + np.float32(h) / np.float32(24.0)
     for k in OUT:
         np.testing.assert_array_equal(a.a[k], b.a[k], err_msg=k)
@@ -76,9 +87,11 @@ def test_gpu_forcing_prep_bit_identical(engine, port, when):
     iday, h, m, sec = when
     s, lon, rain = case(ni=512, nj=64, seed=7)
     a = s.copy()
-    ja = port.forcing_prep(a, lon, rain, iday, h, m, sec, scale_vegfra=True)
+    first = iday % 2 == 1
+    ja = port.forcing_prep(a, lon, rain, iday, h, m, sec, scale_vegfra=True, first_step=first)
     d = s.to_device("cuda:0")
-    jd = engine.forcing_prep(d, torch.from_numpy(lon).cuda(), torch.from_numpy(rain).cuda(), iday, h, m, sec, scale_vegfra=True)
+    jd = engine.forcing_prep(d, torch.from_numpy(lon).cuda(), torch.from_numpy(rain).cuda(), iday, h, m, sec, scale_vegfra=True,
+                             first_step=first)
     assert ja == jd
     hst = d.to_host()
     for k in OUT:
@@ -89,3 +102,102 @@ def test_gpu_forcing_prep_bit_identical(engine, port, when):
                                                 abi.MEM_HOST, None, None)
         assert rc == -104
         raise RuntimeError("host arrays are refused")
+
+
+# ---- temporal interpolation between two forcing records (hrldas_input_interpolate, netcdf_io:1369-1403)
+IOUT = ["t3d", "qv3d", "u_phy", "v_phy", "p8w3d", "glw", "swdown", "vegfra", "xlaixy"]
+BRACKETS = [(0, 10800), (1800, 10800), (3600, 10800), (7200, 10800), (10800, 10800), (1, 3), (3599, 3600)]
+
+
+def records(ni, nj, seed, with_veg=True):
+    r = np.random.default_rng(seed)
+    rng = dict(t=(250, 310), q=(1e-4, 2e-2), u=(-10, 10), v=(-10, 10), p=(6e4, 1.02e5), lw=(150, 450), sw=(0, 1000),
+               pcp=(0, 2e-3), fpar=(0, 1), lai=(0, 6))
+    out = []
+    for _ in range(2):
+        d = {k: r.uniform(lo, hi, size=(nj, ni)).astype(np.float32) for k, (lo, hi) in rng.items()}
+        if not with_veg:
+            d["fpar"] = d["lai"] = None
+        out.append(d)
+    return out
+
+
+def icase(ni, nj, seed):
+    s, _, _ = case(ni, nj, seed)
+    for k in ("glw", "swdown", "xlaixy"):
+        s[k] = -777.0
+    return s
+
+
+@pytest.mark.parametrize("idts,idts2", BRACKETS)
+def test_interpolate_oracle_properties(port, idts, idts2):
+    ni, nj = 96, 40
+    ra, rb = records(ni, nj, 11)
+    s = icase(ni, nj, 3)
+    rain = np.full((nj, ni), -1.0, np.float32)
+    port.forcing_interpolate(s, ra, rb, idts, idts2, rain)
+    f = np.float32(idts2 - idts) / np.float32(idts2)
+    g = np.float32(1.0) - f
+    for k3, k in (("t3d", "t"), ("qv3d", "q"), ("u_phy", "u"), ("v_phy", "v"), ("p8w3d", "p")):
+        np.testing.assert_array_equal(s.a[k3][:, 0, :], ra[k] * f + rb[k] * g, err_msg=k)     # numpy float32, no FMA
+        assert (s.a[k3][:, 1, :] == -777.0).all()                                             # level 2 is forcing_prep's
+    np.testing.assert_array_equal(s["glw"], ra["lw"] * f + rb["lw"] * g)
+    np.testing.assert_array_equal(s["swdown"], ra["sw"] * f + rb["sw"] * g)
+    np.testing.assert_array_equal(rain, ra["pcp"])                                            # not interpolated
+    np.testing.assert_array_equal(s["vegfra"], ra["fpar"])
+    np.testing.assert_array_equal(s["xlaixy"], ra["lai"])
+    if idts == 0:
+        np.testing.assert_array_equal(s.a["t3d"][:, 0, :], ra["t"])
+    if idts == idts2:
+        np.testing.assert_array_equal(s.a["t3d"][:, 0, :], rb["t"])
+
+
+def test_interpolate_copy_and_missing_vegetation(port):
+    ni, nj = 64, 16
+    ra, _ = records(ni, nj, 12, with_veg=False)
+    s = icase(ni, nj, 4)
+    veg0, lai0 = s["vegfra"].copy(), s["xlaixy"].copy()
+    rain = np.zeros((nj, ni), np.float32)
+    port.forcing_interpolate(s, ra, None, 0, 0, rain)                  # hrldas_input_copy
+    np.testing.assert_array_equal(s.a["qv3d"][:, 0, :], ra["q"])
+    np.testing.assert_array_equal(s["swdown"], ra["sw"])
+    np.testing.assert_array_equal(s["vegfra"], veg0)                   # variable absent: carried over
+    np.testing.assert_array_equal(s["xlaixy"], lai0)
+
+
+@pytest.mark.parametrize("idts,idts2", BRACKETS[1::2])
+def test_interpolate_device_source_on_host_matches_oracle(port, idts, idts2):
+    from host_emul.emullib import EmulLib
+    em = EmulLib()
+    ni, nj = 96, 40
+    ra, rb = records(ni, nj, 13)
+    a, b = icase(ni, nj, 5), icase(ni, nj, 5)
+    raina, rainb = np.zeros((nj, ni), np.float32), np.zeros((nj, ni), np.float32)
+    port.forcing_interpolate(a, ra, rb, idts, idts2, raina)
+    em.forcing_interpolate(b, ra, rb, idts, idts2, rainb)
+    for k in IOUT:
+        np.testing.assert_array_equal(a.a[k], b.a[k], err_msg=k)
+    np.testing.assert_array_equal(raina, rainb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idts,idts2", [(1800, 10800), (3599, 3600), (None, None)])
+def test_gpu_forcing_interpolate_bit_identical(engine, port, idts, idts2):
+    import torch
+    ni, nj = 512, 64
+    ra, rb = records(ni, nj, 14)
+    if idts is None:
+        rb, idts, idts2 = None, 0, 0
+    a, s = icase(ni, nj, 6), icase(ni, nj, 6)
+    rain = np.zeros((nj, ni), np.float32)
+    port.forcing_interpolate(a, ra, rb, idts, idts2, rain)
+    d = s.to_device("cuda:0")
+    dev = lambda r: None if r is None else {k: torch.from_numpy(v).cuda() for k, v in r.items()}
+    raind = torch.zeros((nj, ni), dtype=torch.float32, device="cuda:0")
+    engine.forcing_interpolate(d, dev(ra), dev(rb), idts, idts2, raind)
+    hst = d.to_host()
+    for k in IOUT:
+        np.testing.assert_array_equal(a.a[k], hst.a[k], err_msg=k)
+    np.testing.assert_array_equal(rain, raind.cpu().numpy())
+    with pytest.raises(RuntimeError):                                   # target outside the bracket is refused
+        engine.forcing_interpolate(d, dev(ra), dev(ra), 7200, 3600, raind)

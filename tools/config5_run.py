@@ -1,0 +1,147 @@
+"""SURVEY 8d config 5 on the GPU, end to end on device-resident arrays: cold start (noahmp_hip_init), then per hourly
+step forcing interpolation between 3-hourly records (noahmp_hip_forcing_interpolate), forcing preparation with the
+solar zenith angle (noahmp_hip_forcing_prep) and the column step (noahmp_hip_step_async) -- nothing returns to the host
+between the cold start and the end of the run.
+
+Parity at full size: columns are independent, so a random SAMPLE of columns is advanced by the oracle (C restatement)
+through the same chain from the same raw state and the same forcing records, and compared bit for bit with the same
+columns of the full-size device run at a few checkpoints and at the end.
+
+usage: config5_run.py [ni nj [nsteps [nsample]]]      default 3600 1800 720 4096
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from noahmp_amd import synth5  # noqa: E402
+from noahmp_amd.driver import Engine  # noqa: E402
+from noahmp_amd.state import ColumnStore  # noqa: E402
+from noahmp_amd.tables import load_tables  # noqa: E402
+from oracle.portlib import PortLib  # noqa: E402
+from tools.compare import exact_check  # noqa: E402
+
+
+def extract(store, flat, n=None):
+    """Columns `flat` (linear j*ni+i indices) of a host or device store as an n x 1 host ColumnStore."""
+    flat = np.asarray(flat, dtype=np.int64)
+    out = ColumnStore(len(flat), 1, store.cfg)
+    for k, v in store.a.items():
+        if k == "dzs" or k not in out.a:
+            continue
+        if not isinstance(v, np.ndarray):
+            idx = torch.from_numpy(flat).to(v.device)
+            if v.dim() == 3:
+                col = v.permute(0, 2, 1).reshape(-1, v.shape[1])[idx].cpu().numpy()
+            else:
+                col = v.reshape(-1)[idx].cpu().numpy()
+        elif v.ndim == 3:
+            col = v.transpose(0, 2, 1).reshape(-1, v.shape[1])[flat]
+        else:
+            col = v.reshape(-1)[flat]
+        out.a[k][...] = col.T[None] if col.ndim == 2 else col[None]
+    return out
+
+
+def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240)):
+    T, tb = load_tables("usgs")
+    port = PortLib(autobuild=not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libnoahmp_oracle.so")))
+    port.set_tables(T)
+    eng = Engine(T, device=0)
+    raw, lon, static = synth5.config5_raw(ni, nj, seed=seed)
+    dev = torch.device("cuda", 0)
+    d = raw.to_device("cuda:0")
+    eng.noahmp_init(d, fndsnowh=True)                                  # cold start on the device
+    perm = eng.sort_store(d)                                           # (class, vegetation type, TSK bin) order
+    pl = perm.long()
+    srt = lambda x: torch.from_numpy(x).to(dev).reshape(-1)[pl].reshape(nj, ni).contiguous()
+    lon_d = srt(lon)
+    recs = synth5.Records(d.a["xlatin"], lon_d, {k: srt(v) for k, v in static.items()})
+    rain_d = torch.zeros((nj, ni), dtype=torch.float32, device=dev)
+    n_land = int(((d.a["xland"] < 1.5) & (d.a["xice"] < raw.cfg.xice_thres)).sum().item())        # soil + glacier columns
+
+    # ---- the sample: sorted positions, their tile columns, their raw state and forcing records
+    r = np.random.Generator(np.random.Philox(seed + 100))
+    nsample = min(nsample, ni * nj)
+    pos = np.sort(r.choice(ni * nj, size=nsample, replace=False))
+    tile_cols = perm.cpu().numpy().astype(np.int64)[pos]
+    osamp = extract(raw, tile_cols)
+    lon_s = lon.reshape(-1)[tile_cols][None].copy()
+    pos_t = torch.from_numpy(pos).to(dev)
+    nrec = (nsteps + synth5.RECORD_HOURS - 1) // synth5.RECORD_HOURS + 1
+    rec_s = []
+    for i in range(nrec):
+        rec_s.append({k: (v.reshape(-1)[pos_t].cpu().numpy()[None].copy() if v is not None else None)
+                      for k, v in recs.at(i).items()})
+    checkpoints = sorted(set([c for c in checkpoints if c < nsteps] + [nsteps]))
+
+    # ---- device run: record evaluation (torch) and the engine's kernels share one stream, so they are ordered
+    snaps = {}
+    ts = torch.cuda.Stream(device=dev)
+    sp = ts.cuda_stream
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    rec_a = rec_b = None
+    with torch.cuda.stream(ts):
+        for n in range(nsteps):
+            ri, k = divmod(n, synth5.RECORD_HOURS)
+            if k == 0:
+                rec_a = rec_b if rec_b is not None else recs.at(ri)
+                rec_b = recs.at(ri + 1)
+            eng.forcing_interpolate(d, rec_a, rec_b if k else None, 3600 * k, 3600 * synth5.RECORD_HOURS, rain_d, stream=sp)
+            iday, ihour = synth5.step_time(n)
+            jul = eng.forcing_prep(d, lon_d, rain_d, iday, ihour, first_step=(n == 0), stream=sp)
+            eng.noahmplsm_async(d.step_args(n + 1, 2000, jul), stream=sp)
+            if n + 1 in checkpoints or (n + 1) % 24 == 0:
+                st, _ = eng.sync()
+                kernel_ms += st.kernel_ms
+                if n + 1 in checkpoints:
+                    t_hold = time.perf_counter()
+                    snaps[n + 1] = extract(d, pos)
+                    ts.synchronize()
+                    t0 += time.perf_counter() - t_hold                   # snapshots are not part of the run
+        ts.synchronize()
+    wall = time.perf_counter() - t0
+
+    # ---- oracle on the sample
+    t1 = time.perf_counter()
+    port.noahmp_init(osamp, fndsnowh=True)
+    rain_s = np.zeros((1, nsample), np.float32)
+    report, ok_all = [], True
+    for n in range(nsteps):
+        ri, k = divmod(n, synth5.RECORD_HOURS)
+        port.forcing_interpolate(osamp, rec_s[ri], rec_s[ri + 1] if k else None, 3600 * k, 3600 * synth5.RECORD_HOURS, rain_s)
+        iday, ihour = synth5.step_time(n)
+        jul = port.forcing_prep(osamp, lon_s, rain_s, iday, ihour, first_step=(n == 0))
+        so = port.noahmplsm(osamp, n + 1, 2000, jul)
+        assert so.code == 0, "oracle: fatal code %d" % so.code
+        if n + 1 in snaps:
+            ok, lines = exact_check(osamp, snaps[n + 1])
+            ok_all &= ok
+            report.append((n + 1, ok, lines[:4]))
+    t_or = time.perf_counter() - t1
+    isn = sorted(set(np.unique(osamp.a["isnowxy"]).tolist()))
+    res = dict(grid=[ni, nj], steps=nsteps, land_columns=n_land, wall_s=round(wall, 3), ms_per_step=round(wall / nsteps * 1e3, 3),
+               column_steps_per_s=n_land * nsteps / wall, column_kernel_ms_per_step=round(kernel_ms / nsteps, 3),
+               sample=nsample, sample_bit_identical=bool(ok_all), checkpoints=[c for c, _, _ in report],
+               isnow_states_in_sample=isn, oracle_sample_s=round(t_or, 1),
+               glacier_in_sample=int((osamp.a["ivgtyp"] == raw.cfg.isice).sum()),
+               water_in_sample=int((osamp.a["xland"] > 1.5).sum()))
+    if verbose:
+        for c, ok, lines in report:
+            print("checkpoint step %d: %s" % (c, "BIT-IDENTICAL" if ok else "DIFFERS\n  " + "\n  ".join(lines)))
+        print(json.dumps(res))
+    return res
+
+
+if __name__ == "__main__":
+    a = [int(x) for x in sys.argv[1:]]
+    res = run(*(a[:2] if len(a) >= 2 else (3600, 1800)), nsteps=a[2] if len(a) > 2 else 720,
+              nsample=a[3] if len(a) > 3 else 4096)
+    sys.exit(0 if res["sample_bit_identical"] else 1)
