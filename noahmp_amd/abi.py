@@ -134,6 +134,8 @@ def load_library(path=None):
                                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Status)]
     lib.noahmp_hip_gather_fields.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                              C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.noahmp_hip_output_fields.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                             C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
     lib.noahmp_hip_scatter_fields.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.noahmp_hip_declination.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -161,7 +163,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "noahmp_hip_abi_version", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
     "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
-    "noahmp_hip_step", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
+    "noahmp_hip_step", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_output_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_set_option", "noahmp_hip_error_string",
     "noahmp_hip_last_error", "noahmp_hip_finalize",
 ]
 

@@ -37,14 +37,17 @@ struct GatherArgs {
   void* dst[kMaxGather];
   const void* src[kMaxGather];
   int nlev[kMaxGather];
-  const int* perm;
+  const int* perm;                  // NULL = identity
+  const int* vegtyp;                // output packing only: IVGTYP in SOURCE order, or NULL
+  int iswater;
+  unsigned mask;                    // bit f: field f gets -1.E33 on water points (put_var_2d / put_var_3d)
   int n, ni, nj;
 };
 __global__ void __launch_bounds__(256) noahmp_gather_kernel(const GatherArgs k) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long ncol = (long)k.ni * k.nj;
   if (p >= ncol) return;
-  const long gsrc = k.perm[p];
+  const long gsrc = k.perm ? k.perm[p] : p;
   const int pj = (int)(p / k.ni), pi = (int)(p - (long)pj * k.ni);
   const int gj = (int)(gsrc / k.ni), gi = (int)(gsrc - (long)gj * k.ni);
   for (int f = 0; f < k.n; f++) {
@@ -52,6 +55,15 @@ __global__ void __launch_bounds__(256) noahmp_gather_kernel(const GatherArgs k) 
     const uint32_t* s = (const uint32_t*)k.src[f];
     uint32_t* d = (uint32_t*)k.dst[f];
     for (int l = 0; l < nk; l++) d[((size_t)pj * nk + l) * k.ni + pi] = s[((size_t)gj * nk + l) * k.ni + gi];
+  }
+  if (k.vegtyp && k.mask && k.vegtyp[gsrc] == k.iswater) {
+    const uint32_t missing = __float_as_uint(-1.E33f);              // netcdf_io:1971, 2041
+    for (int f = 0; f < k.n; f++) {
+      if (!((k.mask >> f) & 1u)) continue;
+      const int nk = k.nlev[f];
+      uint32_t* d = (uint32_t*)k.dst[f];
+      for (int l = 0; l < nk; l++) d[((size_t)pj * nk + l) * k.ni + pi] = missing;
+    }
   }
 }
 }  // namespace
@@ -136,6 +148,29 @@ int noahmp_hip_gather_fields(int n, void* const* dst, const void* const* src, co
   memset(&k, 0, sizeof(k));
   for (int f = 0; f < n; f++) { k.dst[f] = dst[f]; k.src[f] = src[f]; k.nlev[f] = nlev[f]; }
   k.perm = perm; k.n = n; k.ni = ni; k.nj = nj;
+  const long ncol = (long)ni * nj;
+  if (ncol > 0 && n > 0)
+    hipLaunchKernelGGL(noahmp_gather_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, s, k);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Output / restart packing for a device-resident run: what put_var_2d / put_var_3d do to an array before nf90_put_var
+// (driver/module_hrldas_netcdf_io.F90:1971-1975, 2039-2042: water points become -1.E33 -- in output files for every real
+// field, in restart files for the layered fields only, netcdf_io:2347 restart_flag) fused with the return from the sorted
+// layout to tile order.  dst column p <- src column perm[p]; ivgtyp_src is in SOURCE order.
+int noahmp_hip_output_fields(int n, void* const* dst, const void* const* src, const int* nlev, const int32_t* perm,
+                             const int32_t* ivgtyp_src, int iswater, uint32_t mask_fields, int ni, int nj, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (n < 0 || n > kMaxGather) { g.last_error = "noahmp_hip_output_fields: at most 32 fields per call"; return -107; }
+  if (mask_fields && !ivgtyp_src) { g.last_error = "noahmp_hip_output_fields: masking needs IVGTYP"; return -105; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  GatherArgs k;
+  memset(&k, 0, sizeof(k));
+  for (int f = 0; f < n; f++) { k.dst[f] = dst[f]; k.src[f] = src[f]; k.nlev[f] = nlev[f]; }
+  k.perm = perm; k.vegtyp = ivgtyp_src; k.iswater = iswater; k.mask = mask_fields;
+  k.n = n; k.ni = ni; k.nj = nj;
   const long ncol = (long)ni * nj;
   if (ncol > 0 && n > 0)
     hipLaunchKernelGGL(noahmp_gather_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, s, k);

@@ -48,7 +48,7 @@ def extract(store, flat, n=None):
     return out
 
 
-def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240)):
+def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240), restart_path=None):
     T, tb = load_tables("usgs")
     port = PortLib(autobuild=not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libnoahmp_oracle.so")))
     port.set_tables(T)
@@ -108,6 +108,16 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
                     t0 += time.perf_counter() - t_hold                   # snapshots are not part of the run
         ts.synchronize()
     wall = time.perf_counter() - t0
+    restart_s = None
+    if restart_path:                                                   # checkpoint of the sorted device state (8f-4)
+        from noahmp_amd import restart
+        t2 = time.perf_counter()
+        names = [f for _, f, _ in restart.RESTART_VARS]
+        vals = restart.fetch(eng, d, names, perm=perm, mask=[f for _, f, lay in restart.RESTART_VARS if lay])
+        fetch_s = time.perf_counter() - t2
+        restart.write_restart(restart_path, d, "2000-07-20_00:00:00", "2000-06-20_00:00:00", engine=eng, perm=perm)
+        restart_s = dict(fetch_s=round(fetch_s, 3), fetch_and_write_s=round(time.perf_counter() - t2 - fetch_s, 3),
+                         bytes=os.path.getsize(restart_path), host_bytes=sum(v.nbytes for v in vals.values()))
 
     # ---- oracle on the sample
     t1 = time.perf_counter()
@@ -132,7 +142,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
                sample=nsample, sample_bit_identical=bool(ok_all), checkpoints=[c for c, _, _ in report],
                isnow_states_in_sample=isn, oracle_sample_s=round(t_or, 1),
                glacier_in_sample=int((osamp.a["ivgtyp"] == raw.cfg.isice).sum()),
-               water_in_sample=int((osamp.a["xland"] > 1.5).sum()))
+               water_in_sample=int((osamp.a["xland"] > 1.5).sum()), restart=restart_s)
     if verbose:
         for c, ok, lines in report:
             print("checkpoint step %d: %s" % (c, "BIT-IDENTICAL" if ok else "DIFFERS\n  " + "\n  ".join(lines)))
@@ -143,5 +153,5 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:]]
     res = run(*(a[:2] if len(a) >= 2 else (3600, 1800)), nsteps=a[2] if len(a) > 2 else 720,
-              nsample=a[3] if len(a) > 3 else 4096)
+              nsample=a[3] if len(a) > 3 else 4096, restart_path=os.environ.get("NMP_RESTART_PATH"))
     sys.exit(0 if res["sample_bit_identical"] else 1)
