@@ -222,15 +222,15 @@ int noahmp_hip_forcing_prep(const noahmp_step_args* a, const float* lon2d, const
   k.k1 = 1 - a->kms;
   if (k.nka < 2) { g.last_error = "forcing_prep needs two atmospheric levels (kms:kme)"; return -105; }
   const int nti = a->ite - a->its + 1, ntj = a->jte - a->jts + 1;
-  HIPCHK(hipEventRecord(g.ev0, s));
+  if (st) HIPCHK(hipEventRecord(g.ev0, s));
   if (nti > 0 && ntj > 0) {
     const long n = (long)nti * ntj;
     hipLaunchKernelGGL(noahmp_forcing_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.ev1, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (st) {
+  if (st) {                                   // st == NULL: enqueue only (ordered on `stream`), no host wait
+    HIPCHK(hipEventRecord(g.ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     hipEventElapsedTime(&ms, g.ev0, g.ev1);
     st->kernel_ms = ms;
@@ -276,15 +276,15 @@ int noahmp_hip_forcing_interpolate(const noahmp_step_args* a, const noahmp_forci
   k.nka = a->kme - a->kms + 1;
   k.k1 = 1 - a->kms;
   const int nti = a->ite - a->its + 1, ntj = a->jte - a->jts + 1;
-  HIPCHK(hipEventRecord(g.ev0, s));
+  if (st) HIPCHK(hipEventRecord(g.ev0, s));
   if (nti > 0 && ntj > 0) {
     const long n = (long)nti * ntj;
     hipLaunchKernelGGL(noahmp_interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.ev1, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (st) {
+  if (st) {                                   // st == NULL: enqueue only (ordered on `stream`), no host wait
+    HIPCHK(hipEventRecord(g.ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
     float ms = 0.f;
     hipEventElapsedTime(&ms, g.ev0, g.ev1);
     st->kernel_ms = ms;

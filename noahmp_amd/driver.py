@@ -84,7 +84,7 @@ class Engine:
         return st
 
     def forcing_prep(self, store, lon, rain_rate, iday, ihour, iminute=0, isecond=0, scale_vegfra=False, stream=None,
-                     first_step=False):
+                     first_step=False, wait=True):
         """Device-resident forcing preparation (reference hdrv:336-354 + CALC_DECLIN): `lon` and `rain_rate` are
         device tensors shaped like a 2-D field; level 1 of t3d/qv3d/u_phy/v_phy/p8w3d holds the new forcing.
         first_step adds the driver's itime = 1 guesses of EAH / TAH / CH / CM (hdrv:374-384).  Returns JULIAN."""
@@ -94,13 +94,13 @@ class Engine:
         st = abi.Status()
         rc = self.lib.noahmp_hip_forcing_prep(C.byref(a), lon.data_ptr(), rain_rate.data_ptr(), iday, ihour, iminute,
                                               isecond, store.cfg.zlvl, (1 if scale_vegfra else 0) | (2 if first_step else 0), C.byref(jul),
-                                              abi.MEM_DEVICE, stream, C.byref(st))
+                                              abi.MEM_DEVICE, stream, C.byref(st) if wait else None)
         self.last_status = st
         if rc:
             raise RuntimeError("noahmp_hip_forcing_prep: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return jul.value
 
-    def forcing_interpolate(self, store, rec_a, rec_b, idts, idts2, rain_rate, stream=None):
+    def forcing_interpolate(self, store, rec_a, rec_b, idts, idts2, rain_rate, stream=None, wait=True):
         """Device-resident hrldas_input_interpolate / hrldas_input_copy (netcdf_io:1351-1403): `rec_a`, `rec_b` are
         dicts of device tensors keyed t q u v p lw sw pcp [fpar lai] (rec_b None = take rec_a as it is); `rain_rate`
         receives RAINBL_tmp.  Follow with forcing_prep(scale_vegfra=True)."""
@@ -117,7 +117,8 @@ class Engine:
         rb = rec(rec_b) if rec_b is not None else None
         st = abi.Status()
         rc = self.lib.noahmp_hip_forcing_interpolate(C.byref(a), C.byref(ra), C.byref(rb) if rb is not None else None,
-                                                     idts, idts2, rain_rate.data_ptr(), abi.MEM_DEVICE, stream, C.byref(st))
+                                                     idts, idts2, rain_rate.data_ptr(), abi.MEM_DEVICE, stream,
+                                                     C.byref(st) if wait else None)
         self.last_status = st
         if rc:
             raise RuntimeError("noahmp_hip_forcing_interpolate: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))

@@ -94,9 +94,9 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
             if k == 0:
                 rec_a = rec_b if rec_b is not None else recs.at(ri)
                 rec_b = recs.at(ri + 1)
-            eng.forcing_interpolate(d, rec_a, rec_b if k else None, 3600 * k, 3600 * synth5.RECORD_HOURS, rain_d, stream=sp)
+            eng.forcing_interpolate(d, rec_a, rec_b if k else None, 3600 * k, 3600 * synth5.RECORD_HOURS, rain_d, stream=sp, wait=False)
             iday, ihour = synth5.step_time(n)
-            jul = eng.forcing_prep(d, lon_d, rain_d, iday, ihour, first_step=(n == 0), stream=sp)
+            jul = eng.forcing_prep(d, lon_d, rain_d, iday, ihour, first_step=(n == 0), stream=sp, wait=False)
             eng.noahmplsm_async(d.step_args(n + 1, 2000, jul), stream=sp)
             if n + 1 in checkpoints or (n + 1) % 24 == 0:
                 st, _ = eng.sync()
