@@ -62,7 +62,7 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
       float snliqv = fminf(epore, y.snliq[L(iz)] / (dz * DENH2O));
       float bdsnoi = (y.snice[L(iz)] + y.snliq[L(iz)]) / dz;
       hcpct[L(iz)] = CICE * snicev + CWAT * snliqv;
-      df[L(iz)] = 3.2217E-6f * (bdsnoi * bdsnoi);   // BDSNOI**2. (lsm:2004)
+      df[L(iz)] = 3.2217E-6f * pow_two(bdsnoi);     // BDSNOI**2. (lsm:2004)
     }
   }
   const bool urban = (s.vegtyp == c.isurban);
@@ -509,7 +509,7 @@ NMP_DEV void canres(const Parm& P, float par, float sfctmp, float rcsoil, float 
   float rcs = (ff + P.rsmin / P.rsmax) / (1.0f + ff);
   rcs = fmaxf(rcs, 0.0001f);
   float dt_ = P.topt - sfctmp;
-  float rct = 1.0f - 0.0016f * (dt_ * dt_);
+  float rct = 1.0f - 0.0016f * pow_two(dt_);                    // (TOPT - SFCTMP)**2.0 (lsm:5664)
   rct = fmaxf(rct, 0.0001f);
   float rcq = 1.0f / (1.0f + P.hs * fmaxf(0.f, q2sat - q2));
   rcq = fmaxf(rcq, 0.01f);
@@ -928,7 +928,7 @@ NMP_DEV float frh2o(const Parm& P, float tkelv, float smc, float sh2o) {
   while ((nlog < 10) && (kcount == 0)) {
     nlog = nlog + 1;
     float t1 = 1.f + CK * swl;
-    float df = nmp_logf((P.psisat * GRAV / HFUS) * (t1 * t1) * nmp_powf(P.smcmax / (smc - swl), bx)) -
+    float df = nmp_logf((P.psisat * GRAV / HFUS) * pow_two(t1) * nmp_powf(P.smcmax / (smc - swl), bx)) -
                nmp_logf(-(tkelv - TFRZ) / tkelv);
     float denom = 2.f * CK / (1.f + CK * swl) + bx / (smc - swl);
     float swlk = swl - df / denom;
@@ -1090,7 +1090,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   if (live) {
   s.irc = 0.f; s.shc = 0.f; s.irg = 0.f; s.shg = 0.f; s.evg = 0.f; s.evc = 0.f; s.tr = 0.f;
   s.ghv = 0.f; s.t2mv = 0.f; s.q2v = 0.f; s.chv = 0.f; s.chleaf = 0.f; s.chuc = 0.f; s.chv2 = 0.f;
-  q.ur = fmaxf(sqrtf(s.uu * s.uu + s.vv * s.vv), 1.f);          // UU**2.+VV**2. (lsm:1536)
+  q.ur = fmaxf(sqrtf(pow_two(s.uu) + pow_two(s.vv)), 1.f);      // UU**2.+VV**2. (lsm:1536)
   q.vai = s.elai + s.esai;
   veg = (q.vai > 0.f);
   s.fsno = 0.f;

@@ -225,7 +225,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     }
   }
   // ---- ENERGY_GLACIER
-  const float ur = fmaxf(sqrtf(s.uu * s.uu + s.vv * s.vv), 1.f);
+  const float ur = fmaxf(sqrtf(pow_two(s.uu) + pow_two(s.vv)), 1.f);      // gla:490
   const float z0m = Z0SNO, zpd = s.snowh, zlvl = zpd + s.zlvl;
   float df[NL], hcpct[NL], fact[NL];
 #pragma unroll
@@ -240,7 +240,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
         float snliqv = fminf(epore, y.snliq[L(iz)] / (dz * DENH2O));
         float bdsnoi = (y.snice[L(iz)] + y.snliq[L(iz)]) / dz;
         hcpct[L(iz)] = CICE * snicev + CWAT * snliqv;
-        df[L(iz)] = 3.2217E-6f * (bdsnoi * bdsnoi);
+        df[L(iz)] = 3.2217E-6f * pow_two(bdsnoi);     // gla:695
       }
     }
     float above = 0.f;

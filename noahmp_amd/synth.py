@@ -194,3 +194,74 @@ def groundwater_fields(store, tables_dict, seed=4, area=1.0e6, stress=0.0, water
     wat = r.random(size=shp) < water_frac
     a["xland"][wat] = 2.0
     return store
+
+
+SNOW_EDGES = (0.025, 0.05, 0.10, 0.20, 0.25, 0.45)     # layer create / divide / combine depths [m] of SNOW_INIT, DIVIDE, COMBINE
+
+
+def veg_snow_matrix(tables, cfg=None, seed=21):
+    """SURVEY 8c fixture (2): every USGS category (27 columns) x 8 rows = {no snow, 1, 2, 3 snow layers} x {soil 3, soil 9}.
+    Category 16 (water) is skipped by noahmplsm, 24 runs the glacier path."""
+    cfg = cfg or ModelConfig()
+    r = _rng(seed)
+    ni, nj = 27, 8
+    s = _base_store(ni, nj, cfg)
+    a = s.a
+    shp = (nj, ni)
+    a["ivgtyp"][...] = np.arange(1, 28, dtype=np.int32)[None, :]
+    a["isltyp"][...] = np.where(np.arange(nj)[:, None] < 4, 3, 9)
+    a["isltyp"][a["ivgtyp"] == cfg.isice] = 16
+    a["isltyp"][a["ivgtyp"] == cfg.iswater] = 14
+    a["xland"][a["ivgtyp"] == cfg.iswater] = 2.0
+    a["vegfra"][...] = r.uniform(30.0, 85.0, size=shp).astype(F)
+    a["vegmax"][...] = np.maximum(a["vegfra"], F(90.0))
+    depth = np.array([0.0, 0.04, 0.15, 0.60], dtype=F)[np.arange(nj) % 4][:, None] * np.ones(shp, F)
+    snowy = depth > 0
+    tair = np.where(snowy, F(268.0), F(285.0)) + r.uniform(-2.0, 2.0, size=shp).astype(F)
+    tair[a["ivgtyp"] == cfg.isice] = np.minimum(tair[a["ivgtyp"] == cfg.isice], F(266.0))
+    s.t_offset = (tair - F(283.0)).astype(F)
+    a["tmn"][...] = (tair + F(2.0)).astype(F)
+    a["tsk"][...] = tair
+    a["snowh"][...] = depth
+    a["snow"][...] = depth * F(200.0)
+    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+        a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
+        a["smois"][:, k, :] = F(sm) + r.uniform(-0.04, 0.04, size=shp).astype(F)
+    diurnal_forcing(s, 0, t_offset=s.t_offset)
+    noahmp_init(s, tables)
+    return s
+
+
+def snow_edges(tables, cfg=None, seed=22):
+    """SURVEY 8c fixture (4): snow depths one float32 ulp below / at / above each layering threshold, on grass (7),
+    evergreen needleleaf (14), barren (19) and glacier (24) columns; rows: cold (accumulating) and near-melting air."""
+    cfg = cfg or ModelConfig()
+    r = _rng(seed)
+    edges = []
+    for e in SNOW_EDGES:
+        e = F(e)
+        edges += [np.nextafter(e, F(0.0)), e, np.nextafter(e, F(1.0))]
+    edges = np.array(edges, dtype=F)
+    vegs = np.array([7, 14, 19, cfg.isice], dtype=np.int32)
+    ni, nj = len(edges), 2 * len(vegs)
+    s = _base_store(ni, nj, cfg)
+    a = s.a
+    shp = (nj, ni)
+    a["ivgtyp"][...] = vegs[np.arange(nj) % len(vegs)][:, None]
+    a["isltyp"][...] = 6
+    a["isltyp"][a["ivgtyp"] == cfg.isice] = 16
+    a["vegfra"][...] = 60.0
+    a["vegmax"][...] = 90.0
+    cold = (np.arange(nj) < len(vegs))[:, None] & np.ones(shp, bool)
+    tair = np.where(cold, F(264.0), F(272.5)).astype(F) + r.uniform(-0.5, 0.5, size=shp).astype(F)
+    s.t_offset = (tair - F(283.0)).astype(F)
+    a["tmn"][...] = F(272.0)
+    a["tsk"][...] = tair
+    a["snowh"][...] = edges[None, :]
+    a["snow"][...] = edges[None, :] * r.uniform(120.0, 300.0, size=shp).astype(F)
+    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+        a["tslb"][:, k, :] = np.minimum(a["tsk"], F(273.0)) + F(dt_)
+        a["smois"][:, k, :] = F(sm)
+    diurnal_forcing(s, 0, t_offset=s.t_offset)
+    noahmp_init(s, tables)
+    return s

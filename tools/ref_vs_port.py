@@ -1,0 +1,55 @@
+"""Dev-container check (needs oracle/_ref): the C restatement against the COMPILED REFERENCE on a coarse config-5 grid
+(all USGS classes incl. glacier / urban / water, all ISNOW states, day and night), every output of every step compared
+bit for bit; the restatement restarts from the reference's state each step so that every mismatch is counted once.
+usage: ref_vs_port.py [ni nj nsteps] [key=value ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from noahmp_amd import synth5  # noqa: E402
+from noahmp_amd.state import ModelConfig  # noqa: E402
+from noahmp_amd.tables import load_tables  # noqa: E402
+from oracle.portlib import PortLib  # noqa: E402
+from oracle.reflib import RefLib  # noqa: E402
+from tools.compare import exact_check  # noqa: E402
+
+pos = [a for a in sys.argv[1:] if "=" not in a]
+kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+ni, nj, nsteps = (int(pos[0]), int(pos[1]), int(pos[2])) if len(pos) >= 3 else (144, 72, 240)
+T, tb = load_tables("usgs")
+port = PortLib()
+port.set_tables(T)
+ref = RefLib("O0")
+ref.set_tables(T)
+s, lon, static = synth5.config5_raw(ni, nj, cfg=ModelConfig(**kw) if kw else None)
+recs = synth5.Records(torch.from_numpy(s.a["xlatin"]), torch.from_numpy(lon), {k: torch.from_numpy(v) for k, v in static.items()})
+host = lambda r: {k: (v.numpy() if v is not None else None) for k, v in r.items()}
+ref.noahmp_init(s, fndsnowh=True)
+rain = np.zeros((nj, ni), np.float32)
+bad_steps, bad_cols, t0 = 0, 0, time.time()
+ra = rb = None
+for n in range(nsteps):
+    ri, k = divmod(n, synth5.RECORD_HOURS)
+    if k == 0:
+        ra = rb if rb is not None else host(recs.at(ri))
+        rb = host(recs.at(ri + 1))
+    port.forcing_interpolate(s, ra, rb if k else None, 3600 * k, 10800, rain)
+    jul = port.forcing_prep(s, lon, rain, *synth5.step_time(n), first_step=(n == 0))
+    p = s.copy()
+    ref.noahmplsm(s, n + 1, 2000, jul)
+    st = port.noahmplsm(p, n + 1, 2000, jul)
+    assert st.code == 0
+    ok, lines = exact_check(s, p)
+    if not ok:
+        bad_steps += 1
+        bad_cols += int(lines[0].split()[0])
+        if bad_steps <= 5:
+            print("step", n + 1, "\n  ".join(lines[:5]))
+print("config %s: %d columns x %d steps, %.0f s: %s" % (kw, ni * nj, nsteps, time.time() - t0,
+      "BIT-IDENTICAL to the compiled reference" if not bad_steps else "%d steps / %d column-steps differ" % (bad_steps, bad_cols)))
+sys.exit(1 if bad_steps else 0)
