@@ -29,7 +29,16 @@ ref.set_tables(T)
 s, lon, static = synth5.config5_raw(ni, nj, cfg=ModelConfig(**kw) if kw else None)
 recs = synth5.Records(torch.from_numpy(s.a["xlatin"]), torch.from_numpy(lon), {k: torch.from_numpy(v) for k, v in static.items()})
 host = lambda r: {k: (v.numpy() if v is not None else None) for k, v in r.items()}
+if kw.get("iopt_run") == 5:            # NOAHMP_INIT under OPT_RUN=5 needs the MMF planes (drv:1146-1176): cold-start as run=1,
+    s.cfg = ModelConfig(**dict(kw, iopt_run=1))      # then give the in-column part of the scheme a plausible equilibrium state
 ref.noahmp_init(s, fndsnowh=True)
+if kw.get("iopt_run") == 5:
+    s.cfg = ModelConfig(**kw)
+    s.a["smoiseq"][...] = s.a["smois"]
+    s["smcwtdxy"] = s.a["smois"][:, -1, :]
+    s["zwtxy"] = -6.0
+    for k in ("waxy", "wtxy", "deeprechxy", "rechxy"):
+        s[k] = 0.0
 rain = np.zeros((nj, ni), np.float32)
 bad_steps, bad_cols, t0 = 0, 0, time.time()
 ra = rb = None
@@ -44,7 +53,9 @@ for n in range(nsteps):
     ref.noahmplsm(s, n + 1, 2000, jul)
     st = port.noahmplsm(p, n + 1, 2000, jul)
     assert st.code == 0
-    ok, lines = exact_check(s, p)
+    # OPT_SFC=2 leaves FH2 undefined in the reference (lsm:3557-3571): six 2-m diagnostics are stack garbage there
+    skip = ("t2mvxy", "t2mbxy", "q2mvxy", "q2mbxy", "chv2xy", "chb2xy") if kw.get("iopt_sfc") == 2 else ()
+    ok, lines = exact_check(s, p, skip=skip)
     if not ok:
         bad_steps += 1
         bad_cols += int(lines[0].split()[0])
