@@ -70,12 +70,23 @@ extern "C" long libm_check_pow(int mode, long n, int nthreads, uint32_t* bad_xy)
   for (int t = 0; t < nthreads; t++)
     th.emplace_back([&, t]() {
       uint64_t s = 0x1234567ull * (t + 1) + mode;
-      const long cnt = mode == 2 ? (long)nsp * nsp : n / nthreads;
+      // mode 3: the constant real exponents of the reference (X**2., **3., **4., **0.5, **0.25, **(-0.25), **1.7, **(2./3.))
+      // over every n-th positive finite float
+      static const float fixed_y[] = {2.0f, 3.0f, 4.0f, 0.5f, 0.25f, -0.25f, 1.7f, 2.f / 3.f};
+      const long cnt = mode == 2 ? (long)nsp * nsp : mode == 3 ? (long)(0x7f800000u / (uint32_t)n) : n / nthreads;
       for (long c = 0; c < cnt; c++) {
         float x, y;
         if (mode == 2) {
           if (t) break;
           x = asfloat(sp[c / nsp]); y = asfloat(sp[c % nsp]);
+        } else if (mode == 3) {
+          if (c % nthreads != t) continue;
+          x = asfloat((uint32_t)c * (uint32_t)n + 1u);
+          for (int q = 0; q < 7; q++) {
+            const float a = powf_(x, fixed_y[q]), b = ::powf(x, fixed_y[q]);
+            if (!same(a, b)) { if (!bad[t]) { bx[t] = asuint(x); by[t] = asuint(fixed_y[q]); } bad[t]++; }
+          }
+          y = fixed_y[7];
         } else {
           const uint64_t r = splitmix(s);
           if (mode == 0) { x = asfloat((uint32_t)r); y = asfloat((uint32_t)(r >> 32)); }
