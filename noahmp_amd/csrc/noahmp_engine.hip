@@ -150,6 +150,23 @@ int noahmp_hip_set_device(int device) {
   return 0;
 }
 
+// Device memory for callers without a HIP binding of their own (a Fortran driver without hipfort): plain
+// hipMalloc / hipMemcpy / hipFree on the engine's device.  kind: 0 = host -> device, 1 = device -> host, 2 = device -> device.
+void* noahmp_hip_malloc(size_t bytes) {
+  if (ensure_init()) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g.last_error = "noahmp_hip_malloc: hipMalloc failed"; return nullptr; }
+  return p;
+}
+int noahmp_hip_memcpy(void* dst, const void* src, size_t bytes, int kind) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, k));
+  return 0;
+}
+void noahmp_hip_free(void* p) { if (p) hipFree(p); }
+
 int noahmp_hip_set_tables(const noahmp_tables* t) {
   int rc = ensure_init();
   if (rc) return rc;

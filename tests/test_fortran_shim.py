@@ -95,3 +95,35 @@ def test_fortran_groundwater_shim_end_to_end(engine, tables):
     engine.set_option("pin_host_arrays", 0)
     for k in GW_OUT:
         np.testing.assert_array_equal(via_c.a[k], via_f.a[k], err_msg=k)
+
+
+@pytest.mark.gpu
+@needs_flang
+def test_fortran_device_resident_time_loop(engine, port, tables):
+    """tests/fortran/dev_driver.f90 -- upload once, [forcing_prep -> step_async] x 30 in Fortran, one sync, one download --
+    against the oracle advanced through the same chain: bit-identical."""
+    lib = C.CDLL(build_shim.build())
+    lib.dev_driver_run.argtypes = [C.POINTER(abi.StepArgs), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                   C.POINTER(C.c_float)]
+    engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))
+    r = np.random.default_rng(9)
+    s = synth.mixed_small(tables[1], ni=96, nj=6, seed=19)
+    synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+    s["xlatin"] = r.uniform(-60.0, 70.0, size=(s.nj, s.ni)).astype(np.float32)
+    lon = r.uniform(-180.0, 180.0, size=(s.nj, s.ni)).astype(np.float32)
+    rain = np.where(r.random((s.nj, s.ni)) < 0.3, 4e-4, 0.0).astype(np.float32)
+    nsteps, iday0 = 30, 200
+    o, f = s.copy(), s.copy()
+    for n in range(nsteps):
+        jul_o = port.forcing_prep(o, lon, rain, iday0 + n // 24, n % 24, first_step=(n == 0))
+        st = port.noahmplsm(o, n + 1, 2000, jul_o)
+        assert st.code == 0
+    jul_f = C.c_float(0)
+    a = f.step_args(1, 2000, 0.0)
+    rc = lib.dev_driver_run(C.byref(a), lon.ctypes.data, rain.ctypes.data, nsteps, iday0, s.cfg.zlvl, C.byref(jul_f))
+    assert rc == 0, engine.lib.noahmp_hip_last_error().decode()
+    assert jul_f.value == jul_o
+    for k in o.a:
+        if FIELD_INFO[k][2] != "in":
+            np.testing.assert_array_equal(o.a[k], f.a[k], err_msg=k)
+    assert set(np.unique(o["isnowxy"])) >= {0, -1}
