@@ -125,6 +125,7 @@ def load_library(path=None):
     lib.noahmp_hip_set_device.argtypes = [C.c_int]
     lib.noahmp_hip_set_tables.argtypes = [C.POINTER(Tables)]
     lib.noahmp_hip_step.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_void_p, C.POINTER(Status)]
+    lib.noahmp_hip_fetch.argtypes = [C.POINTER(StepArgs)]
     lib.noahmp_hip_step_async.argtypes = [C.POINTER(StepArgs), C.c_void_p]
     lib.noahmp_hip_sync.argtypes = [C.POINTER(Status), C.POINTER(C.c_int)]
     lib.noahmp_hip_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(Status)]
@@ -168,7 +169,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "noahmp_hip_abi_version", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
     "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
-    "noahmp_hip_step", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_output_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_malloc", "noahmp_hip_memcpy", "noahmp_hip_free", "noahmp_hip_set_option", "noahmp_hip_error_string",
+    "noahmp_hip_step", "noahmp_hip_fetch", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_output_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_wtable_mmf", "noahmp_hip_groundwater_init", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_malloc", "noahmp_hip_memcpy", "noahmp_hip_free", "noahmp_hip_set_option", "noahmp_hip_error_string",
     "noahmp_hip_last_error", "noahmp_hip_finalize",
 ]
 

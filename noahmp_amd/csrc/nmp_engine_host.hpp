@@ -51,6 +51,12 @@ struct Engine {
   int pin_host_arrays = 0;      // hipHostRegister arrays seen twice at the same address (caller guarantees their lifetime)
   int trust_out_mirror = 0;     // do not re-upload OUT arrays after the first call (caller leaves them alone between calls)
   bool out_mirror_valid = false;
+  // resident host path: the device mirrors ARE the state between calls; only IN arrays are uploaded, INOUT / OUT arrays come back
+  // on request (noahmp_hip_fetch) unless lazy_download is off
+  int resident_state = 0, lazy_download = 0;
+  bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
+  std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call
+  noahmp_step_args resident_args;                        // the argument block of that call (for fetch)
   int block = 256;             // 4 waves per workgroup: ~1 % faster than 64 at 1 M columns (bench); 64 and 128 selectable
   int use_lds = 1;
   std::string last_error;

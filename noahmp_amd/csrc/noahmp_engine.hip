@@ -197,6 +197,20 @@ int noahmp_hip_set_option(const char* key, int value) {
     prev = g.trust_out_mirror;
     if (value == 0 || value == 1) { g.trust_out_mirror = value; g.out_mirror_valid = false; }
   }
+  else if (!strcmp(key, "resident_state")) {
+    prev = g.resident_state;
+    if (value == 0 || value == 1) {
+      if (!value && g.resident_dirty) noahmp_hip_fetch(nullptr);     // leaving the mode: bring the host arrays up to date
+      g.resident_state = value; g.resident_valid = false;
+    }
+  }
+  else if (!strcmp(key, "lazy_download")) {
+    prev = g.lazy_download;
+    if (value == 0 || value == 1) {
+      if (!value && g.resident_dirty) noahmp_hip_fetch(nullptr);
+      g.lazy_download = value;
+    }
+  }
   else if (!strcmp(key, "exact_libm")) prev = NMP_EXACT_LIBM;   // read-only: how this library was built
   return prev;
 }
@@ -352,7 +366,103 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
   return code;
 }
 
+// Resident host path ("resident_state" = 1): the caller's arrays are host arrays, but between calls the STATE lives in the device
+// mirrors.  The first call (or any call with other arrays / extents) uploads everything; later calls upload only the IN
+// arrays (forcing and static fields) and, with "lazy_download" = 1, copy nothing back: noahmp_hip_fetch() does that when the
+// caller needs the arrays (output / restart times, hdrv:440-441, 588).  The caller promises not to modify INOUT / OUT
+// arrays in between without switching the option off and on again.
+static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_status* st) {
+  KArgs k;
+  fill_kargs(k, a);
+  if (g.mirror_host.empty()) g.mirror_host.assign(kNumFields, nullptr);
+  bool valid = g.resident_valid;
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    const size_t bytes = field_elems(fd, a) * 4;
+    const void* host = *(void* const*)((const char*)a + fd.off);
+    if (g.mirror_bytes[f] != bytes) {
+      if (g.mirror[f]) HIPCHK(hipFree(g.mirror[f]));
+      HIPCHK(hipMalloc(&g.mirror[f], bytes));
+      g.mirror_bytes[f] = bytes;
+      valid = false;
+    }
+    if (g.mirror_host[f] != host) valid = false;
+  }
+  if (!valid && g.resident_dirty) {            // other arrays than last time while results are still only on the device
+    int rc = noahmp_hip_fetch(nullptr);
+    if (rc) return rc;
+  }
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    const size_t bytes = field_elems(fd, a) * 4;
+    void* host = *(void* const*)((const char*)a + fd.off);
+    maybe_pin(host, bytes);
+    if (!valid || fd.io == 0) HIPCHK(hipMemcpyAsync(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+    g.mirror_host[f] = host;
+    *(void**)((char*)&k.a + fd.off) = g.mirror[f];
+  }
+  g.out_mirror_valid = false;
+  *g.h_err = ~0ULL;
+  HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
+  HIPCHK(hipEventRecord(g.ev0, s));
+  launch_any(k, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
+  if (!g.lazy_download)
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      if (fd.io == 0) continue;
+      HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+    }
+  HIPCHK(hipStreamSynchronize(s));
+  g.resident_valid = true;
+  g.resident_dirty = g.lazy_download != 0;
+  g.resident_args = *a;
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, g.ev0, g.ev1);
+  int code = 0;
+  if (st) {
+    st->kernel_ms = ms;
+    int cnt[4];
+    nmp_host::sum_counts(cnt);
+    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+  }
+  if (*g.h_err != ~0ULL) {
+    code = (int)(*g.h_err & 0xFF);
+    const long t = (long)(*g.h_err >> 8) - 1;
+    if (st) { st->code = code; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
+  }
+  return code;
+}
+
 extern "C" {
+
+// Copy the INOUT and OUT arrays of the resident mirrors back into the host arrays of the last resident call (a = NULL) or
+// of `a` (which must name the same arrays).  No-op when nothing is pending.
+int noahmp_hip_fetch(const noahmp_step_args* a) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (!g.resident_valid) { if (g.resident_dirty) { g.last_error = "noahmp_hip_fetch: no resident state"; return -108; } return 0; }
+  const noahmp_step_args* r = &g.resident_args;
+  if (a)
+    for (int f = 0; f < kNumFields; f++)
+      if (*(void* const*)((const char*)a + kFields[f].off) != g.mirror_host[f]) {
+        g.last_error = "noahmp_hip_fetch: these are not the arrays of the resident state";
+        return -108;
+      }
+  if (!g.resident_dirty) return 0;
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    if (fd.io == 0) continue;
+    HIPCHK(hipMemcpyAsync(const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4, hipMemcpyDeviceToHost, g.own_stream));
+  }
+  HIPCHK(hipStreamSynchronize(g.own_stream));
+  g.resident_dirty = false;
+  return 0;
+}
 
 int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
   if (st) memset(st, 0, sizeof(*st));
@@ -362,6 +472,8 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   if (rc) return rc;
   if (g.async_pending) { g.last_error = "noahmp_hip_step: asynchronous steps are pending, call noahmp_hip_sync() first"; return -106; }
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  if (mem == NOAHMP_MEM_HOST && g.resident_state) return step_host_resident(a, s, st);
+  if (mem == NOAHMP_MEM_HOST) g.resident_valid = false;
   // the row-chunk pipeline only pays with pinned arrays (pageable asynchronous copies are staged and serialise)
   if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && g.host_chunks > 1 &&
       (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) >= 32768 &&
@@ -544,6 +656,7 @@ int noahmp_hip_debug_phase_ticks(unsigned long long* out, int n) {
 void noahmp_hip_finalize(void) {
   for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& b : g.mirror_bytes) b = 0;
+  g.resident_valid = false; g.resident_dirty = false; g.mirror_host.clear();
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto e : g.async_events) hipEventDestroy(e);

@@ -131,6 +131,10 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   k.counts = g.d_counts;
 
   if (mem == NOAHMP_MEM_HOST) {
+    // a resident column state (noahmp_hip_step, "resident_state") shares SMOIS / SH2O / ZWTXY ... with this call: bring the host
+    // arrays up to date first, and let the next column step upload them again
+    if (g.resident_dirty) { rc = noahmp_hip_fetch(nullptr); if (rc) return rc; }
+    g.resident_valid = false;
     if (g.gw_mirror.empty()) { g.gw_mirror.assign(kNW, nullptr); g.gw_mirror_bytes.assign(kNW, 0); }
     for (int f = 0; f < kNW; f++) {
       const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);

@@ -43,6 +43,12 @@ class Engine:
     def set_option(self, key, value):
         return self.lib.noahmp_hip_set_option(key.encode(), int(value))
 
+    def fetch(self):
+        """Bring the host arrays of a resident run ("resident_state" + "lazy_download") up to date."""
+        rc = self.lib.noahmp_hip_fetch(None)
+        if rc:
+            raise RuntimeError("noahmp_hip_fetch: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+
     def noahmplsm(self, store, itimestep, yr, julian, stream=None, check=True):
         a = store.step_args(itimestep, yr, julian)
         mem = abi.MEM_DEVICE if isinstance(store, DeviceColumnStore) else abi.MEM_HOST

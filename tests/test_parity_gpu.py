@@ -510,3 +510,38 @@ def test_pipelined_host_path_bit_identical(engine, tables):
     finally:
         for k, v in prev.items():
             engine.set_option(k, v)
+
+
+def test_resident_host_path_lazy_download(engine, port, tables):
+    """Host arrays, state resident in the device mirrors ("resident_state" + "lazy_download"): per call only the IN arrays
+    travel; the results appear in the host arrays at noahmp_hip_fetch -- and are the bits of the ordinary host path."""
+    s = synth.mixed_small(tables[1], ni=128, nj=8, seed=23)
+    synth.first_step_fixups(s)
+    plain, res = s.copy(), s.copy()
+    start = res.copy()
+    nsteps = 12
+    for it in range(1, nsteps + 1):
+        synth.diurnal_forcing(plain, (it - 1) % 24, t_offset=s.t_offset)
+        engine.noahmplsm(plain, it, 2000, 180.0)
+    try:
+        engine.set_option("resident_state", 1)
+        engine.set_option("lazy_download", 1)
+        for it in range(1, nsteps + 1):
+            synth.diurnal_forcing(res, (it - 1) % 24, t_offset=s.t_offset)       # in place: same arrays every call
+            st = engine.noahmplsm(res, it, 2000, 180.0)
+            assert st.code == 0 and st.n_land > 0
+        np.testing.assert_array_equal(res["tslb"], start["tslb"])                  # nothing came back yet
+        np.testing.assert_array_equal(res["hfx"], start["hfx"])
+        engine.fetch()
+        _check(plain, res, engine, steps=nsteps, fields=_outs(plain))
+        # another set of arrays: the engine notices, uploads everything and keeps going
+        other = plain.copy()
+        synth.diurnal_forcing(other, nsteps % 24, t_offset=s.t_offset)
+        synth.diurnal_forcing(plain, nsteps % 24, t_offset=s.t_offset)
+        engine.noahmplsm(other, nsteps + 1, 2000, 180.0)
+        engine.fetch()
+    finally:
+        engine.set_option("lazy_download", 0)
+        engine.set_option("resident_state", 0)
+    engine.noahmplsm(plain, nsteps + 1, 2000, 180.0)
+    _check(plain, other, engine, steps=nsteps + 1, fields=_outs(plain))
