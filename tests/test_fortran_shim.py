@@ -127,3 +127,39 @@ def test_fortran_device_resident_time_loop(engine, port, tables):
         if FIELD_INFO[k][2] != "in":
             np.testing.assert_array_equal(o.a[k], f.a[k], err_msg=k)
     assert set(np.unique(o["isnowxy"])) >= {0, -1}
+
+
+@pytest.mark.gpu
+@needs_flang
+def test_fortran_shim_resident_mode(engine, tables):
+    """The unchanged Fortran call pattern with resident_state + lazy_download, noahmp_hip_fetch_state() before reading."""
+    from oracle.reflib import RefLib
+    ref = RefLib("O0")
+    ref.set_tables(tables[0])
+    lib = C.CDLL(build_shim.build())
+    lib.shim_noahmplsm.argtypes = [C.POINTER(abi.StepArgs)]
+    fetch_state = getattr(lib, "_QMmodule_sf_noahmpdrv_hipPnoahmp_hip_fetch_state")      # flang's name of the module procedure
+    fetch_state.restype = None
+    s = synth.mixed_small(tables[1], ni=64, nj=4, seed=29)
+    synth.first_step_fixups(s)
+    plain, res = s.copy(), s.copy()
+    for it in range(1, 7):
+        synth.diurnal_forcing(plain, (it + 8) % 24, t_offset=s.t_offset)
+        engine.noahmplsm(plain, it, 2000, 180.0)
+    try:
+        engine.set_option("resident_state", 1)
+        engine.set_option("lazy_download", 1)
+        for it in range(1, 7):
+            synth.diurnal_forcing(res, (it + 8) % 24, t_offset=s.t_offset)
+            a = res.step_args(it, 2000, 180.0)
+            lib.shim_noahmplsm(C.byref(a))
+        assert not np.array_equal(res["tslb"], plain["tslb"])          # still the start values on the host
+        fetch_state()
+    finally:
+        engine.set_option("lazy_download", 0)
+        engine.set_option("resident_state", 0)
+        engine.set_option("pin_host_arrays", 0)
+        engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))
+    for k in plain.a:
+        if FIELD_INFO[k][2] != "in":
+            np.testing.assert_array_equal(plain.a[k], res.a[k], err_msg=k)
