@@ -177,7 +177,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
 
   float qfx_out = 0.f, lh_out = 0.f;
   if (cls == 1 && !failed) {
-    s.tbot = fminf(s.tbot, 263.15f);                                               // drv:555
+    s.tbot = nmp_min(s.tbot, 263.15f);                                               // drv:555
     glacier(k.c, s, y);
     if (s.err) failed = s.err;
     else {

@@ -61,6 +61,13 @@ extern "C" long nmp_libm_calls[8];
 #else
 #define NMP_CNT(i) ((void)0)
 #endif
+// Fortran MAX / MIN as the reference's compilers lower them: a select on an ordered compare (x86 MAXSS / MINSS semantics), so a NaN
+// in the SECOND operand propagates and a NaN in the first does not.  fmaxf / fminf (v_max_f32, IEEE maxNum) would swallow both; the
+// difference only shows in columns that already carry NaNs (e.g. dynamic vegetation on a category without vegetation parameters),
+// where the reference keeps running because its balance checks compare false.  Argument order = the reference's.
+NMP_DEV float nmp_max(float a, float b) { return a > b ? a : b; }
+NMP_DEV float nmp_min(float a, float b) { return a < b ? a : b; }
+
 #if NMP_EXACT_LIBM
 NMP_DEV float nmp_expf(float x) { NMP_CNT(0); return libm::expf_(x); }
 NMP_DEV float nmp_logf(float x) { NMP_CNT(1); return libm::logf_(x); }

@@ -26,7 +26,7 @@ NMP_DEV void esat_sel(float t, float& es, float& des) {
           t * (3.005693132E-07f + t * (2.158542548E-09f + t * 7.131097725E-12f))))));
   }
 }
-NMP_DEV float tdc(float t) { return fminf(50.f, fmaxf(-50.f, (t - TFRZ))); }   // lsm:3247
+NMP_DEV float tdc(float t) { return nmp_min(50.f, nmp_max(-50.f, (t - TFRZ))); }   // lsm:3247
 
 // TDFCND lsm:2014-2118
 // `thks_pow` = THKS**(1-SMCMAX) with THKS = 7.7**QUARTZ * 2**(1-QUARTZ): per-column constants, evaluated once by
@@ -57,9 +57,9 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
   for (int iz = -2; iz <= 0; iz++) {
     if (iz > isnow) {
       float dz = y.dzsnso[L(iz)];
-      float snicev = fminf(1.f, y.snice[L(iz)] / (dz * DENICE));
+      float snicev = nmp_min(1.f, y.snice[L(iz)] / (dz * DENICE));
       float epore = 1.f - snicev;
-      float snliqv = fminf(epore, y.snliq[L(iz)] / (dz * DENH2O));
+      float snliqv = nmp_min(epore, y.snliq[L(iz)] / (dz * DENH2O));
       float bdsnoi = (y.snice[L(iz)] + y.snliq[L(iz)]) / dz;
       hcpct[L(iz)] = CICE * snicev + CWAT * snliqv;
       df[L(iz)] = 3.2217E-6f * pow_two(bdsnoi);     // BDSNOI**2. (lsm:2004)
@@ -91,12 +91,12 @@ NMP_DEV void snow_age(float dt, float tg, float sneqvo, float sneqv, float& taus
     float dela0 = 1.E-6f * dt;
     float arg = 5.E3f * (1.f / TFRZ - 1.f / tg);
     float age1 = nmp_expf(arg);
-    float age2 = nmp_expf(fminf(0.f, 10.f * arg));
+    float age2 = nmp_expf(nmp_min(0.f, 10.f * arg));
     float tage = age1 + age2 + 0.3f;
     float dela = dela0 * tage;
-    float dels = fmaxf(0.0f, sneqv - sneqvo) / SWEMX;
+    float dels = nmp_max(0.0f, sneqv - sneqvo) / SWEMX;
     float sge = (tauss + dela) * (1.0f - dels);
-    tauss = fmaxf(0.f, sge);
+    tauss = nmp_max(0.f, sge);
   }
   fage = tauss / (tauss + 1.f);
 }
@@ -116,22 +116,22 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
     gap = 0.f; kopen = 0.f;
     if (c.O.rad == 1) {
       float rc = T->rc[v];
-      float denfveg = -nmp_logf(fmaxf(1.0f - fveg, 0.01f)) / (PAI * powi2(rc));
+      float denfveg = -nmp_logf(nmp_max(1.0f - fveg, 0.01f)) / (PAI * powi2(rc));
       float hd = T->hvt[v] - T->hvb[v];
       float bb = 0.5f * hd;
-      float thetap = nmp_atanf(bb / rc * nmp_tanf(nmp_acosf(fmaxf(0.01f, cosz))));
+      float thetap = nmp_atanf(bb / rc * nmp_tanf(nmp_acosf(nmp_max(0.01f, cosz))));
       bgap = nmp_expf(-denfveg * PAI * powi2(rc) / nmp_cosf(thetap));
       float fa = vai / (1.33f * PAI * nmp_powf(rc, 3.0f) * (bb / rc) * denfveg);
       float newvai = hd * fa;
       wgap = (1.0f - bgap) * nmp_expf(-0.5f * newvai / cosz);
-      gap = fminf(1.0f - fveg, bgap + wgap);
+      gap = nmp_min(1.0f - fveg, bgap + wgap);
       kopen = 0.05f;
     }
     if (c.O.rad == 2) { gap = 0.0f; kopen = 0.0f; }
     if (c.O.rad == 3) { gap = 1.0f - fveg; kopen = 1.0f - fveg; }
   }
-  float coszi = fmaxf(0.001f, cosz);
-  float chil = fminf(fmaxf(T->xl[v], -0.4f), 0.6f);
+  float coszi = nmp_max(0.001f, cosz);
+  float chil = nmp_min(nmp_max(T->xl[v], -0.4f), 0.6f);
   if (fabsf(chil) <= 0.01f) chil = 0.01f;
   float phi1 = 0.5f - 0.633f * chil - 0.330f * chil * chil;
   float phi2 = 0.877f * (1.f - 2.f * phi1);
@@ -218,34 +218,34 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
   s.bgap = 0.f; s.wgap = 0.f;
   const float vai = s.elai + s.esai;
   if (s.cosz > 0.f) {                                   // lsm:2356: whole block skipped at night
-    float wl = s.elai / fmaxf(vai, MPE);
-    float ws = s.esai / fmaxf(vai, MPE);
+    float wl = s.elai / nmp_max(vai, MPE);
+    float ws = s.esai / nmp_max(vai, MPE);
     float rho[2], tau[2], albsnd[2], albsni[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {
-      rho[ib] = fmaxf(T->rhol[ib][v] * wl + T->rhos[ib][v] * ws, MPE);
-      tau[ib] = fmaxf(T->taul[ib][v] * wl + T->taus[ib][v] * ws, MPE);
+      rho[ib] = nmp_max(T->rhol[ib][v] * wl + T->rhos[ib][v] * ws, MPE);
+      tau[ib] = nmp_max(T->taul[ib][v] * wl + T->taus[ib][v] * ws, MPE);
     }
     float fage;
     snow_age(c.dt, s.tg, s.sneqvo, s.sneqv, s.tauss, fage);
     if (c.O.alb == 1) {                                 // SNOWALB_BATS lsm:2599-2649
       float sl = 2.0f, sl1 = 1.f / sl, sl2 = 2.f * sl;
       float cf1 = ((1.f + sl1) / (1.f + sl2 * s.cosz) - sl1);
-      float fzen = fmaxf(cf1, 0.f);
+      float fzen = nmp_max(cf1, 0.f);
       albsni[0] = 0.95f * (1.f - 0.2f * fage);
       albsni[1] = 0.65f * (1.f - 0.5f * fage);
       albsnd[0] = albsni[0] + 0.4f * fzen * (1.f - albsni[0]);
       albsnd[1] = albsni[1] + 0.4f * fzen * (1.f - albsni[1]);
     } else {                                            // SNOWALB_CLASS lsm:2652-2700
       float alb = 0.55f + (s.albold - 0.55f) * nmp_expf(-0.01f * c.dt / 3600.f);
-      if (s.qsnow > 0.f) alb = alb + fminf(s.qsnow * c.dt, SWEMX) * (0.84f - alb) / (SWEMX);
+      if (s.qsnow > 0.f) alb = alb + nmp_min(s.qsnow * c.dt, SWEMX) * (0.84f - alb) / (SWEMX);
       albsni[0] = albsni[1] = albsnd[0] = albsnd[1] = alb;
       s.albold = alb;
     }
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {                    // GROUNDALB lsm:2703-2765 (IST=1 branch)
-      float inc = fmaxf(0.11f - 0.40f * smc1, 0.f);
-      float albsod = fminf(T->albsat[ib][s.isc - 1] + inc, T->albdry[ib][s.isc - 1]);
+      float inc = nmp_max(0.11f - 0.40f * smc1, 0.f);
+      float albsod = nmp_min(T->albsat[ib][s.isc - 1] + inc, T->albdry[ib][s.isc - 1]);
       float albsoi = albsod;
       if (s.isc == 9) { albsod += 0.10f; albsoi += 0.10f; }
       albgrd[ib] = albsod * (1.f - s.fsno) + albsnd[ib] * s.fsno;
@@ -265,7 +265,7 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
       }
     }
     float ext = gdir / s.cosz * sqrtf(1.f - rho[0] - tau[0]);
-    fsun = (1.f - nmp_expf(-ext * vai)) / fmaxf(ext * vai, MPE);
+    fsun = (1.f - nmp_expf(-ext * vai)) / nmp_max(ext * vai, MPE);
     if (fsun < 0.01f) fsun = 0.f;
   }
   RadOut r;
@@ -288,13 +288,13 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
     s.sag = s.sag + abs_;
     s.fsa = s.fsa + abs_;
   }
-  float laifra = s.elai / fmaxf(vai, MPE);
+  float laifra = s.elai / nmp_max(vai, MPE);
   if (fsun > 0.f) {
-    r.parsun = (cad[0] + fsun * cai[0]) * laifra / fmaxf(r.laisun, MPE);
-    r.parsha = (fsha * cai[0]) * laifra / fmaxf(r.laisha, MPE);
+    r.parsun = (cad[0] + fsun * cai[0]) * laifra / nmp_max(r.laisun, MPE);
+    r.parsha = (fsha * cai[0]) * laifra / nmp_max(r.laisha, MPE);
   } else {
     r.parsun = 0.f;
-    r.parsha = (cad[0] + cai[0]) * laifra / fmaxf(r.laisha, MPE);
+    r.parsha = (cad[0] + cai[0]) * laifra / nmp_max(r.laisha, MPE);
   }
   float rvis = albd[0] * solad[0] + albi[0] * solai[0];
   float rnir = albd[1] * solad[1] + albi[1] * solai[1];
@@ -335,8 +335,8 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, float rhoair, float h, fl
     float tmp1 = VKC * (GRAV / tvir) * h / (rhoair * CPAIR);
     if (fabsf(tmp1) <= mpe) tmp1 = mpe;
     float mol = -1.f * powi3(m.fv) / tmp1;
-    m.moz = fminf((zlvl - zpd) / mol, 1.f);
-    moz2 = fminf((2.0f + z0h) / mol, 1.f);
+    m.moz = nmp_min((zlvl - zpd) / mol, 1.f);
+    moz2 = nmp_min((2.0f + z0h) / mol, 1.f);
   }
   if (mozold * m.moz < 0.f) m.mozsgn = m.mozsgn + 1;
   if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
@@ -363,10 +363,10 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, float rhoair, float h, fl
     m.fm2 = 0.5f * (m.fm2 + fm2new);
     m.fh2 = 0.5f * (m.fh2 + fh2new);
   }
-  m.fh = fminf(m.fh, 0.9f * tmpch);
-  m.fm = fminf(m.fm, 0.9f * tmpcm);
-  m.fh2 = fminf(m.fh2, 0.9f * tmpch2);
-  m.fm2 = fminf(m.fm2, 0.9f * tmpcm2);
+  m.fh = nmp_min(m.fh, 0.9f * tmpch);
+  m.fm = nmp_min(m.fm, 0.9f * tmpcm);
+  m.fh2 = nmp_min(m.fh2, 0.9f * tmpch2);
+  m.fm2 = nmp_min(m.fm2, 0.9f * tmpcm2);
   float cmfm = tmpcm - m.fm, chfh = tmpch - m.fh;
   if (fabsf(cmfm) <= mpe) cmfm = mpe;
   if (fabsf(chfh) <= mpe) chfh = mpe;
@@ -392,20 +392,20 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   float rdz = 1.f / zlm;
   float cxch = EXCM * rdz;
   float dthv = thlm - thz0;
-  float du2 = fmaxf(sfcspd * sfcspd, EPSU2);
+  float du2 = nmp_max(sfcspd * sfcspd, EPSU2);
   float btgh = BTG * HPBL;
   if (iter == 1) {
     if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * nmp_powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
     else wstar2 = 0.0f;
-    ustar = fmaxf(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
+    ustar = nmp_max(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
     rlmo = ELFC * akhs * dthv / powi3(ustar);
   }
-  float zt = fmaxf(1.E-6f, nmp_expf(zilfc * sqrtf(ustar * z0)) * z0);
+  float zt = nmp_max(1.E-6f, nmp_expf(zilfc * sqrtf(ustar * z0)) * z0);
   float zslu = zlm + zu;
   float zslt = zlm + zt;
   float rlogu = nmp_logf(zslu / zu);
   float rlogt = nmp_logf(zslt / zt);
-  float zetalt = fmaxf(zslt * rlmo, ZTMIN);
+  float zetalt = nmp_max(zslt * rlmo, ZTMIN);
   rlmo = zetalt / zslt;
   float zetalu = zslu * rlmo;
   float zetau = zu * rlmo;
@@ -419,17 +419,17 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
     pshz = psphu(xt);
     simh = psphu(xlt) - pshz + rlogt;
   } else {
-    zetalu = fminf(zetalu, ZTMAX);
-    zetalt = fminf(zetalt, ZTMAX);
+    zetalu = nmp_min(zetalu, ZTMAX);
+    zetalt = nmp_min(zetalt, ZTMAX);
     psmz = 5.f * zetau;
     simm = 5.f * zetalu - psmz + rlogu;
     pshz = 5.f * zetat;
     simh = 5.f * zetalt - pshz + rlogt;
   }
-  ustar = fmaxf(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
+  ustar = nmp_max(sqrtf(akms * sqrtf(du2 + wstar2)), EPSUST);
   float ustark = ustar * VKRM;
-  akms = fmaxf(ustark / simm, cxch);
-  akhs = fmaxf(ustark / simh, cxch);
+  akms = nmp_max(ustark / simm, cxch);
+  akhs = nmp_max(ustark / simh, cxch);
   if (btgh * akhs * dthv != 0.0f) wstar2 = WWST2 * nmp_powf(fabsf(btgh * akhs * dthv), 2.f / 3.f);
   else wstar2 = 0.0f;
   float rlmn = ELFC * akhs * dthv / powi3(ustar);
@@ -464,7 +464,7 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
   psn = 0.0f;
   if (apar <= 0.0f) return;
   const float c3 = T->c3psn[v], mpv = T->mp[v];
-  float fnf = fminf(foln / fmaxf(mpe, T->folnmx[v]), 1.0f);
+  float fnf = nmp_min(foln / nmp_max(mpe, T->folnmx[v]), 1.0f);
   float ppf = 4.6f * apar;
   float j = ppf * T->qe25[v];
   const float awc = st.awc, cp = st.cp;
@@ -474,11 +474,11 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
 #pragma unroll 1
   for (int iter = 1; iter <= 20; iter++) {
     float ci = 0.5f * (cihi + cilow);
-    float wj = fmaxf(ci - cp, 0.0f) * j / (ci + 2.0f * cp) * c3 + j * (1.f - c3);
-    float wc = fmaxf(ci - cp, 0.0f) * vcmx / (ci + awc) * c3 + vcmx * (1.f - c3);
+    float wj = nmp_max(ci - cp, 0.0f) * j / (ci + 2.0f * cp) * c3 + j * (1.f - c3);
+    float wc = nmp_max(ci - cp, 0.0f) * vcmx / (ci + awc) * c3 + vcmx * (1.f - c3);
     float we = 0.5f * vcmx * c3 + 4000.0f * vcmx * ci / sfcprs * (1.f - c3);
-    psn = fminf(fminf(wj, wc), we) * igs;
-    float cs = fmaxf(co2 - 1.37f * rlb * sfcprs * psn, mpe);
+    psn = nmp_min(nmp_min(wj, wc), we) * igs;
+    float cs = nmp_max(co2 - 1.37f * rlb * sfcprs * psn, mpe);
     float a = mpv * psn * sfcprs * ea / (cs * ei) + bpv;
     float b = (mpv * psn * sfcprs / cs + bpv) * rlb - 1.f;
     float cq = -rlb;
@@ -486,8 +486,8 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
     if (b >= 0.0f) q = -0.5f * (b + sqrtf(b * b - 4.0f * a * cq));
     else q = -0.5f * (b - sqrtf(b * b - 4.0f * a * cq));
     float r1 = q / a, r2 = cq / q;
-    rs = fmaxf(r1, r2);
-    float fci = fmaxf(cs - psn * sfcprs * 1.65f * rs, 0.0f);
+    rs = nmp_max(r1, r2);
+    float fci = nmp_max(cs - psn * sfcprs * 1.65f * rs, 0.0f);
     if (((cihi - cilow) <= 5e-2f) || fabsf(fci - ci) <= mpe) break;
     else if (fci > ci) cilow = ci;
     else cihi = ci;
@@ -507,12 +507,12 @@ NMP_DEV void canres(const Parm& P, float par, float sfctmp, float rcsoil, float 
   q2sat = q2sat / 1.E3f;
   float ff = 2.0f * par / P.rgl;
   float rcs = (ff + P.rsmin / P.rsmax) / (1.0f + ff);
-  rcs = fmaxf(rcs, 0.0001f);
+  rcs = nmp_max(rcs, 0.0001f);
   float dt_ = P.topt - sfctmp;
   float rct = 1.0f - 0.0016f * pow_two(dt_);                    // (TOPT - SFCTMP)**2.0 (lsm:5664)
-  rct = fmaxf(rct, 0.0001f);
-  float rcq = 1.0f / (1.0f + P.hs * fmaxf(0.f, q2sat - q2));
-  rcq = fmaxf(rcq, 0.01f);
+  rct = nmp_max(rct, 0.0001f);
+  float rcq = 1.0f / (1.0f + P.hs * nmp_max(0.f, q2sat - q2));
+  rcq = nmp_max(rcq, 0.01f);
   rc = P.rsmin / (rcs * rct * rcq * rcsoil);
   psn = -999.99f;
 }
@@ -558,7 +558,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     L.cm = L.cm / ur;
   }
   NMP_TIC(16);   // vege loop1: sfcdif
-  L.rahc = fmaxf(1.f, 1.f / (L.ch * ur));
+  L.rahc = nmp_max(1.f, 1.f / (L.ch * ur));
   const float rawc = L.rahc;
   {                                                   // RAGRB lsm:3960-4057
     float mozg = 0.f, fhgnew;
@@ -566,7 +566,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
       float tmp1 = VKC * (GRAV / L.tah) * L.hg / (rhoair * CPAIR);
       if (fabsf(tmp1) <= MPE) tmp1 = MPE;
       float molg = -1.f * powi3(L.mo.fv) / tmp1;
-      mozg = fminf((L.zpd - L.z0mg) / molg, 1.f);
+      mozg = nmp_min((L.zpd - L.z0mg) / molg, 1.f);
     }
     if (mozg < 0.f) fhgnew = pow_neg_quarter(1.f - 15.f * mozg);
     else fhgnew = 1.f + 4.7f * mozg;
@@ -576,7 +576,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     float tmp1 = nmp_expf(-cwpc * z0hg / hcan);
     float tmp2 = nmp_expf(-cwpc * (z0h + L.zpd) / hcan);
     float tmprah2 = hcan * nmp_expf(cwpc) / cwpc * (tmp1 - tmp2);
-    float kh = fmaxf(VKC * L.mo.fv * (hcan - L.zpd), MPE);
+    float kh = nmp_max(VKC * L.mo.fv * (hcan - L.zpd), MPE);
     L.rahg = tmprah2 / kh;
     float tmprb = cwpc * 50.f / (1.f - nmp_expf(-cwpc / 2.f));
     L.rb = tmprb * L.sqrt_dleaf_uc;
@@ -629,8 +629,8 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   L.shc = fveg * rhoair * CPAIR * cvh * (L.tv - L.tah);
   L.evc = fveg * rhoair * CPAIR * cew * (estv - L.eah) / L.gammav;
   L.tr = fveg * rhoair * CPAIR * ctw * (estv - L.eah) / L.gammav;
-  if (L.tv > TFRZ) L.evc = fminf(L.canliq * L.latheav / c.dt, L.evc);
-  else L.evc = fminf(L.canice * L.latheav / c.dt, L.evc);
+  if (L.tv > TFRZ) L.evc = nmp_min(L.canliq * L.latheav / c.dt, L.evc);
+  else L.evc = nmp_min(L.canice * L.latheav / c.dt, L.evc);
   float b = L.sav - L.irc - L.shc - L.evc - L.tr;
   float a = fveg * (4.f * L.cir * powi3(L.tv) + csh + (cev + ctr) * destv);
   L.dtv = b / a;
@@ -682,9 +682,9 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.fwet = s.fwet; L.sfcprs = s.sfcprs; L.thair = s.thair; L.czil = P.czil;
     L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
     L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
-    L.vaie = fminf(6.f, q.vai / fveg);
-    L.laisune = fminf(6.f, q.laisun / fveg);
-    L.laishae = fminf(6.f, q.laisha / fveg);
+    L.vaie = nmp_min(6.f, q.vai / fveg);
+    L.laisune = nmp_min(6.f, q.laisun / fveg);
+    L.laishae = nmp_min(6.f, q.laisha / fveg);
     float t = tdc(L.tg), destg_unused;
     esat_sel(t, L.estg, destg_unused);
     L.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
@@ -780,9 +780,9 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
       sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
       ch = ch / ur;
       cm = cm / ur;
-      if (s.snowh > 0.f) { cm = fminf(0.01f, cm); ch = fminf(0.01f, ch); }
+      if (s.snowh > 0.f) { cm = nmp_min(0.01f, cm); ch = nmp_min(0.01f, ch); }
     }
-    float rahb = fmaxf(1.f, 1.f / (ch * ur));
+    float rahb = nmp_max(1.f, 1.f / (ch * ur));
     float rawb = rahb;
     ehb = 1.f / rahb;
     t = tdc(tgb);
@@ -942,7 +942,7 @@ NMP_DEV float frh2o(const Parm& P, float tkelv, float smc, float sh2o) {
   if (kcount == 0) {
     float fk = nmp_powf((HFUS / (GRAV * (-P.psisat))) * ((tkelv - TFRZ) / tkelv), -1 / bx) * P.smcmax;
     if (fk < 0.02f) fk = 0.02f;
-    free_ = fminf(fk, smc);
+    free_ = nmp_min(fk, smc);
   }
   return free_;
 }
@@ -1007,13 +1007,13 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
   (void)hm1; (void)xm1;
   if (isnow == 0 && s.sneqv > 0.f && xm[L(1)] > 0.f) {
     float temp1 = s.sneqv;
-    s.sneqv = fmaxf(0.f, temp1 - xm[L(1)]);
+    s.sneqv = nmp_max(0.f, temp1 - xm[L(1)]);
     float propor = s.sneqv / temp1;
-    s.snowh = fmaxf(0.f, propor * s.snowh);
+    s.snowh = nmp_max(0.f, propor * s.snowh);
     float heatr = hm[L(1)] - HFUS * (temp1 - s.sneqv) / dt;
     if (heatr > 0.f) { xm[L(1)] = heatr * dt / HFUS; hm[L(1)] = heatr; }
     else { xm[L(1)] = 0.f; hm[L(1)] = 0.f; }
-    qmelt = fmaxf(0.f, (temp1 - s.sneqv)) / dt;
+    qmelt = nmp_max(0.f, (temp1 - s.sneqv)) / dt;
     ponding = temp1 - s.sneqv;
   }
 #pragma unroll
@@ -1022,29 +1022,29 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
       if (imelt[L(j)] > 0 && fabsf(hm[L(j)]) > 0.f) {
         float heatr = 0.f;
         if (xm[L(j)] > 0.f) {
-          mice[L(j)] = fmaxf(0.f, wice0[L(j)] - xm[L(j)]);
+          mice[L(j)] = nmp_max(0.f, wice0[L(j)] - xm[L(j)]);
           heatr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
         } else if (xm[L(j)] < 0.f) {
           if (j <= 0) {
-            mice[L(j)] = fminf(wmass0[L(j)], wice0[L(j)] - xm[L(j)]);
+            mice[L(j)] = nmp_min(wmass0[L(j)], wice0[L(j)] - xm[L(j)]);
           } else {
             if (wmass0[L(j)] < supercool[L(j)]) {
               mice[L(j)] = 0.f;
             } else {
-              mice[L(j)] = fminf(wmass0[L(j)] - supercool[L(j)], wice0[L(j)] - xm[L(j)]);
-              mice[L(j)] = fmaxf(mice[L(j)], 0.0f);
+              mice[L(j)] = nmp_min(wmass0[L(j)] - supercool[L(j)], wice0[L(j)] - xm[L(j)]);
+              mice[L(j)] = nmp_max(mice[L(j)], 0.0f);
             }
           }
           heatr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
         }
-        mliq[L(j)] = fmaxf(0.f, wmass0[L(j)] - mice[L(j)]);
+        mliq[L(j)] = nmp_max(0.f, wmass0[L(j)] - mice[L(j)]);
         if (fabsf(heatr) > 0.f) {
           stc[L(j)] = stc[L(j)] + fact[L(j)] * heatr;
           if (j <= 0) {
             if (mliq[L(j)] * mice[L(j)] > 0.f) stc[L(j)] = TFRZ;
           }
         }
-        if (j < 1) qmelt = qmelt + fmaxf(0.f, (wice0[L(j)] - mice[L(j)])) / dt;
+        if (j < 1) qmelt = qmelt + nmp_max(0.f, (wice0[L(j)] - mice[L(j)])) / dt;
       }
     }
   }
@@ -1090,7 +1090,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   if (live) {
   s.irc = 0.f; s.shc = 0.f; s.irg = 0.f; s.shg = 0.f; s.evg = 0.f; s.evc = 0.f; s.tr = 0.f;
   s.ghv = 0.f; s.t2mv = 0.f; s.q2v = 0.f; s.chv = 0.f; s.chleaf = 0.f; s.chuc = 0.f; s.chv2 = 0.f;
-  q.ur = fmaxf(sqrtf(pow_two(s.uu) + pow_two(s.vv)), 1.f);      // UU**2.+VV**2. (lsm:1536)
+  q.ur = nmp_max(sqrtf(pow_two(s.uu) + pow_two(s.vv)), 1.f);      // UU**2.+VV**2. (lsm:1536)
   q.vai = s.elai + s.esai;
   veg = (q.vai > 0.f);
   s.fsno = 0.f;
@@ -1109,7 +1109,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
     q.z0m = q.z0mg;
     q.zpd = zpdg;
   }
-  q.zlvl = fmaxf(q.zpd, s.htop) + s.zlvl;
+  q.zlvl = nmp_max(q.zpd, s.htop) + s.zlvl;
   if (zpdg >= q.zlvl) q.zlvl = zpdg + s.zlvl;
   q.cwp = T->cwpvt[v];
   NMP_TIC(2);    // energy: preamble
@@ -1130,29 +1130,29 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
       if (c.O.btr == 1) {
         gx = (sh - P.smcwlt) / (P.smcref - P.smcwlt);
       } else {
-        float psi = fmaxf(PSIWLT, -P.psisat * nmp_powf(fmaxf(0.01f, sh) / P.smcmax, -P.bexp));
+        float psi = nmp_max(PSIWLT, -P.psisat * nmp_powf(nmp_max(0.01f, sh) / P.smcmax, -P.bexp));
         if (c.O.btr == 2) gx = (1.f - psi / PSIWLT) / (1.f + P.psisat / PSIWLT);
         else gx = 1.f - nmp_expf(-5.8f * (nmp_logf(PSIWLT / psi)));
       }
-      gx = fminf(1.f, fmaxf(0.f, gx));
-      float bt = fmaxf(MPE, y.dzsnso[L(iz)] / zroot * gx);
+      gx = nmp_min(1.f, nmp_max(0.f, gx));
+      float bt = nmp_max(MPE, y.dzsnso[L(iz)] / zroot * gx);
       y.btrani[L(iz)] = bt;
       s.btran = s.btran + bt;
     }
   }
-  s.btran = fmaxf(MPE, s.btran);
+  s.btran = nmp_max(MPE, s.btran);
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++)
     if (iz <= P.nroot) y.btrani[L(iz)] = y.btrani[L(iz)] / s.btran;
   // soil surface resistance lsm:1644-1669
   {
     float sh1 = y.sh2o[L(1)];
-    float l_rsurf = (-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - fminf(1.0f, sh1 / P.smcmax))) - 1.0f) /
+    float l_rsurf = (-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - nmp_min(1.0f, sh1 / P.smcmax))) - 1.0f) /
                     (2.71828f - 1.0f);
     float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * nmp_powf(1.0f - P.smcwlt / P.smcmax, 2.0f + 3.0f / P.bexp);
     q.rsurf = l_rsurf / d_rsurf;
     if (sh1 < 0.01f && s.snowh == 0.f) q.rsurf = 1.E6f;
-    float psi = -P.psisat * nmp_powf(fmaxf(0.01f, sh1) / P.smcmax, -P.bexp);
+    float psi = -P.psisat * nmp_powf(nmp_max(0.01f, sh1) / P.smcmax, -P.bexp);
     q.rhsur = s.fsno + (1.f - s.fsno) * nmp_expf(psi * GRAV / (RW * s.tg));
   }
   if (s.vegtyp == c.isurban && s.snowh == 0.f) q.rsurf = 1.E6f;

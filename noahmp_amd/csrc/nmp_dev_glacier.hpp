@@ -47,13 +47,13 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
   }
   if (isnow == 0 && s.sneqv > 0.f && xm[L(1)] > 0.f) {
     float temp1 = s.sneqv;
-    s.sneqv = fmaxf(0.f, temp1 - xm[L(1)]);
+    s.sneqv = nmp_max(0.f, temp1 - xm[L(1)]);
     float propor = s.sneqv / temp1;
-    s.snowh = fmaxf(0.f, propor * s.snowh);
+    s.snowh = nmp_max(0.f, propor * s.snowh);
     float h1 = hm[L(1)] - HFUS * (temp1 - s.sneqv) / dt;
     if (h1 > 0.f) { xm[L(1)] = h1 * dt / HFUS; hm[L(1)] = h1; imelt[L(1)] = 1; }
     else { xm[L(1)] = 0.f; hm[L(1)] = 0.f; imelt[L(1)] = 0; }
-    qmelt = fmaxf(0.f, (temp1 - s.sneqv)) / dt;
+    qmelt = nmp_max(0.f, (temp1 - s.sneqv)) / dt;
     ponding = temp1 - s.sneqv;
   }
 #pragma unroll
@@ -62,18 +62,18 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
       if (imelt[L(j)] > 0 && fabsf(hm[L(j)]) > 0.f) {
         float hr = 0.f;
         if (xm[L(j)] > 0.f) {
-          mice[L(j)] = fmaxf(0.f, wice0[L(j)] - xm[L(j)]);
+          mice[L(j)] = nmp_max(0.f, wice0[L(j)] - xm[L(j)]);
           hr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
         } else if (xm[L(j)] < 0.f) {
-          mice[L(j)] = fminf(wmass0[L(j)], wice0[L(j)] - xm[L(j)]);
+          mice[L(j)] = nmp_min(wmass0[L(j)], wice0[L(j)] - xm[L(j)]);
           hr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
         }
-        mliq[L(j)] = fmaxf(0.f, wmass0[L(j)] - mice[L(j)]);
+        mliq[L(j)] = nmp_max(0.f, wmass0[L(j)] - mice[L(j)]);
         if (fabsf(hr) > 0.f) {
           stc[L(j)] = stc[L(j)] + fact[L(j)] * hr;
           if (j <= 0) { if (mliq[L(j)] * mice[L(j)] > 0.f) stc[L(j)] = TFRZ; }
         }
-        if (j < 1) qmelt = qmelt + fmaxf(0.f, (wice0[L(j)] - mice[L(j)])) / dt;
+        if (j < 1) qmelt = qmelt + nmp_max(0.f, (wice0[L(j)] - mice[L(j)])) / dt;
       }
     }
   }
@@ -148,7 +148,7 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
               mice[L(k)] = 0.0f;
               stc[L(k)] = TFRZ;
             }
-            mliq[L(k)] = fmaxf(0.f, wmass0[L(k)] - mice[L(k)]);
+            mliq[L(k)] = nmp_max(0.f, wmass0[L(k)] - mice[L(k)]);
           }
         }
         heatr[L(j)] = xm[L(j)] * HFUS / dt;
@@ -174,7 +174,7 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
               mice[L(k)] = wmass0[L(k)];
               stc[L(k)] = TFRZ;
             }
-            mliq[L(k)] = fmaxf(0.f, wmass0[L(k)] - mice[L(k)]);
+            mliq[L(k)] = nmp_max(0.f, wmass0[L(k)] - mice[L(k)]);
           }
         }
         heatr[L(j)] = xm[L(j)] * HFUS / dt;
@@ -193,7 +193,7 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
 #pragma unroll
   for (int j = 1; j <= NSOIL; j++) {
     float sh = mliq[L(j)] / (1000.f * y.dzsnso[L(j)]);
-    y.sh2o[L(j)] = fmaxf(0.0f, fminf(1.0f, sh));
+    y.sh2o[L(j)] = nmp_max(0.0f, nmp_min(1.0f, sh));
     y.smc[L(j)] = 1.0f;
   }
   s.qmelt = qmelt;
@@ -225,7 +225,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     }
   }
   // ---- ENERGY_GLACIER
-  const float ur = fmaxf(sqrtf(pow_two(s.uu) + pow_two(s.vv)), 1.f);      // gla:490
+  const float ur = nmp_max(sqrtf(pow_two(s.uu) + pow_two(s.vv)), 1.f);      // gla:490
   const float z0m = Z0SNO, zpd = s.snowh, zlvl = zpd + s.zlvl;
   float df[NL], hcpct[NL], fact[NL];
 #pragma unroll
@@ -235,9 +235,9 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     for (int iz = -2; iz <= 0; iz++) {
       if (iz > s.isnow) {
         float dz = y.dzsnso[L(iz)];
-        float snicev = fminf(1.f, y.snice[L(iz)] / (dz * DENICE));
+        float snicev = nmp_min(1.f, y.snice[L(iz)] / (dz * DENICE));
         float epore = 1.f - snicev;
-        float snliqv = fminf(epore, y.snliq[L(iz)] / (dz * DENH2O));
+        float snliqv = nmp_min(epore, y.snliq[L(iz)] / (dz * DENH2O));
         float bdsnoi = (y.snice[L(iz)] + y.snliq[L(iz)]) / dz;
         hcpct[L(iz)] = CICE * snicev + CWAT * snliqv;
         df[L(iz)] = 3.2217E-6f * pow_two(bdsnoi);     // gla:695
@@ -272,7 +272,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     if (c.O.alb == 1) {
       float sl = 2.0f, sl1 = 1.f / sl, sl2 = 2.f * sl;
       float cf1 = ((1.f + sl1) / (1.f + sl2 * s.cosz) - sl1);
-      float fzen = fmaxf(cf1, 0.f);
+      float fzen = nmp_max(cf1, 0.f);
       albsni[0] = 0.95f * (1.f - 0.2f * fage);
       albsni[1] = 0.65f * (1.f - 0.5f * fage);
       albsnd[0] = albsni[0] + 0.4f * fzen * (1.f - albsni[0]);
@@ -280,7 +280,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     }
     if (c.O.alb == 2) {
       float alb = 0.55f + (s.albold - 0.55f) * nmp_expf(-0.01f * dt / 3600.f);
-      if (s.qsnow > 0.f) alb = alb + fminf(s.qsnow * dt, SWEMX) * (0.84f - alb) / (SWEMX);
+      if (s.qsnow > 0.f) alb = alb + nmp_min(s.qsnow * dt, SWEMX) * (0.84f - alb) / (SWEMX);
       albsni[0] = albsni[1] = albsnd[0] = albsnd[1] = alb;
       s.albold = alb;
     }
@@ -310,7 +310,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
 #pragma unroll 1
     for (int iter = 1; iter <= 5; iter++) {
       sfcdif1(s.err, iter, s.sfctmp, s.rhoair, h, s.qair, zlvl, zpd, z0m, z0m, ur, MPE, mo, s.cm, s.ch);
-      rahb = fmaxf(1.f, 1.f / (s.ch * ur));
+      rahb = nmp_max(1.f, 1.f / (s.ch * ur));
       float rawb = rahb;
       t = tdc(tgb);
       esat_sel(t, estg, destg);
@@ -335,7 +335,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     }
     float sicemax = -1.e30f;
 #pragma unroll
-    for (int k = 1; k <= NSOIL; k++) sicemax = fmaxf(sicemax, y.smc[L(k)] - y.sh2o[L(k)]);
+    for (int k = 1; k <= NSOIL; k++) sicemax = nmp_max(sicemax, y.smc[L(k)] - y.sh2o[L(k)]);
     if (c.O.stc == 1) {
       if ((sicemax > 0.0f || s.snowh > 0.0f) && tgb > TFRZ) {
         tgb = TFRZ;
@@ -373,12 +373,12 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
   float sice_save[NL], sh2o_save[NL];
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    float si = fmaxf(0.0f, y.smc[L(k)] - y.sh2o[L(k)]);
+    float si = nmp_max(0.0f, y.smc[L(k)] - y.sh2o[L(k)]);
     y.sice[L(k)] = si; sice_save[L(k)] = si; sh2o_save[L(k)] = y.sh2o[L(k)];
   }
   s.sneqvo = s.sneqv;
-  float qvap = fmaxf(s.fgev / lathea, 0.f);
-  float qdew = fabsf(fminf(s.fgev / lathea, 0.f));
+  float qvap = nmp_max(s.fgev / lathea, 0.f);
+  float qdew = fabsf(nmp_min(s.fgev / lathea, 0.f));
   s.edir = qvap - qdew;
   // ---- WATER_GLACIER gla:1924-2110
   float snoflow = 0.f;
@@ -394,7 +394,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     fpice = (s.sfctmp >= TFRZ) ? 0.f : 1.0f;
   }
   s.fpice = fpice;
-  float bdfall = fminf(120.f, 67.92f + 51.25f * nmp_expf((s.sfctmp - TFRZ) / 2.59f));
+  float bdfall = nmp_min(120.f, 67.92f + 51.25f * nmp_expf((s.sfctmp - TFRZ) / 2.59f));
   float qrain = s.prcp * (1.f - fpice);
   s.qsnow = s.prcp * fpice;
   float snowhin = s.qsnow / bdfall;
@@ -412,7 +412,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
       newnode = 1;
       y.dzsnso[L(0)] = s.snowh;
       s.snowh = 0.f;
-      y.stc[L(0)] = fminf(273.16f, s.sfctmp);
+      y.stc[L(0)] = nmp_min(273.16f, s.sfctmp);
       y.snice[L(0)] = s.sneqv;
       y.snliq[L(0)] = 0.f;
     }
@@ -459,7 +459,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
   replace = replace * 1000.0f / dt;
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    float si = fminf(1.0f, sice_save[L(k)]);
+    float si = nmp_min(1.0f, sice_save[L(k)]);
     y.sice[L(k)] = si;
     y.sh2o[L(k)] = 1.0f - si;
   }

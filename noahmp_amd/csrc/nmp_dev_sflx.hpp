@@ -62,11 +62,11 @@ NMP_DEV void phenology(const Ctx& c, Col& s) {
     s.lai = 0.f; s.sai = 0.f;
   }
   const float hvt = T->hvt[v], hvb = T->hvb[v];
-  float db = fminf(fmaxf(s.snowh - hvb, 0.f), hvt - hvb);
-  float fb = db / fmaxf(1.E-06f, hvt - hvb);
+  float db = nmp_min(nmp_max(s.snowh - hvb, 0.f), hvt - hvb);
+  float fb = db / nmp_max(1.E-06f, hvt - hvb);
   if (hvt > 0.f && hvt <= 1.0f) {
     float snowhc = hvt * nmp_expf(-s.snowh / 0.2f);
-    fb = fminf(s.snowh, snowhc) / snowhc;
+    fb = nmp_min(s.snowh, snowhc) / snowhc;
   }
   s.elai = s.lai * (1.f - fb);
   s.esai = s.sai * (1.f - fb);
@@ -111,10 +111,10 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float lfmsmn = laimin / lapm, stmsmn = xsamin / sapm;
   float rf = (s.igs == 0.f) ? 0.5f : 1.0f;
   float tv = s.tv;
-  float fnf = fminf(s.foln / fmaxf(1.E-06f, T->folnmx[v]), 1.0f);
+  float fnf = nmp_min(s.foln / nmp_max(1.E-06f, T->folnmx[v]), 1.0f);
   float tf = nmp_powf(T->arm[v], (tv - 298.16f) / 10.f);
   float resp = T->rmf25[v] * tf * fnf * s.lai * rf * (1.f - wstres);
-  float rsleaf = fminf(s.lfmass / dt, resp * 12.e-6f);
+  float rsleaf = nmp_min(s.lfmass / dt, resp * 12.e-6f);
   float rsroot = T->rmr25[v] * (s.rtmass * 1E-3f) * tf * rf * 12.e-6f;
   float rsstem = T->rms25[v] * (s.stmass * 1E-3f) * tf * rf * 12.e-6f;
   float rswood = rswoodc * nmp_expf(0.08f * (tv - 298.16f)) * s.wood * T->wdpool[v];
@@ -133,23 +133,23 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float sttovr = T->ltovrc[v] * 1.E-6f * s.stmass;
   float rttovr = rtovrc * s.rtmass;
   float wdtovr = 9.5E-10f * s.wood;
-  float sc = nmp_expf(-0.3f * fmaxf(0.f, tv - T->tdlef[v])) * (s.lfmass / 120.f);
+  float sc = nmp_expf(-0.3f * nmp_max(0.f, tv - T->tdlef[v])) * (s.lfmass / 120.f);
   float sd = nmp_expf((wstres - 1.f) * wstrc);
   float dielf = s.lfmass * 1.E-6f * (T->dilefw[v] * sd + T->dilefc[v] * sc);
   float diest = s.stmass * 1.E-6f * (T->dilefw[v] * sd + T->dilefc[v] * sc);
-  float grleaf = fmaxf(0.0f, T->fragr[v] * (leafpt * carbfx - rsleaf));
-  float grstem = fmaxf(0.0f, T->fragr[v] * (stempt * carbfx - rsstem));
-  float grroot = fmaxf(0.0f, T->fragr[v] * (rootpt * carbfx - rsroot));
-  float grwood = fmaxf(0.0f, T->fragr[v] * (woodpt * carbfx - rswood));
-  float addnpplf = fmaxf(0.f, leafpt * carbfx - grleaf - rsleaf);
-  float addnppst = fmaxf(0.f, stempt * carbfx - grstem - rsstem);
+  float grleaf = nmp_max(0.0f, T->fragr[v] * (leafpt * carbfx - rsleaf));
+  float grstem = nmp_max(0.0f, T->fragr[v] * (stempt * carbfx - rsstem));
+  float grroot = nmp_max(0.0f, T->fragr[v] * (rootpt * carbfx - rsroot));
+  float grwood = nmp_max(0.0f, T->fragr[v] * (woodpt * carbfx - rswood));
+  float addnpplf = nmp_max(0.f, leafpt * carbfx - grleaf - rsleaf);
+  float addnppst = nmp_max(0.f, stempt * carbfx - grstem - rsstem);
   if (tv < T->tmin[v]) { addnpplf = 0.f; addnppst = 0.f; }
   float lfdel = (s.lfmass - lfmsmn) / dt;
   float stdel = (s.stmass - stmsmn) / dt;
-  dielf = fminf(dielf, lfdel + addnpplf - lftovr);
-  diest = fminf(diest, stdel + addnppst - sttovr);
-  float nppl = fmaxf(addnpplf, -lfdel);
-  float npps = fmaxf(addnppst, -stdel);
+  dielf = nmp_min(dielf, lfdel + addnpplf - lftovr);
+  diest = nmp_min(diest, stdel + addnppst - sttovr);
+  float nppl = nmp_max(addnpplf, -lfdel);
+  float npps = nmp_max(addnppst, -stdel);
   float nppr = rootpt * carbfx - rsroot - grroot;
   float nppw = woodpt * carbfx - rswood - grwood;
   s.lfmass = s.lfmass + (nppl - lftovr - dielf) * dt;
@@ -160,7 +160,7 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   s.fastcp = s.fastcp + (rttovr + lftovr + sttovr + wdtovr + dielf) * dt;
   float fst = nmp_powf(2.0f, (y.stc[L(1)] - 283.16f) / 10.f);
   float fsw = wroot / (0.20f + wroot) * 0.23f / (0.23f + wroot);
-  float rssoil = fsw * fst * T->mrp[v] * fmaxf(0.f, s.fastcp * 1.E-3f) * 12.E-6f;
+  float rssoil = fsw * fst * T->mrp[v] * nmp_max(0.f, s.fastcp * 1.E-3f) * 12.E-6f;
   float stablc = 0.1f * rssoil;
   s.fastcp = s.fastcp - (rssoil + stablc) * dt;
   s.stblcp = s.stblcp + stablc * dt;
@@ -168,8 +168,8 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   s.npp = nppl + nppw + nppr;
   float autors = rsroot + rswood + rsleaf + grleaf + grroot + grwood;
   s.nee = (autors + rssoil - s.gpp) * 44.f / 12.f;
-  s.lai = fmaxf(s.lfmass * lapm, laimin);
-  s.sai = fmaxf(s.stmass * sapm, xsamin);
+  s.lai = nmp_max(s.lfmass * lapm, laimin);
+  s.sai = nmp_max(s.stmass * sapm, xsamin);
 }
 
 // NOAHMP_SFLX lsm:518-947 (with ATM lsm:949-1007 and ERROR lsm:1106-1228)
@@ -245,9 +245,9 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
 template <class A>
 NMP_DEV void sflx_water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float beg_wb) {
 #pragma unroll
-  for (int iz = 1; iz <= NSOIL; iz++) y.sice[L(iz)] = fmaxf(0.0f, y.smc[L(iz)] - y.sh2o[L(iz)]);
-  float qvap = fmaxf(s.fgev / s.latheag, 0.f);
-  float qdew = fabsf(fminf(s.fgev / s.latheag, 0.f));
+  for (int iz = 1; iz <= NSOIL; iz++) y.sice[L(iz)] = nmp_max(0.0f, y.smc[L(iz)] - y.sh2o[L(iz)]);
+  float qvap = nmp_max(s.fgev / s.latheag, 0.f);
+  float qdew = fabsf(nmp_min(s.fgev / s.latheag, 0.f));
   s.edir = qvap - qdew;
 
   NMP_TIC(12);   // water preamble

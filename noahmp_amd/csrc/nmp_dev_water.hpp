@@ -27,7 +27,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
     fpice = (sfctmp >= TFRZ) ? 0.f : 1.0f;
   }
   s.fpice = fpice;
-  float bdfall = fminf(120.f, 67.92f + 51.25f * nmp_expf((sfctmp - TFRZ) / 2.59f));
+  float bdfall = nmp_min(120.f, 67.92f + 51.25f * nmp_expf((sfctmp - TFRZ) / 2.59f));
   float rain = (s.qprecc + s.qprecl) * (1.f - fpice);
   float snow = (s.qprecc + s.qprecl) * fpice;
   if (s.qprecc + s.qprecl > 0.f) fp = (s.qprecc + s.qprecl) / (10.f * s.qprecc + s.qprecl);
@@ -35,55 +35,55 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   float maxliq = T->ch2op[v] * vai;
   if (vai > 0.f) {
     qintr = fveg * rain * fp;
-    qintr = fminf(qintr, (maxliq - s.canliq) / dt * (1.f - nmp_expf(-rain * dt / maxliq)));
-    qintr = fmaxf(qintr, 0.f);
+    qintr = nmp_min(qintr, (maxliq - s.canliq) / dt * (1.f - nmp_expf(-rain * dt / maxliq)));
+    qintr = nmp_max(qintr, 0.f);
     qdripr = fveg * rain - qintr;
     qthror = (1.f - fveg) * rain;
   } else {
     qintr = 0.f; qdripr = 0.f; qthror = rain;
   }
   if (!s.frozen_canopy) {
-    s.etran = fmaxf(s.fctr / HVAP, 0.f);
-    qevac = fmaxf(s.fcev / HVAP, 0.f);
-    qdewc = fabsf(fminf(s.fcev / HVAP, 0.f));
+    s.etran = nmp_max(s.fctr / HVAP, 0.f);
+    qevac = nmp_max(s.fcev / HVAP, 0.f);
+    qdewc = fabsf(nmp_min(s.fcev / HVAP, 0.f));
     qsubc = 0.f; qfroc = 0.f;
   } else {
-    s.etran = fmaxf(s.fctr / HSUB, 0.f);
+    s.etran = nmp_max(s.fctr / HSUB, 0.f);
     qevac = 0.f; qdewc = 0.f;
-    qsubc = fmaxf(s.fcev / HSUB, 0.f);
-    qfroc = fabsf(fminf(s.fcev / HSUB, 0.f));
+    qsubc = nmp_max(s.fcev / HSUB, 0.f);
+    qfroc = fabsf(nmp_min(s.fcev / HSUB, 0.f));
   }
-  qevac = fminf(s.canliq / dt, qevac);
-  s.canliq = fmaxf(0.f, s.canliq + (qintr + qdewc - qevac) * dt);
+  qevac = nmp_min(s.canliq / dt, qevac);
+  s.canliq = nmp_max(0.f, s.canliq + (qintr + qdewc - qevac) * dt);
   if (s.canliq <= 1.E-06f) s.canliq = 0.0f;
   float maxsno = 6.6f * (0.27f + 46.f / bdfall) * vai;
   if (vai > 0.f) {
     qints = fveg * snow * fp;
-    qints = fminf(qints, (maxsno - s.canice) / dt * (1.f - nmp_expf(-snow * dt / maxsno)));
-    qints = fmaxf(qints, 0.f);
-    float ft = fmaxf(0.0f, (s.tv - 270.15f) / 1.87E5f);
+    qints = nmp_min(qints, (maxsno - s.canice) / dt * (1.f - nmp_expf(-snow * dt / maxsno)));
+    qints = nmp_max(qints, 0.f);
+    float ft = nmp_max(0.0f, (s.tv - 270.15f) / 1.87E5f);
     float fv = sqrtf(s.uu * s.uu + s.vv * s.vv) / 1.56E5f;
-    qdrips = fmaxf(0.f, s.canice) * (fv + ft);
+    qdrips = nmp_max(0.f, s.canice) * (fv + ft);
     qthros = (1.0f - fveg) * snow + (fveg * snow - qints);
   } else {
     qints = 0.f; qdrips = 0.f; qthros = snow;
   }
-  qsubc = fminf(s.canice / dt, qsubc);
-  s.canice = fmaxf(0.f, s.canice + (qints - qdrips) * dt + (qfroc - qsubc) * dt);
+  qsubc = nmp_min(s.canice / dt, qsubc);
+  s.canice = nmp_max(0.f, s.canice + (qints - qdrips) * dt + (qfroc - qsubc) * dt);
   if (s.canice <= 1.E-6f) s.canice = 0.f;
-  if (s.canice > 0.f) s.fwet = fmaxf(0.f, s.canice) / fmaxf(maxsno, 1.E-06f);
-  else s.fwet = fmaxf(0.f, s.canliq) / fmaxf(maxliq, 1.E-06f);
-  s.fwet = nmp_powf(fminf(s.fwet, 1.f), 0.667f);
+  if (s.canice > 0.f) s.fwet = nmp_max(0.f, s.canice) / nmp_max(maxsno, 1.E-06f);
+  else s.fwet = nmp_max(0.f, s.canliq) / nmp_max(maxliq, 1.E-06f);
+  s.fwet = nmp_powf(nmp_min(s.fwet, 1.f), 0.667f);
   if (s.canice > 1.E-6f && s.tv > TFRZ) {
-    float qmeltc = fminf(s.canice / dt, (s.tv - TFRZ) * CICE * s.canice / DENICE / (dt * HFUS));
-    s.canice = fmaxf(0.f, s.canice - qmeltc * dt);
-    s.canliq = fmaxf(0.f, s.canliq + qmeltc * dt);
+    float qmeltc = nmp_min(s.canice / dt, (s.tv - TFRZ) * CICE * s.canice / DENICE / (dt * HFUS));
+    s.canice = nmp_max(0.f, s.canice - qmeltc * dt);
+    s.canliq = nmp_max(0.f, s.canliq + qmeltc * dt);
     s.tv = s.fwet * TFRZ + (1.f - s.fwet) * s.tv;
   }
   if (s.canliq > 1.E-6f && s.tv < TFRZ) {
-    float qfrzc = fminf(s.canliq / dt, (TFRZ - s.tv) * CWAT * s.canliq / DENH2O / (dt * HFUS));
-    s.canliq = fmaxf(0.f, s.canliq - qfrzc * dt);
-    s.canice = fmaxf(0.f, s.canice + qfrzc * dt);
+    float qfrzc = nmp_min(s.canliq / dt, (TFRZ - s.tv) * CWAT * s.canliq / DENH2O / (dt * HFUS));
+    s.canliq = nmp_max(0.f, s.canliq - qfrzc * dt);
+    s.canice = nmp_max(0.f, s.canice + qfrzc * dt);
     s.tv = s.fwet * TFRZ + (1.f - s.fwet) * s.tv;
   }
   s.ecan = qevac + qsubc - qdewc - qfroc;
@@ -135,7 +135,7 @@ NMP_DEV void combine(Col& s, const Lay<A>& y) {
           } else {
             s.ponding1 = y.snliq[L(j)] + y.snice[L(j)];
             if (s.ponding1 < 0.f) {
-              y.sice[L(1)] = fmaxf(0.0f, y.sice[L(1)] + s.ponding1 / (y.dzsnso[L(1)] * 1000.f));
+              y.sice[L(1)] = nmp_max(0.0f, y.sice[L(1)] + s.ponding1 / (y.dzsnso[L(1)] * 1000.f));
               s.ponding1 = 0.0f;
             }
             s.sneqv = 0.0f;
@@ -283,7 +283,7 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
       float void_ = 1.f - (snice / DENICE + snliq / DENH2O) / dz;
       if (void_ > 0.001f && snice > 0.1f) {
         float bi = snice / dz;
-        float td = fmaxf(0.f, TFRZ - y.stc[L(j)]);
+        float td = nmp_max(0.f, TFRZ - y.stc[L(j)]);
         float dexpf = nmp_expf(-C4 * td);
         float ddz1 = -C3 * dexpf, ddz3;
         if (bi > DM) ddz1 = ddz1 * nmp_expf(-46.0E-3f * (bi - DM));
@@ -291,13 +291,13 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
         float ddz2 = -(burden + 0.5f * wx) * nmp_expf(-0.08f * td - C2 * bi) / ETA0;
         if (y.imelt[L(j)] == 1.f) {
           float fo = y.ficeold[L(j)];
-          ddz3 = fmaxf(0.f, (fo - fice) / fmaxf(1.E-6f, fo));
+          ddz3 = nmp_max(0.f, (fo - fice) / nmp_max(1.E-6f, fo));
           ddz3 = -ddz3 / c.dt;
         } else {
           ddz3 = 0.f;
         }
         float pdzdtc = (ddz1 + ddz2 + ddz3) * c.dt;
-        pdzdtc = fmaxf(-0.5f, pdzdtc);
+        pdzdtc = nmp_max(-0.5f, pdzdtc);
         y.dzsnso[L(j)] = dz * (1.f + pdzdtc);
       }
       burden = burden + wx;
@@ -317,7 +317,7 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
     float temp = s.sneqv;
     s.sneqv = s.sneqv - qsnsub * dt + qsnfro * dt;
     float propor = s.sneqv / temp;
-    s.snowh = fmaxf(0.f, propor * s.snowh);
+    s.snowh = nmp_max(0.f, propor * s.snowh);
     if (s.sneqv < 0.f) {
       y.sice[L(1)] = y.sice[L(1)] + s.sneqv / (y.dzsnso[L(1)] * 1000.f);
       s.sneqv = 0.f; s.snowh = 0.f;
@@ -331,7 +331,7 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
     if (wgdif < 1.e-6f && s.isnow < 0) combine<GLAC>(s, y);
     if (s.isnow < 0) {
       float v = y.snliq[L(s.isnow + 1)] + qrain * dt;
-      y.snliq[L(s.isnow + 1)] = fmaxf(0.f, v);
+      y.snliq[L(s.isnow + 1)] = nmp_max(0.f, v);
     }
   }
   float vol_liq[3], vol_ice[3], epore[3];
@@ -340,9 +340,9 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
     vol_liq[j + 2] = 0.f; vol_ice[j + 2] = 0.f; epore[j + 2] = 0.f;
     if (j > s.isnow) {
       float dz = y.dzsnso[L(j)];
-      vol_ice[j + 2] = fminf(1.f, y.snice[L(j)] / (dz * DENICE));
+      vol_ice[j + 2] = nmp_min(1.f, y.snice[L(j)] / (dz * DENICE));
       epore[j + 2] = 1.f - vol_ice[j + 2];
-      vol_liq[j + 2] = fminf(epore[j + 2], y.snliq[L(j)] / (dz * DENH2O));
+      vol_liq[j + 2] = nmp_min(epore[j + 2], y.snliq[L(j)] / (dz * DENH2O));
     }
   }
   float qin = 0.f, qout = 0.f;
@@ -356,11 +356,11 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
         if (epore[j + 2] < 0.05f || epore[jp + 2] < 0.05f) {
           qout = 0.f;
         } else {
-          qout = fmaxf(0.f, (vol_liq[j + 2] - SSI * epore[j + 2]) * dz);
-          qout = fminf(qout, (1.f - vol_ice[jp + 2] - vol_liq[jp + 2]) * y.dzsnso[L(jp)]);
+          qout = nmp_max(0.f, (vol_liq[j + 2] - SSI * epore[j + 2]) * dz);
+          qout = nmp_min(qout, (1.f - vol_ice[jp + 2] - vol_liq[jp + 2]) * y.dzsnso[L(jp)]);
         }
       } else {
-        qout = fmaxf(0.f, (vol_liq[j + 2] - SSI * epore[j + 2]) * dz);
+        qout = nmp_max(0.f, (vol_liq[j + 2] - SSI * epore[j + 2]) * dz);
       }
       qout = qout * 1000.f;
       y.snliq[L(j)] = snl - qout;
@@ -406,7 +406,7 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
       newnode = 1;
       y.dzsnso[L(0)] = s.snowh;
       s.snowh = 0.f;
-      y.stc[L(0)] = fminf(273.16f, s.sfctmp);
+      y.stc[L(0)] = nmp_min(273.16f, s.sfctmp);
       y.snice[L(0)] = s.sneqv;
       y.snliq[L(0)] = 0.f;
     }
@@ -445,14 +445,14 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
 
 // WDFCND1 lsm:8329-8362 / WDFCND2 lsm:8364-8400
 NMP_DEV void wdfcnd1(const Parm& P, float& wdf, float& wcnd, float smc, float fcr) {
-  float factr = fmaxf(0.01f, smc / P.smcmax);
+  float factr = nmp_max(0.01f, smc / P.smcmax);
   wdf = P.dwsat * nmp_powf(factr, P.bexp + 2.0f);
   wdf = wdf * (1.0f - fcr);
   wcnd = P.dksat * nmp_powf(factr, 2.0f * P.bexp + 3.0f);
   wcnd = wcnd * (1.0f - fcr);
 }
 NMP_DEV void wdfcnd2(const Parm& P, float& wdf, float& wcnd, float smc, float sice) {
-  float factr = fmaxf(0.01f, smc / P.smcmax);
+  float factr = nmp_max(0.01f, smc / P.smcmax);
   float expon = P.bexp + 2.0f;
   wdf = P.dwsat * nmp_powf(factr, expon);
   if (sice > 0.0f) {
@@ -478,15 +478,15 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
   }
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    float epore = fmaxf(1.E-4f, (P.smcmax - sice[L(k)]));
-    rsat = rsat + fmaxf(0.f, sh2o[L(k)] - epore) * dz[L(k)];
-    sh2o[L(k)] = fminf(epore, sh2o[L(k)]);
+    float epore = nmp_max(1.E-4f, (P.smcmax - sice[L(k)]));
+    rsat = rsat + nmp_max(0.f, sh2o[L(k)] - epore) * dz[L(k)];
+    sh2o[L(k)] = nmp_min(epore, sh2o[L(k)]);
   }
   const float ea4 = nmp_expf(-4.0f);
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    float fice = fminf(1.0f, sice[L(k)] / P.smcmax);
-    fcr[L(k)] = fmaxf(0.0f, nmp_expf(-4.0f * (1.f - fice)) - ea4) / (1.0f - ea4);
+    float fice = nmp_min(1.0f, sice[L(k)] / P.smcmax);
+    fcr[L(k)] = nmp_max(0.0f, nmp_expf(-4.0f * (1.f - fice)) - ea4) / (1.0f - ea4);
     if (sice[L(k)] > sicemax) sicemax = sice[L(k)];
     if (fcr[L(k)] > fcrmax) fcrmax = fcr[L(k)];
   }
@@ -510,7 +510,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
   if (c.O.run == 1 || c.O.run == 2 || c.O.run == 4 || c.O.run == 5) {
     float fsat;
     if (c.O.run == 1) fsat = FSATMX * nmp_expf(-0.5f * 6.0f * (s.zwt - 2.0f));
-    else if (c.O.run == 5) fsat = FSATMX * nmp_expf(-0.5f * 6.0f * fmaxf(-2.0f - s.zwt, 0.f));
+    else if (c.O.run == 5) fsat = FSATMX * nmp_expf(-0.5f * 6.0f * nmp_max(-2.0f - s.zwt, 0.f));
     else if (c.O.run == 2) fsat = FSATMX * nmp_expf(-0.5f * 2.0f * s.zwt);
     else {
       float smctot = 0.f, dztot = 0.f;
@@ -524,7 +524,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
         }
       }
       smctot = smctot / dztot;
-      fsat = nmp_powf(fmaxf(0.01f, smctot / P.smcmax), 4.f);
+      fsat = nmp_powf(nmp_max(0.01f, smctot / P.smcmax), 4.f);
     }
     if (qinsur > 0.f) {
       s.runsrf = qinsur * ((1.0f - fcr[L(1)]) * fsat + fcr[L(1)]);
@@ -549,7 +549,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       }
       float val = (1.f - nmp_expf(-P.kdt * dt1));
       float ddt = dd * val;
-      float px = fmaxf(0.f, qinsur * dt);
+      float px = nmp_max(0.f, qinsur * dt);
       float infmax = (px * (ddt / (px + ddt))) / dt;
       float fcr_ = 1.f;
       if (dice > 1.E-2f) {
@@ -562,9 +562,9 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       infmax = infmax * fcr_;
       float wdf_, wcnd_;
       wdfcnd2(P, wdf_, wcnd_, sh2o[L(1)], sicemax);
-      infmax = fmaxf(infmax, wcnd_);
-      infmax = fminf(infmax, px);
-      s.runsrf = fmaxf(0.f, qinsur - infmax);
+      infmax = nmp_max(infmax, wcnd_);
+      infmax = nmp_min(infmax, px);
+      s.runsrf = nmp_max(0.f, qinsur - infmax);
       pddum = qinsur - s.runsrf;
     }
   }
@@ -665,9 +665,9 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
         s.deeprech = s.deeprech + dtf * qdrain;
       } else {
         s.smcwtd = s.smcwtd + dtf * qdrain / dz[L(NSOIL)];
-        wplus = fmaxf((s.smcwtd - P.smcmax), 0.0f) * dz[L(NSOIL)];
-        float wminus = fmaxf((1.E-4f - s.smcwtd), 0.0f) * dz[L(NSOIL)];
-        s.smcwtd = fmaxf(fminf(s.smcwtd, P.smcmax), 1.E-4f);
+        wplus = nmp_max((s.smcwtd - P.smcmax), 0.0f) * dz[L(NSOIL)];
+        float wminus = nmp_max((1.E-4f - s.smcwtd), 0.0f) * dz[L(NSOIL)];
+        s.smcwtd = nmp_max(nmp_min(s.smcwtd, P.smcmax), 1.E-4f);
         sh2o[L(NSOIL)] = sh2o[L(NSOIL)] + wplus / dz[L(NSOIL)];
         qdrain = qdrain - wplus / dtf;
         s.deeprech = s.deeprech - wminus;
@@ -675,15 +675,15 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     }
 #pragma unroll
     for (int k = NSOIL; k >= 2; k--) {
-      float epore = fmaxf(1.E-4f, (P.smcmax - sice[L(k)]));
-      wplus = fmaxf((sh2o[L(k)] - epore), 0.0f) * dz[L(k)];
-      sh2o[L(k)] = fminf(epore, sh2o[L(k)]);
+      float epore = nmp_max(1.E-4f, (P.smcmax - sice[L(k)]));
+      wplus = nmp_max((sh2o[L(k)] - epore), 0.0f) * dz[L(k)];
+      sh2o[L(k)] = nmp_min(epore, sh2o[L(k)]);
       sh2o[L(k - 1)] = sh2o[L(k - 1)] + wplus / dz[L(k - 1)];
     }
     {
-      float epore = fmaxf(1.E-4f, (P.smcmax - sice[L(1)]));
-      wplus = fmaxf((sh2o[L(1)] - epore), 0.0f) * dz[L(1)];
-      sh2o[L(1)] = fminf(epore, sh2o[L(1)]);
+      float epore = nmp_max(1.E-4f, (P.smcmax - sice[L(1)]));
+      wplus = nmp_max((sh2o[L(1)] - epore), 0.0f) * dz[L(1)];
+      sh2o[L(1)] = nmp_min(epore, sh2o[L(1)]);
     }
 #pragma unroll
     for (int k = 1; k <= NSOIL; k++) smc[L(k)] = sh2o[L(k)] + sice[L(k)];
@@ -743,7 +743,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     float sh = y.sh2o[L(iz)], si = y.sice[L(iz)];
     smc[L(iz)] = sh + si;
     mliq[L(iz)] = sh * dzmm[L(iz)];
-    epore[L(iz)] = fmaxf(0.01f, P.smcmax - si);
+    epore[L(iz)] = nmp_max(0.01f, P.smcmax - si);
     hk[L(iz)] = 1.E3f * wcnd[L(iz)];
   }
   int iwt = NSOIL;
@@ -757,22 +757,22 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
   float smc_iwt = (iwt == 1) ? smc[L(1)] : (iwt == 2) ? smc[L(2)] : (iwt == 3) ? smc[L(3)] : smc[L(4)];
   float hk_iwt = (iwt == 1) ? hk[L(1)] : (iwt == 2) ? hk[L(2)] : (iwt == 3) ? hk[L(3)] : hk[L(4)];
   float zn_iwt = (iwt == 1) ? znode[L(1)] : (iwt == 2) ? znode[L(2)] : (iwt == 3) ? znode[L(3)] : znode[L(4)];
-  double s_node = fminf(1.0f, smc_iwt / P.smcmax);
+  double s_node = nmp_min(1.0f, smc_iwt / P.smcmax);
   s_node = (s_node > (double)0.01f) ? s_node : (double)0.01f;
   float smpfz = (float)(-((double)(P.psisat * 1000.f) * pow(s_node, (double)(-P.bexp))));
-  smpfz = fmaxf(-120000.0f, CMIC * smpfz);
+  smpfz = nmp_max(-120000.0f, CMIC * smpfz);
   float wh_zwt = -s.zwt * 1.E3f;
   float wh = smpfz - zn_iwt * 1.E3f;
   float qin = -hk_iwt * (wh_zwt - wh) / ((s.zwt - zn_iwt) * 1.E3f);
-  qin = fmaxf(-10.0f / dt, fminf(10.f / dt, qin));
+  qin = nmp_max(-10.0f / dt, nmp_min(10.f / dt, qin));
   s.wt = s.wt + (qin - qdis) * dt;
   if (iwt == NSOIL) {
     s.wa = s.wa + (qin - qdis) * dt;
     s.wt = s.wa;
     s.zwt = (-c.zsoil[L(NSOIL)] + 25.f) - s.wa / 1000.f / ROUS;
     mliq[L(NSOIL)] = mliq[L(NSOIL)] - qin * dt;
-    mliq[L(NSOIL)] = mliq[L(NSOIL)] + fmaxf(0.f, (s.wa - 5000.f));
-    s.wa = fminf(s.wa, 5000.f);
+    mliq[L(NSOIL)] = mliq[L(NSOIL)] + nmp_max(0.f, (s.wa - 5000.f));
+    s.wa = nmp_min(s.wa, 5000.f);
   } else {
     if (iwt == NSOIL - 1) {
       s.zwt = -c.zsoil[L(NSOIL)] - (s.wt - ROUS * 1000 * 25.f) / (epore[L(NSOIL)]) / 1000.f;
@@ -791,7 +791,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
 #pragma unroll
     for (int iz = 1; iz <= NSOIL; iz++) mliq[L(iz)] = mliq[L(iz)] - qdis * dt * hk[L(iz)] * dzmm[L(iz)] / wtsub;
   }
-  s.zwt = fmaxf(1.5f, s.zwt);
+  s.zwt = nmp_max(1.5f, s.zwt);
   float xs;
   const float watmin = 0.01f;
 #pragma unroll
@@ -837,13 +837,13 @@ NMP_DEV void shallowwatertable(const Ctx& c, const Parm& P, Col& s, const Lay<A>
         if (kwtd >= 1) {
           if (smc[L(kwtd)] > smceq[L(kwtd)]) {
             wtdold = wtd;
-            wtd = fminf((smc[L(kwtd)] * dzs[L(kwtd)] - smceq[L(kwtd)] * zsoil0[L(iwtd)] +
+            wtd = nmp_min((smc[L(kwtd)] * dzs[L(kwtd)] - smceq[L(kwtd)] * zsoil0[L(iwtd)] +
                          P.smcmax * zsoil0[L(kwtd)]) / (P.smcmax - smceq[L(kwtd)]), zsoil0[L(iwtd)]);
             s.rech = s.rech - (wtdold - wtd) * (P.smcmax - smceq[L(kwtd)]);
           }
         }
       } else {
-        wtd = fminf((smc[L(kwtd)] * dzs[L(kwtd)] - smceq[L(kwtd)] * zsoil0[L(iwtd)] +
+        wtd = nmp_min((smc[L(kwtd)] * dzs[L(kwtd)] - smceq[L(kwtd)] * zsoil0[L(iwtd)] +
                      P.smcmax * zsoil0[L(kwtd)]) / (P.smcmax - smceq[L(kwtd)]), zsoil0[L(iwtd)]);
         s.rech = -(wtdold - wtd) * (P.smcmax - smceq[L(kwtd)]);
       }
@@ -855,7 +855,7 @@ NMP_DEV void shallowwatertable(const Ctx& c, const Parm& P, Col& s, const Lay<A>
       if (kwtd <= NSOIL) {
         wtdold = wtd;
         if (smc[L(kwtd)] > smceq[L(kwtd)])
-          wtd = fminf((smc[L(kwtd)] * dzs[L(kwtd)] - smceq[L(kwtd)] * zsoil0[L(iwtd)] +
+          wtd = nmp_min((smc[L(kwtd)] * dzs[L(kwtd)] - smceq[L(kwtd)] * zsoil0[L(iwtd)] +
                        P.smcmax * zsoil0[L(kwtd)]) / (P.smcmax - smceq[L(kwtd)]), zsoil0[L(iwtd)]);
         else
           wtd = zsoil0[L(kwtd)];
@@ -863,7 +863,7 @@ NMP_DEV void shallowwatertable(const Ctx& c, const Parm& P, Col& s, const Lay<A>
       } else {
         wtdold = wtd;
         float smceqdeep = P.smcmax * nmp_powf(-P.psisat / (-P.psisat - dzn), 1.f / P.bexp);
-        wtd = fminf((s.smcwtd * dzn - smceqdeep * zsoil0[L(NSOIL)] + P.smcmax * (zsoil0[L(NSOIL)] - dzn)) /
+        wtd = nmp_min((s.smcwtd * dzn - smceqdeep * zsoil0[L(NSOIL)] + P.smcmax * (zsoil0[L(NSOIL)] - dzn)) /
                     (P.smcmax - smceqdeep), zsoil0[L(NSOIL)]);
         s.rech = s.rech - (wtdold - wtd) * (P.smcmax - smceqdeep);
       }
@@ -872,7 +872,7 @@ NMP_DEV void shallowwatertable(const Ctx& c, const Parm& P, Col& s, const Lay<A>
     wtdold = wtd;
     float smceqdeep = P.smcmax * nmp_powf(-P.psisat / (-P.psisat - dzn), 1.f / P.bexp);
     if (s.smcwtd > smceqdeep) {
-      wtd = fminf((s.smcwtd * dzn - smceqdeep * zsoil0[L(NSOIL)] + P.smcmax * (zsoil0[L(NSOIL)] - dzn)) /
+      wtd = nmp_min((s.smcwtd * dzn - smceqdeep * zsoil0[L(NSOIL)] + P.smcmax * (zsoil0[L(NSOIL)] - dzn)) /
                   (P.smcmax - smceqdeep), zsoil0[L(NSOIL)]);
       s.rech = -(wtdold - wtd) * (P.smcmax - smceqdeep);
     } else {
@@ -896,7 +896,7 @@ NMP_DEV void water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float q
   s.runsub = 0.f;
   canwater(c, s, qrain, snowhin);
   float qsnsub = 0.f;
-  if (s.sneqv > 0.f) qsnsub = fminf(qvap, s.sneqv / dt);
+  if (s.sneqv > 0.f) qsnsub = nmp_min(qvap, s.sneqv / dt);
   float qseva = qvap - qsnsub;
   float qsnfro = 0.f;
   if (s.sneqv > 0.f) qsnfro = qdew;
