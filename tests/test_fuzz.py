@@ -1,0 +1,30 @@
+"""Randomised parity (tools/fuzz_parity.py): broad random states and forcing over every USGS category, cold start + 3 steps, every
+output bit for bit (NaN-carrying columns included).  CPU: the device source compiled for the host vs the C restatement, and the
+restatement vs the compiled reference where oracle/_ref exists; GPU: the HIP engine vs the restatement."""
+import pytest
+
+from tools import fuzz_parity
+
+OPTS = [dict(), dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_sfc=2, iopt_frz=2), dict(iopt_run=5, idveg=3),
+        dict(iopt_rad=1, iopt_alb=1, iopt_snf=3, iopt_tbot=1, idveg=5, iopt_crs=2, iopt_btr=2, iopt_inf=2)]
+
+
+@pytest.mark.parametrize("kw", OPTS, ids=[repr(k) for k in OPTS])
+def test_device_source_on_host_vs_oracle_random(port, kw):
+    assert fuzz_parity.one_seed("emul", 101, 1536, kw) == 0
+
+
+@pytest.mark.parametrize("kw", OPTS[:2], ids=[repr(k) for k in OPTS[:2]])
+def test_oracle_vs_compiled_reference_random(reflib, port, kw, tmp_path):
+    import subprocess
+    import sys
+    # own process: the reference STOPs the process on a fatal column
+    rc = subprocess.call([sys.executable, fuzz_parity.__file__, "ref", "1", "1536"] + ["%s=%d" % kv for kv in kw.items()] +
+                         ["--seed:202"])
+    assert rc == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", OPTS, ids=[repr(k) for k in OPTS])
+def test_gpu_vs_oracle_random(engine, port, kw):
+    assert fuzz_parity.one_seed("gpu", 303, 4096, kw) == 0
