@@ -98,6 +98,14 @@ NMP_DEV void scatter_energy_outputs(const KArgs& k, const Col& s, size_t ij) {
   G2(chv2xy) = s.chv2; G2(chb2xy) = s.chb2;
 }
 
+// The part of the gather (drv:449-545) that only WATER, CARBON and the final pass-through scatter read.
+NMP_DEV void gather_water_state(const KArgs& k, Col& s, size_t ij) {
+  s.wslake = G2(wslakexy); s.zwt = G2(zwtxy); s.wt = G2(wtxy);
+  s.lfmass = G2(lfmassxy); s.rtmass = G2(rtmassxy); s.stmass = G2(stmassxy); s.wood = G2(woodxy);
+  s.stblcp = G2(stblcpxy); s.fastcp = G2(fastcpxy);
+  s.smcwtd = G2(smcwtdxy);
+}
+
 // Gather -> REDPRM -> NOAHMP_SFLX | NOAHMP_GLACIER -> scatter for one land / glacier column.
 // Returns the column's status word (0 = ok).  A column that fails before or inside the ENERGY phase is
 // left untouched; one that fails the closing water-balance check has already stored its energy-phase
@@ -153,10 +161,10 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   s.tv = G2(tvxy); s.tg = G2(tgxy); s.canliq = G2(canliqxy); s.canice = G2(canicexy);
   s.eah = G2(eahxy); s.tah = G2(tahxy); s.cm = G2(cmxy); s.ch = G2(chxy); s.fwet = G2(fwetxy);
   s.sneqvo = G2(sneqvoxy); s.albold = G2(alboldxy); s.qsnow = G2(qsnowxy);
-  s.wslake = G2(wslakexy); s.zwt = G2(zwtxy); s.wa = G2(waxy); s.wt = G2(wtxy);
-  s.lfmass = G2(lfmassxy); s.rtmass = G2(rtmassxy); s.stmass = G2(stmassxy); s.wood = G2(woodxy);
-  s.stblcp = G2(stblcpxy); s.fastcp = G2(fastcpxy); s.lai = G2(xlaixy); s.sai = G2(xsaixy);
-  s.tauss = G2(taussxy); s.smcwtd = G2(smcwtdxy);
+  s.lai = G2(xlaixy); s.sai = G2(xsaixy);
+  s.tauss = G2(taussxy); s.wa = G2(waxy);                  // WA enters the water balance taken at the start (lsm:703)
+  // WSLAKE, ZWT, WT, SMCWTD and the carbon pools are first read by the WATER / CARBON phase: they are gathered there
+  // (gather_water_state), not here, so that they do not occupy registers (or scratch) through the ENERGY phase
   s.rech = 0.f; s.deeprech = 0.f;
   s.co2air = 395.e-06f * s.sfcprs;
   s.o2air = 0.209f * s.sfcprs;
@@ -178,6 +186,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   float qfx_out = 0.f, lh_out = 0.f;
   if (cls == 1 && !failed) {
     s.tbot = nmp_min(s.tbot, 263.15f);                                               // drv:555
+    gather_water_state(k, s, ij);              // passed through, or overwritten by glacier_fill_undefined (drv:571-625)
     glacier(k.c, s, y);
     if (s.err) failed = s.err;
     else {
@@ -196,6 +205,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
       else {
         lh_out = s.fcev + s.fgev + s.fctr;                                         // drv:714
         scatter_energy_outputs(k, s, ij);
+        gather_water_state(k, s, ij);
         NMP_TIC(11);   // energy tail + early scatter
         sflx_water(k.c, P, s, y, beg_wb);
         beg_wb_trunc = beg_wb;
