@@ -124,6 +124,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   Parm P = {};
   bool live = (cls == 0);          // advances through NOAHMP_SFLX
   int failed = 0;
+  int soiltyp_w = 1;               // the validated soil type, kept for redprm_water
   NMP_TIC0();
   if (cls <= 1) {
   // ---- gather, drv:449-545
@@ -176,6 +177,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }
   NMP_TIC(0);    // gather
   redprm(k.c, s, P, vegtyp, soiltyp);
+  soiltyp_w = soiltyp;
   NMP_TIC(1);    // redprm
   s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
   if (s.err) { failed = s.err; live = false; }                                     // REDPRM fatals, lsm:9266-9344
@@ -206,6 +208,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
         lh_out = s.fcev + s.fgev + s.fctr;                                         // drv:714
         scatter_energy_outputs(k, s, ij);
         gather_water_state(k, s, ij);
+        redprm_water(k.c, P, soiltyp_w);
         NMP_TIC(11);   // energy tail + early scatter
         sflx_water(k.c, P, s, y, beg_wb);
         beg_wb_trunc = beg_wb;

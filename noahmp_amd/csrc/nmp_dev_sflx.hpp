@@ -14,8 +14,6 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   const int st = soiltyp - 1, vt = vegtyp - 1;
   P.csoil = T->csoil_data;
   P.bexp = T->bb[st];
-  P.dksat = T->satdk[st];
-  P.dwsat = T->satdw[st];
   P.psisat = T->satpsi[st];
   P.quartz = T->qtz[st];
   P.smcmax = T->maxsmc[st];
@@ -24,9 +22,6 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   if (vegtyp == c.isurban) { P.smcmax = 0.45f; P.smcref = 0.42f; P.smcwlt = 0.40f; P.csoil = 3.E6f; }
   P.zbot = T->zbot_data;
   P.czil = T->czil_data;
-  P.kdt = T->refkdt_data * P.dksat / T->refdk_data;
-  P.slope = T->slope_data[0];                         // SLOPETYP = 1 (drv:525)
-  P.frzx = T->frzk_data * ((P.smcmax / P.smcref) * (0.412f / 0.468f));
   P.topt = T->topt_data;
   P.rgl = T->rgltbl[vt];
   P.rsmax = T->rsmax_data;
@@ -35,6 +30,19 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   P.nroot = T->nrotbl[vt];
   if (vegtyp == c.isurban) P.rsmin = 400.0f;
   if (P.nroot > NSOIL) { raise(s, NOAHMP_ERR_NROOT_GT_NSOIL); P.nroot = NSOIL; }
+}
+
+// The REDPRM outputs only the WATER phase reads (DKSAT, DWSAT, KDT, SLOPE, FRZX; lsm:9286-9287, 9316-9322): looked up when
+// that phase starts, so that they do not sit in registers through ENERGY.  `soiltyp` as REDPRM validated it.
+NMP_DEV void redprm_water(const Ctx& c, Parm& P, int soiltyp) {
+  const noahmp_tables* T = c.T;
+  if (soiltyp > T->slcats || soiltyp < 1) soiltyp = 1;
+  const int st = soiltyp - 1;
+  P.dksat = T->satdk[st];
+  P.dwsat = T->satdw[st];
+  P.kdt = T->refkdt_data * P.dksat / T->refdk_data;
+  P.slope = T->slope_data[0];                         // SLOPETYP = 1 (drv:525)
+  P.frzx = T->frzk_data * ((P.smcmax / P.smcref) * (0.412f / 0.468f));
 }
 
 // PHENOLOGY lsm:1010-1104
