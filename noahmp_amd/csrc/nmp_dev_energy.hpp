@@ -471,8 +471,11 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
   float vcmx = T->vcmx25[v] / (1.0f + st.vcmx_t) * fnf * btran * avcmx_pow;
   float rlb = rb / cf;
   float cihi = 1.5f * co2, cilow = 0.0f;
+#ifndef NMP_EXP_STOMATA_ITERS
+#define NMP_EXP_STOMATA_ITERS 20       // profiling variants only (tools): fewer bisection steps = wrong results, for timing
+#endif
 #pragma unroll 1
-  for (int iter = 1; iter <= 20; iter++) {
+  for (int iter = 1; iter <= NMP_EXP_STOMATA_ITERS; iter++) {
     float ci = 0.5f * (cihi + cilow);
     float wj = nmp_max(ci - cp, 0.0f) * j / (ci + 2.0f * cp) * c3 + j * (1.f - c3);
     float wc = nmp_max(ci - cp, 0.0f) * vcmx / (ci + awc) * c3 + vcmx * (1.f - c3);
