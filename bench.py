@@ -173,12 +173,18 @@ def main():
         k_avg_ms = kernel_ms / args.steps
         achieved = ALG_BYTES_PER_COLSTEP * (n_land / args.steps) / (k_avg_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
             try:
                 prof = json.load(open(tpath))
                 # PMC counters come from a separate rocprofv3 --pmc pass of this very workload (tools/run_profile.sh)
-                traffic = prof.get("hbm_bytes_per_launch") if prof.get("columns_per_launch") == ncol else None
+                same = prof.get("columns_per_launch") == ncol
+                traffic = prof.get("hbm_bytes_per_launch") if same else None
+                dv = prof.get("derived") if same else None
+                if dv:      # what actually binds this kernel (same PMC passes): VALU issue, 2 waves per SIMD
+                    valu = {"insts_per_column_step": dv["valu_insts_per_column_step"], "lane_utilisation": dv["lane_utilisation"],
+                            "simd_issue_utilisation": 2.0 * dv["valu_active_share_of_wave_cycles"], "waves_per_simd": 2}
             except Exception:
                 traffic = None
         out = {
@@ -194,7 +200,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "noahmp_column_kernel", "kernel_ms_avg": k_avg_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * ncol,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * ncol, "valu": valu,
                          "note": "824 B/column-step x columns / HIP-event kernel time; the kernel is VALU-issue and "
                                  "divergence bound (24 k VALU instructions per column-step wave, 90 % lane utilisation: "
                                  "profiles/r01_profile.md), not HBM bound (SURVEY 8d)"},
