@@ -20,6 +20,7 @@ struct KArgs {
   int* counts;               // [0]=land [1]=glacier [2]=skipped
   unsigned long long err_base;   // step ordinal << 40 for asynchronous stepping (0 otherwise)
   long t_offset;                 // tile index of this launch's first column when a tile is advanced in row chunks
+  long t_first, t_count;         // class-range launches (sorted layout): this launch covers tile indices [t_first, t_first + t_count)
 };
 
 constexpr int LAY_SLOTS = 4 * 7 + 5 * 4 + 3 * 3;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold
@@ -115,7 +116,8 @@ NMP_DEV void gather_water_state(const KArgs& k, Col& s, size_t ij) {
 // lets a runner synchronise the workgroup, which is why threads without a column (cls == 2) may call this
 // function too and every phase is guarded by `live`; see DESIGN.md section 6 for the lane-compaction runner that
 // was measured and dropped.
-template <int STRIDE, class Runner>
+// MODE 0: any mix of land and glacier columns; 1: land columns only (no glacier code in the kernel); 2: glacier columns only.
+template <int STRIDE, int MODE = 0, class Runner>
 NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base, Runner& runner) {
   Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
   // value-initialise (NOT memset(): HIP's device memset is a byte loop through a pointer PHI, which
@@ -186,6 +188,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   if (NMP_TRUNC == 1) live = false;
 
   float qfx_out = 0.f, lh_out = 0.f;
+  if constexpr (MODE != 1)
   if (cls == 1 && !failed) {
     s.tbot = nmp_min(s.tbot, 263.15f);                                               // drv:555
     gather_water_state(k, s, ij);              // passed through, or overwritten by glacier_fill_undefined (drv:571-625)
@@ -198,7 +201,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
     }
   }
   float beg_wb_trunc = 0.f;
-  {
+  if constexpr (MODE != 2) {
     float beg_wb = 0.f;
     sflx_energy(k.c, P, s, y, beg_wb, live, runner);                               // all threads (see above)
     if (NMP_TRUNC && NMP_TRUNC <= 8) live = false;

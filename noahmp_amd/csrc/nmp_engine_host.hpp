@@ -57,6 +57,7 @@ struct Engine {
   bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
   std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call
   noahmp_step_args resident_args;                        // the argument block of that call (for fetch)
+  long sorted_land = -1, sorted_glacier = -1;   // class ranges of a sorted device-resident layout (-1: not declared)
   int block = 256;             // 4 waves per workgroup: ~1 % faster than 64 at 1 M columns (bench); 64 and 128 selectable
   int use_lds = 1;
   std::string last_error;

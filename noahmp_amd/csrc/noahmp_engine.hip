@@ -26,18 +26,22 @@ namespace {
 #endif
 
 // One thread = one column-step (the ILOOP body, drv:424-837).
-template <int BLOCK, bool USE_LDS>
+// MODE 0: the tile as it is (any mix of classes).  MODE 1 / 2 / 3: a range of a class-sorted layout that holds only land /
+// only glacier / only skipped (open water, sea ice) columns -- kernels without the other classes' code; a column of another
+// class in such a range raises NOAHMP_ERR_CLASS_RANGE (its class changed since the sort, e.g. sea ice: sort again).
+template <int BLOCK, bool USE_LDS, int MODE = 0>
 __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(const KArgs k) {
   constexpr int STRIDE = USE_LDS ? BLOCK : 1;
-  __shared__ float lds[USE_LDS ? LAY_SLOTS * BLOCK : 1];
-  float priv[USE_LDS ? 1 : LAY_SLOTS];
+  __shared__ float lds[(USE_LDS && MODE != 3) ? LAY_SLOTS * BLOCK : 1];
+  float priv[(USE_LDS || MODE == 3) ? 1 : LAY_SLOTS];
   float* base = USE_LDS ? (lds + threadIdx.x) : priv;
 
-  libm::libm_stage_tables();
-  const long t = (long)blockIdx.x * BLOCK + threadIdx.x;
+  if (MODE != 3) libm::libm_stage_tables();
+  const long tl = (long)blockIdx.x * BLOCK + threadIdx.x;
+  const long t = k.t_first + tl;
   int ii = 0, jj = 0;
   size_t ij = 0;
-  const int cls = column_classify(k, t, ii, jj, ij);
+  const int cls = (MODE != 0 && tl >= k.t_count) ? 3 : column_classify(k, t, ii, jj, ij);
   {                                           // per-wave tallies (64-wide wavefront)
     unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if ((threadIdx.x & 63) == 0) {
@@ -47,9 +51,13 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
       if (m2) atomicAdd(&cnt[2], __popcll(m2));
     }
   }
-  if (cls > 1) return;
+  if (MODE != 0 && cls != 3 && cls != MODE - 1) {       // not the class this range was declared to hold
+    atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)NOAHMP_ERR_CLASS_RANGE);
+    return;
+  }
+  if (cls > 1 || MODE == 3) return;
   SimpleLoop runner;
-  const int err = column_step<STRIDE>(k, cls, ii, jj, ij, base, runner);
+  const int err = column_step<STRIDE, (MODE == 3 ? 0 : MODE)>(k, cls, ii, jj, ij, base, runner);
   if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)err);   // first column wins
 }
 
@@ -197,6 +205,8 @@ int noahmp_hip_set_option(const char* key, int value) {
     prev = g.trust_out_mirror;
     if (value == 0 || value == 1) { g.trust_out_mirror = value; g.out_mirror_valid = false; }
   }
+  else if (!strcmp(key, "sorted_land_columns")) { prev = (int)g.sorted_land; g.sorted_land = value; }
+  else if (!strcmp(key, "sorted_glacier_columns")) { prev = (int)g.sorted_glacier; g.sorted_glacier = value; }
   else if (!strcmp(key, "resident_state")) {
     prev = g.resident_state;
     if (value == 0 || value == 1) {
@@ -242,9 +252,24 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
   k.a.dzs = nullptr;
 }
 
+template <int MODE>
+static void launch_range(KArgs k, long first, long count, hipStream_t s) {
+  if (count <= 0) return;
+  k.t_first = first; k.t_count = count;
+  hipLaunchKernelGGL((noahmp_column_kernel<256, true, MODE>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k);
+}
+
 static void launch_any(const KArgs& k, hipStream_t s) {
   const long ncol = (long)k.nti * k.ntj;
   if (ncol <= 0) return;
+  // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
+  if (g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
+      g.block == 256 && g.use_lds) {
+    launch_range<1>(k, 0, g.sorted_land, s);
+    launch_range<2>(k, g.sorted_land, g.sorted_glacier, s);
+    launch_range<3>(k, g.sorted_land + g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s);
+    return;
+  }
   if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
   else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
   else launch<64>(k, ncol, g.use_lds, s);
@@ -657,6 +682,7 @@ void noahmp_hip_finalize(void) {
   for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& b : g.mirror_bytes) b = 0;
   g.resident_valid = false; g.resident_dirty = false; g.mirror_host.clear();
+  g.sorted_land = -1; g.sorted_glacier = -1;
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto e : g.async_events) hipEventDestroy(e);

@@ -43,6 +43,14 @@ class Engine:
     def set_option(self, key, value):
         return self.lib.noahmp_hip_set_option(key.encode(), int(value))
 
+    def _apply_ranges(self, ranges):
+        """Declare (or withdraw) the class ranges of the store about to be stepped (set_option sorted_*_columns)."""
+        if ranges != getattr(self.lib, "_ranges_set", None):          # the engine is one per process: remember it on the library
+            n0, n1 = ranges if ranges else (-1, -1)
+            self.lib.noahmp_hip_set_option(b"sorted_land_columns", int(n0))
+            self.lib.noahmp_hip_set_option(b"sorted_glacier_columns", int(n1))
+            self.lib._ranges_set = ranges
+
     def fetch(self):
         """Bring the host arrays of a resident run ("resident_state" + "lazy_download") up to date."""
         rc = self.lib.noahmp_hip_fetch(None)
@@ -52,6 +60,7 @@ class Engine:
     def noahmplsm(self, store, itimestep, yr, julian, stream=None, check=True):
         a = store.step_args(itimestep, yr, julian)
         mem = abi.MEM_DEVICE if isinstance(store, DeviceColumnStore) else abi.MEM_HOST
+        self._apply_ranges(a._ranges if mem == abi.MEM_DEVICE else None)
         st = abi.Status()
         rc = self.lib.noahmp_hip_step(C.byref(a), mem, stream, C.byref(st))
         self.last_status = st
@@ -172,6 +181,8 @@ class Engine:
             tsk = np.nan_to_num(store.a["tsk"].cpu().numpy().ravel().astype(np.float64), nan=250.0)
             key = key * 256 + np.clip(((tsk - 230.0) / tsk_bin).astype(np.int64), 0, 255)
         perm = torch.from_numpy(np.argsort(key, kind="stable").astype(np.int32)).to(store.device)
+        # classes are contiguous now: land, land ice, skipped -- each range gets its own kernel (noahmp_engine.hip, launch_any)
+        store.class_ranges = (int((cls == 0).sum()), int((cls == 1).sum()))
         names = [k for k, v in store.a.items() if not isinstance(v, np.ndarray)]
         for i in range(0, len(names), 32):
             chunk = names[i:i + 32]
@@ -235,6 +246,7 @@ class Engine:
     # ---- asynchronous stepping (device-resident state only)
     def noahmplsm_async(self, args, stream=None):
         """Enqueue one step described by a prepared StepArgs block (store.step_args(...), device pointers)."""
+        self._apply_ranges(getattr(args, "_ranges", None))
         rc = self.lib.noahmp_hip_step_async(C.byref(args), stream)
         if rc:
             raise RuntimeError("noahmp_hip_step_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))

@@ -158,6 +158,7 @@ class ColumnStore:
                 setattr(s, n, self.ptr(n))
             else:
                 setattr(s, n, scal[n])
+        s._ranges = getattr(self, "class_ranges", None)       # (n_land, n_glacier) of a class-sorted device store, or None
         return s
 
     # ------------------------------------------------------------------ device twin
@@ -192,4 +193,6 @@ class DeviceColumnStore(ColumnStore):
         o.idx = dict(self.idx) if self.idx else None
         o.a = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v.clone())
                for k, v in self.a.items()}
+        if hasattr(self, "class_ranges"):
+            o.class_ranges = self.class_ranges
         return o

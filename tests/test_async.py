@@ -121,3 +121,37 @@ def test_sorted_layout_gives_the_same_columns(engine, tables):
             nj, nk, ni = a.shape
             np.testing.assert_array_equal(a.transpose(1, 0, 2).reshape(nk, -1)[:, p], b.transpose(1, 0, 2).reshape(nk, -1),
                                           err_msg=k)
+
+
+def test_class_range_kernels_and_violation(engine, tables):
+    """A class-sorted store is advanced by one kernel per class range (land / land ice / skipped): tallies and results equal the
+    mixed kernel's, water columns keep their first-step side effects, and a column whose class no longer matches its range is
+    reported (NOAHMP_ERR_CLASS_RANGE) instead of being computed by the wrong kernel."""
+    import torch
+    from noahmp_amd.driver import NoahMPFatal
+    s = synth.mixed_small(tables[1], ni=128, nj=16, glacier_frac=0.08, seed=41)
+    s["ivgtyp"][0, :9] = s.cfg.iswater
+    s["xland"][0, :9] = 2.0
+    s["xice"][1, :5] = 1.0                                   # sea ice: skipped, with per-step side effects (drv:436-441)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
+    plain, srt = s.to_device("cuda:0"), s.to_device("cuda:0")
+    perm = engine.sort_store(srt).cpu().numpy()
+    n_land, n_glac = srt.class_ranges
+    assert n_glac > 0 and n_land + n_glac == s.ncol - 14
+    for it in (1, 2):
+        sp = engine.noahmplsm(plain, it, 2000, 180.0)
+        ss = engine.noahmplsm(srt, it, 2000, 180.0)           # ranges declared through the store -> three kernels
+        assert (ss.n_land, ss.n_glacier, ss.n_skipped) == (sp.n_land, sp.n_glacier, sp.n_skipped) == (n_land, n_glac, 14)
+    hp, hs = plain.to_host(), srt.to_host()
+    for k in _outs(hp):
+        a, b = hp.a[k], hs.a[k]
+        a = a.transpose(0, 2, 1).reshape(-1, a.shape[1])[perm] if a.ndim == 3 else a.reshape(-1)[perm]
+        b = b.transpose(0, 2, 1).reshape(-1, b.shape[1]) if b.ndim == 3 else b.reshape(-1)
+        assert np.array_equal(a, b, equal_nan=True), k
+    # a land column turns into land ice without a new sort
+    srt.a["ivgtyp"].view(-1)[3] = s.cfg.isice
+    with pytest.raises(NoahMPFatal) as e:
+        engine.noahmplsm(srt, 3, 2000, 180.0)
+    assert e.value.code == 17
+    engine.noahmplsm(plain, 3, 2000, 180.0)                    # an undeclared store runs the mixed kernel again
