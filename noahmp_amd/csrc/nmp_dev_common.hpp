@@ -133,9 +133,16 @@ static __shared__ long long s_nmp_last[8];
 #define NMP_TRUNC_AT(n) do { if (NMP_TRUNC == (n)) { s.err = 99; return; } } while (0)
 #define NMP_TRUNC_CHK() do { if (NMP_TRUNC && s.err == 99) return; } while (0)
 
+#ifdef NMP_FIXED_DVEG          // option-specialised translation unit (nmp_engine_fixed.inc): the reference's namelist options
+struct Opt {                   // (run/namelist.hrldas) as compile-time constants -- every other alternative's code folds away
+  static constexpr int dveg = NMP_FIXED_DVEG, crs = 1, btr = 1, run = 1, sfc = 1, frz = 1, inf = 1, rad = 3, alb = 2, snf = 1,
+                       tbot = 2, stc = 1;
+};
+#else
 struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)
   int dveg, crs, btr, run, sfc, frz, inf, rad, alb, snf, tbot, stc;
 };
+#endif
 
 struct Parm {  // REDPRM output (lsm:9282-9335): per-column, in registers instead of module globals
   int nroot;

@@ -57,12 +57,29 @@ struct Engine {
   bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
   std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call
   noahmp_step_args resident_args;                        // the argument block of that call (for fetch)
+  int fixed_kernels = 1;        // use the option-specialised kernels when a call's options are the reference's namelist values
   long sorted_land = -1, sorted_glacier = -1;   // class ranges of a sorted device-resident layout (-1: not declared)
   int block = 256;             // 4 waves per workgroup: ~1 % faster than 64 at 1 M columns (bench); 64 and 128 selectable
   int use_lds = 1;
   std::string last_error;
 };
 extern Engine g;
+
+// Everything a column-kernel launch needs, in a form that does not depend on the physics headers' types: the generic
+// translation unit hands it to an option-specialised one (nmp_engine_fixed.inc), which builds its own KArgs from it.
+struct LaunchDesc {
+  noahmp_step_args a;            // array members = device pointers
+  const noahmp_tables* tables;
+  float dt, zsoil[8];
+  int isurban, ni, nka, nti, ntj, k1, kp_lo, kp_hi, yearlen;
+  unsigned long long* err;
+  int* counts;
+  unsigned long long err_base;
+  long t_offset, t_first, t_count;
+};
+// mode: 0 mixed tile, 1 land-only range (template parameter MODE of the kernel); DVEG = 1 / 3, the other options = namelist values
+void launch_fixed_dveg1(const LaunchDesc& d, int mode, hipStream_t s);
+void launch_fixed_dveg3(const LaunchDesc& d, int mode, hipStream_t s);
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \

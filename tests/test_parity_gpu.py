@@ -545,3 +545,41 @@ def test_resident_host_path_lazy_download(engine, port, tables):
         engine.set_option("resident_state", 0)
     engine.noahmplsm(plain, nsteps + 1, 2000, 180.0)
     _check(plain, other, engine, steps=nsteps + 1, fields=_outs(plain))
+
+
+@pytest.mark.parametrize("dveg", [1, 3, 4])
+def test_option_specialised_kernels_bit_identical(engine, tables, dveg):
+    """Calls whose options are the reference's namelist values (DVEG 1 or 3) run kernels compiled with those options as
+    constants (noahmp_engine_dveg*.hip); they must return the bits of the generic kernel -- mixed tile and class ranges alike.
+    DVEG = 4 has no specialised kernel: both settings run the generic one."""
+    cfg = ModelConfig(idveg=dveg)
+    s = synth.mixed_small(tables[1], ni=128, nj=12, glacier_frac=0.06, seed=53, cfg=cfg)
+    synth.first_step_fixups(s)
+    res = {}
+    for fixed in (1, 0):
+        engine.set_option("fixed_option_kernels", fixed)
+        try:
+            tile, srt = s.to_device("cuda:0"), s.to_device("cuda:0")
+            perm = engine.sort_store(srt).cpu().numpy()
+            for it in range(1, 7):
+                synth.diurnal_forcing(s, (it + 9) % 24, t_offset=s.t_offset)
+                import torch
+                for k in ("coszin", "swdown", "glw", "t3d", "rainbl"):
+                    v = torch.from_numpy(s.a[k]).cuda()
+                    tile.a[k].copy_(v)
+                    srt.a[k].copy_((v.permute(0, 2, 1).reshape(-1, v.shape[1])[torch.from_numpy(perm).long().cuda()]
+                                    .reshape(v.shape[0], v.shape[2], v.shape[1]).permute(0, 2, 1)) if v.dim() == 3
+                                   else v.reshape(-1)[torch.from_numpy(perm).long().cuda()].reshape(v.shape))
+                assert engine.noahmplsm(tile, it, 2000, 180.0).code == 0
+                assert engine.noahmplsm(srt, it, 2000, 180.0).code == 0
+            res[fixed] = (tile.to_host(), srt.to_host())
+        finally:
+            engine.set_option("fixed_option_kernels", 1)
+    for which in (0, 1):
+        _check(res[0][which], res[1][which], engine, steps=6, fields=_outs(res[0][which]))
+    a, b = res[1]
+    for k in _outs(a):                                   # and the sorted run is the tile-order run, permuted
+        x, y = a.a[k], b.a[k]
+        x = x.transpose(0, 2, 1).reshape(-1, x.shape[1])[perm] if x.ndim == 3 else x.reshape(-1)[perm]
+        y = y.transpose(0, 2, 1).reshape(-1, y.shape[1]) if y.ndim == 3 else y.reshape(-1)
+        assert np.array_equal(x, y, equal_nan=True), k
