@@ -202,7 +202,7 @@ def main():
                          "kernel": "noahmp_column_kernel", "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * ncol, "valu": valu,
                          "note": "824 B/column-step x columns / HIP-event kernel time; the kernel is VALU-issue and "
-                                 "divergence bound (24 k VALU instructions per column-step wave, 90 % lane utilisation: "
+                                 "divergence bound (23 k VALU instructions per column-step wave, 90 % lane utilisation, SIMD issue 92 % busy: "
                                  "profiles/r01_profile.md), not HBM bound (SURVEY 8d)"},
             "kernel_only_column_steps_per_s": (n_land / args.steps) / (k_avg_ms * 1e-3) * world,
         }
