@@ -135,7 +135,7 @@ static __shared__ long long s_nmp_last[8];
 
 #ifdef NMP_FIXED_DVEG          // option-specialised translation unit (nmp_engine_fixed.inc): the reference's namelist options
 struct Opt {                   // (run/namelist.hrldas) as compile-time constants -- every other alternative's code folds away
-  static constexpr int dveg = NMP_FIXED_DVEG, crs = 1, btr = 1, run = 1, sfc = 1, frz = 1, inf = 1, rad = 3, alb = 2, snf = 1,
+  static constexpr int dveg = NMP_FIXED_DVEG, crs = 1, btr = 1, run = NMP_FIXED_RUN, sfc = 1, frz = 1, inf = 1, rad = 3, alb = 2, snf = 1,
                        tbot = 2, stc = 1;
 };
 #else

@@ -77,9 +77,10 @@ struct LaunchDesc {
   unsigned long long err_base;
   long t_offset, t_first, t_count;
 };
-// mode: 0 mixed tile, 1 land-only range (template parameter MODE of the kernel); DVEG = 1 / 3, the other options = namelist values
-void launch_fixed_dveg1(const LaunchDesc& d, int mode, hipStream_t s);
-void launch_fixed_dveg3(const LaunchDesc& d, int mode, hipStream_t s);
+// mode: 0 mixed tile, 1 land-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
+void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);
+void launch_fixed_d3_r1(const LaunchDesc& d, int mode, hipStream_t s);
+void launch_fixed_d3_r5(const LaunchDesc& d, int mode, hipStream_t s);
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \

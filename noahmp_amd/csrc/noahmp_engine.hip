@@ -209,16 +209,24 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
   k.a.dzs = nullptr;
 }
 
-// 0: generic kernel; 1 / 3: the kernel specialised for the namelist options with DVEG = 1 / 3 can be used
+// the option-specialised translation units (noahmp_engine_d*_r*.hip): (DVEG, RUN) with the other ten options at the namelist values
+#ifndef NMP_NO_FIXED_KERNELS
+struct FixedKernel { int dveg, run; void (*launch)(const nmp_host::LaunchDesc&, int, hipStream_t); };
+static const FixedKernel kFixed[] = {{1, 1, nmp_host::launch_fixed_d1_r1}, {3, 1, nmp_host::launch_fixed_d3_r1},
+                                     {3, 5, nmp_host::launch_fixed_d3_r5}};
+#endif
+// 0: generic kernel; n > 0: kFixed[n-1] can serve this call
 static int fixed_level(const KArgs& k) {
 #ifdef NMP_NO_FIXED_KERNELS
   return 0;
 #else
   const Opt& o = k.c.O;
   if (!g.fixed_kernels) return 0;
-  if (!(o.crs == 1 && o.btr == 1 && o.run == 1 && o.sfc == 1 && o.frz == 1 && o.inf == 1 && o.rad == 3 && o.alb == 2 &&
+  if (!(o.crs == 1 && o.btr == 1 && o.sfc == 1 && o.frz == 1 && o.inf == 1 && o.rad == 3 && o.alb == 2 &&
         o.snf == 1 && o.tbot == 2 && o.stc == 1)) return 0;
-  return o.dveg == 1 ? 1 : o.dveg == 3 ? 3 : 0;
+  for (int n = 0; n < (int)(sizeof(kFixed) / sizeof(kFixed[0])); n++)
+    if (kFixed[n].dveg == o.dveg && kFixed[n].run == o.run) return n + 1;
+  return 0;
 #endif
 }
 
@@ -230,8 +238,7 @@ static void launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
   for (int l = 0; l < NL; l++) d.zsoil[l] = k.c.zsoil[l];
   d.ni = k.ni; d.nka = k.nka; d.nti = k.nti; d.ntj = k.ntj; d.k1 = k.k1; d.kp_lo = k.kp_lo; d.kp_hi = k.kp_hi; d.yearlen = k.yearlen;
   d.err = k.err; d.counts = k.counts; d.err_base = k.err_base; d.t_offset = k.t_offset; d.t_first = k.t_first; d.t_count = k.t_count;
-  if (level == 1) nmp_host::launch_fixed_dveg1(d, mode, s);
-  else nmp_host::launch_fixed_dveg3(d, mode, s);
+  kFixed[level - 1].launch(d, mode, s);
 #endif
 }
 
