@@ -4,7 +4,7 @@
 # The difference between consecutive kernel times is the cost of a phase.
 cd "$(dirname "$0")/../noahmp_amd/csrc" || exit 1
 mkdir -p variants
-B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -ffp-contract=off -Wno-unused-value -I../../include noahmp_engine.hip noahmp_groundwater.hip noahmp_init.hip"
+B="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -shared -std=c++17 -ffp-contract=off -Wno-unused-value -I../../include -DNMP_NO_FIXED_KERNELS noahmp_engine.hip noahmp_groundwater.hip noahmp_init.hip noahmp_forcing.hip"
 for grp in "1 2 3" "4 5 6" "7 8 9"; do
   for n in $grp; do $B -DNMP_TRUNC=$n -o variants/lib_trunc$n.so 2>&1 | grep -E " error|error:" & done
   wait
