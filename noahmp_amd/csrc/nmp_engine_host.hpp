@@ -81,6 +81,8 @@ struct LaunchDesc {
 void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d3_r1(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d3_r5(const LaunchDesc& d, int mode, hipStream_t s);
+void launch_fixed_d4_r1(const LaunchDesc& d, int mode, hipStream_t s);
+void launch_fixed_d4_r3(const LaunchDesc& d, int mode, hipStream_t s);
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \

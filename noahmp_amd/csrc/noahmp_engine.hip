@@ -213,7 +213,8 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
 #ifndef NMP_NO_FIXED_KERNELS
 struct FixedKernel { int dveg, run; void (*launch)(const nmp_host::LaunchDesc&, int, hipStream_t); };
 static const FixedKernel kFixed[] = {{1, 1, nmp_host::launch_fixed_d1_r1}, {3, 1, nmp_host::launch_fixed_d3_r1},
-                                     {3, 5, nmp_host::launch_fixed_d3_r5}};
+                                     {3, 5, nmp_host::launch_fixed_d3_r5}, {4, 1, nmp_host::launch_fixed_d4_r1},
+                                     {4, 3, nmp_host::launch_fixed_d4_r3}};      // (4, 3): the WRF defaults
 #endif
 // 0: generic kernel; n > 0: kFixed[n-1] can serve this call
 static int fixed_level(const KArgs& k) {

@@ -547,12 +547,12 @@ def test_resident_host_path_lazy_download(engine, port, tables):
     _check(plain, other, engine, steps=nsteps + 1, fields=_outs(plain))
 
 
-@pytest.mark.parametrize("dveg", [1, 3, 4])
-def test_option_specialised_kernels_bit_identical(engine, tables, dveg):
+@pytest.mark.parametrize("dveg,run", [(1, 1), (3, 1), (4, 1), (4, 3), (2, 1)])
+def test_option_specialised_kernels_bit_identical(engine, tables, dveg, run):
     """Calls whose options are the reference's namelist values (DVEG 1 or 3) run kernels compiled with those options as
     constants (noahmp_engine_dveg*.hip); they must return the bits of the generic kernel -- mixed tile and class ranges alike.
-    DVEG = 4 has no specialised kernel: both settings run the generic one."""
-    cfg = ModelConfig(idveg=dveg)
+    (DVEG 2, RUN 1) has no specialised kernel: both settings run the generic one."""
+    cfg = ModelConfig(idveg=dveg, iopt_run=run)
     s = synth.mixed_small(tables[1], ni=128, nj=12, glacier_frac=0.06, seed=53, cfg=cfg)
     synth.first_step_fixups(s)
     res = {}
