@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libnoahmp_hip.so")
-SOURCES = ["noahmp_engine.hip", "noahmp_groundwater.hip", "noahmp_init.hip", "noahmp_forcing.hip", "noahmp_engine_d1_r1.hip", "noahmp_engine_d3_r1.hip", "noahmp_engine_d3_r5.hip", "noahmp_engine_d4_r1.hip", "noahmp_engine_d4_r3.hip"]
+SOURCES = ["noahmp_engine.hip", "noahmp_groundwater.hip", "noahmp_init.hip", "noahmp_forcing.hip", "noahmp_engine_d1_r1.hip", "noahmp_engine_d3_r1.hip", "noahmp_engine_d3_r5.hip", "noahmp_engine_d4_r1.hip", "noahmp_engine_d4_r3.hip", "noahmp_jit.hip"]
 def _headers():
     return [f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + ["../../include/noahmp_hip.h"]
 # -ffp-contract=off: keep the reference's a*b+c rounding (no FMA contraction); no fast-math.
@@ -24,7 +24,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-lhiprtc", "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -2,7 +2,9 @@
 // Shared by the GPU kernel (noahmp_engine.hip) and by the host-compiled emulation used only by
 // tests/ (tests/host_emul) to debug the device source without a GPU.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <string.h>
+#endif
 #include "nmp_dev_sflx.hpp"
 #include "nmp_dev_glacier.hpp"
 

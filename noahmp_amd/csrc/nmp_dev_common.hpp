@@ -7,8 +7,10 @@
 // causes a bank conflict: lane t always hits bank (t mod 32) whatever layer it addresses.
 // All arithmetic is float32 in the reference's operation order; no fast-math, no contraction.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 #include "noahmp_hip.h"
 
 namespace nmp {
@@ -133,10 +135,28 @@ static __shared__ long long s_nmp_last[8];
 #define NMP_TRUNC_AT(n) do { if (NMP_TRUNC == (n)) { s.err = 99; return; } } while (0)
 #define NMP_TRUNC_CHK() do { if (NMP_TRUNC && s.err == 99) return; } while (0)
 
-#ifdef NMP_FIXED_DVEG          // option-specialised translation unit (nmp_engine_fixed.inc): the reference's namelist options
-struct Opt {                   // (run/namelist.hrldas) as compile-time constants -- every other alternative's code folds away
-  static constexpr int dveg = NMP_FIXED_DVEG, crs = 1, btr = 1, run = NMP_FIXED_RUN, sfc = 1, frz = 1, inf = 1, rad = 3, alb = 2, snf = 1,
-                       tbot = 2, stc = 1;
+#ifdef NMP_FIXED_DVEG          // option-specialised translation unit (nmp_engine_fixed.inc, or compiled at run time by
+                               // noahmp_jit.hip): the options are compile-time constants -- every other alternative's code folds
+                               // away.  Unset ones default to the reference's namelist (run/namelist.hrldas).
+#ifndef NMP_FIXED_RUN
+#define NMP_FIXED_RUN 1
+#endif
+#ifndef NMP_FIXED_CRS
+#define NMP_FIXED_CRS 1
+#define NMP_FIXED_BTR 1
+#define NMP_FIXED_SFC 1
+#define NMP_FIXED_FRZ 1
+#define NMP_FIXED_INF 1
+#define NMP_FIXED_RAD 3
+#define NMP_FIXED_ALB 2
+#define NMP_FIXED_SNF 1
+#define NMP_FIXED_TBOT 2
+#define NMP_FIXED_STC 1
+#endif
+struct Opt {
+  static constexpr int dveg = NMP_FIXED_DVEG, crs = NMP_FIXED_CRS, btr = NMP_FIXED_BTR, run = NMP_FIXED_RUN, sfc = NMP_FIXED_SFC,
+                       frz = NMP_FIXED_FRZ, inf = NMP_FIXED_INF, rad = NMP_FIXED_RAD, alb = NMP_FIXED_ALB, snf = NMP_FIXED_SNF,
+                       tbot = NMP_FIXED_TBOT, stc = NMP_FIXED_STC;
 };
 #else
 struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)

@@ -57,6 +57,8 @@ struct Engine {
   bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
   std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call
   noahmp_step_args resident_args;                        // the argument block of that call (for fetch)
+  int jit_kernels = 0;          // compile a specialised kernel at run time (hiprtc) for option sets without an ahead-of-time one
+  int jit_compile_only = 0;     // test hook: compile, do not load or launch (works without a GPU)
   int fixed_kernels = 1;        // use the option-specialised kernels when a call's options are the reference's namelist values
   long sorted_land = -1, sorted_glacier = -1;   // class ranges of a sorted device-resident layout (-1: not declared)
   int block = 256;             // 4 waves per workgroup: ~1 % faster than 64 at 1 M columns (bench); 64 and 128 selectable
@@ -83,6 +85,9 @@ void launch_fixed_d3_r1(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d3_r5(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d4_r1(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d4_r3(const LaunchDesc& d, int mode, hipStream_t s);
+// noahmp_jit.hip: the same for any option set o[12] = (DVEG, CRS, BTR, RUN, SFC, FRZ, INF, RAD, ALB, SNF, TBOT, STC), compiled on first use
+bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s);
+void jit_finalize();
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \

@@ -1,9 +1,15 @@
 // The column kernel (one thread = one column-step), shared by the generic translation unit (noahmp_engine.hip: options are run-time
 // values) and the option-specialised ones (nmp_engine_fixed.inc: options are compile-time constants).
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include "nmp_dev_column.hpp"
+#ifndef __HIPCC_RTC__
 #include "nmp_engine_host.hpp"
+#else                      // run-time compilation (hiprtc): only what the kernel itself needs of the host header
+namespace nmp_host { constexpr int kCountSlots = 256, kCountStride = 16; }
+#endif
 
 namespace {
 using namespace nmp;
@@ -19,8 +25,8 @@ using namespace nmp;
 // MODE 0: the tile as it is (any mix of classes).  MODE 1 / 2 / 3: a range of a class-sorted layout that holds only land /
 // only glacier / only skipped (open water, sea ice) columns -- kernels without the other classes' code; a column of another
 // class in such a range raises NOAHMP_ERR_CLASS_RANGE (its class changed since the sort, e.g. sea ice: sort again).
-template <int BLOCK, bool USE_LDS, int MODE = 0>
-__global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(const KArgs k) {
+template <int BLOCK, bool USE_LDS, int MODE>
+__device__ __forceinline__ void column_kernel_body(const KArgs& k) {
   constexpr int STRIDE = USE_LDS ? BLOCK : 1;
   __shared__ float lds[(USE_LDS && MODE != 3) ? LAY_SLOTS * BLOCK : 1];
   float priv[(USE_LDS || MODE == 3) ? 1 : LAY_SLOTS];
@@ -49,6 +55,11 @@ __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(
   SimpleLoop runner;
   const int err = column_step<STRIDE, (MODE == 3 ? 0 : MODE)>(k, cls, ii, jj, ij, base, runner);
   if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)err);   // first column wins
+}
+
+template <int BLOCK, bool USE_LDS, int MODE = 0>
+__global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(const KArgs k) {
+  column_kernel_body<BLOCK, USE_LDS, MODE>(k);
 }
 
 }  // namespace

@@ -161,6 +161,8 @@ int noahmp_hip_set_option(const char* key, int value) {
     prev = g.trust_out_mirror;
     if (value == 0 || value == 1) { g.trust_out_mirror = value; g.out_mirror_valid = false; }
   }
+  else if (!strcmp(key, "jit_option_kernels")) { prev = g.jit_kernels; if (value == 0 || value == 1) g.jit_kernels = value; }
+  else if (!strcmp(key, "jit_compile_only")) { prev = g.jit_compile_only; if (value == 0 || value == 1) g.jit_compile_only = value; }
   else if (!strcmp(key, "fixed_option_kernels")) { prev = g.fixed_kernels; if (value == 0 || value == 1) g.fixed_kernels = value; }
   else if (!strcmp(key, "sorted_land_columns")) { prev = (int)g.sorted_land; g.sorted_land = value; }
   else if (!strcmp(key, "sorted_glacier_columns")) { prev = (int)g.sorted_glacier; g.sorted_glacier = value; }
@@ -224,22 +226,28 @@ static int fixed_level(const KArgs& k) {
   const Opt& o = k.c.O;
   if (!g.fixed_kernels) return 0;
   if (!(o.crs == 1 && o.btr == 1 && o.sfc == 1 && o.frz == 1 && o.inf == 1 && o.rad == 3 && o.alb == 2 &&
-        o.snf == 1 && o.tbot == 2 && o.stc == 1)) return 0;
+        o.snf == 1 && o.tbot == 2 && o.stc == 1)) return g.jit_kernels ? -1 : 0;
   for (int n = 0; n < (int)(sizeof(kFixed) / sizeof(kFixed[0])); n++)
     if (kFixed[n].dveg == o.dveg && kFixed[n].run == o.run) return n + 1;
-  return 0;
+  return g.jit_kernels ? -1 : 0;
 #endif
 }
 
-static void launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
-#ifndef NMP_NO_FIXED_KERNELS
+// level > 0: ahead-of-time kernel kFixed[level-1]; level < 0: compile one for this option set at run time.  false: not available.
+static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
+#ifdef NMP_NO_FIXED_KERNELS
+  return false;
+#else
   nmp_host::LaunchDesc d;
   memset(&d, 0, sizeof(d));
   d.a = k.a; d.tables = k.c.T; d.dt = k.c.dt; d.isurban = k.c.isurban;
   for (int l = 0; l < NL; l++) d.zsoil[l] = k.c.zsoil[l];
   d.ni = k.ni; d.nka = k.nka; d.nti = k.nti; d.ntj = k.ntj; d.k1 = k.k1; d.kp_lo = k.kp_lo; d.kp_hi = k.kp_hi; d.yearlen = k.yearlen;
   d.err = k.err; d.counts = k.counts; d.err_base = k.err_base; d.t_offset = k.t_offset; d.t_first = k.t_first; d.t_count = k.t_count;
-  kFixed[level - 1].launch(d, mode, s);
+  if (level > 0) { kFixed[level - 1].launch(d, mode, s); return true; }
+  const Opt& o = k.c.O;
+  const int opts[12] = {o.dveg, o.crs, o.btr, o.run, o.sfc, o.frz, o.inf, o.rad, o.alb, o.snf, o.tbot, o.stc};
+  return nmp_host::launch_jit(opts, d, mode, s);
 #endif
 }
 
@@ -248,7 +256,7 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
   if (count <= 0) return;
   k.t_first = first; k.t_count = count;
   const int fx = (MODE == 0 || MODE == 1) ? fixed_level(k) : 0;      // land ice / skipped cells hardly depend on the options
-  if (fx) { launch_fixed(k, fx, MODE, s); return; }
+  if (fx && launch_fixed(k, fx, MODE, s)) return;
   hipLaunchKernelGGL((noahmp_column_kernel<256, true, MODE>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k);
 }
 
@@ -677,6 +685,9 @@ void noahmp_hip_finalize(void) {
   for (auto& b : g.mirror_bytes) b = 0;
   g.resident_valid = false; g.resident_dirty = false; g.mirror_host.clear();
   g.sorted_land = -1; g.sorted_glacier = -1;
+#ifndef NMP_NO_FIXED_KERNELS
+  nmp_host::jit_finalize();
+#endif
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto e : g.async_events) hipEventDestroy(e);

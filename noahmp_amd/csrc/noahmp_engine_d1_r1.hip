@@ -3,4 +3,5 @@
 #include "noahmp_hip.h"
 #define NMP_FIXED_DVEG 1
 #define NMP_FIXED_RUN 1
+#define NMP_FIXED_EXPORT_PACK 1
 #include "nmp_engine_fixed.inc"

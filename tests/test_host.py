@@ -125,3 +125,15 @@ def test_store_layout_is_fortran_image():
     s["tslb"][0, 2, 1] = 42.0
     flat = s["tslb"].ravel()
     assert flat[((1 - 1) * 4 + (3 - 1)) * 5 + (2 - 1)] == 42.0
+
+
+def test_runtime_specialisation_compiles_without_gpu():
+    """noahmp_jit.hip: the column kernel compiled by hiprtc for an option set that has no ahead-of-time kernel (the compile step
+    needs no GPU; loading and launching are covered by the GPU tests)."""
+    import ctypes as C
+    lib = abi.load_library()
+    opts = (C.c_int32 * 12)(2, 2, 2, 3, 1, 2, 2, 1, 1, 3, 1, 2)
+    log = C.create_string_buffer(4096)
+    rc = lib.noahmp_hip_jit_compile_check(opts, log, 4096)
+    assert rc == 0, log.value.decode()[:2000]
+    assert log.value.decode().startswith("compiled ")

@@ -583,3 +583,32 @@ def test_option_specialised_kernels_bit_identical(engine, tables, dveg, run):
         x = x.transpose(0, 2, 1).reshape(-1, x.shape[1])[perm] if x.ndim == 3 else x.reshape(-1)[perm]
         y = y.transpose(0, 2, 1).reshape(-1, y.shape[1]) if y.ndim == 3 else y.reshape(-1)
         assert np.array_equal(x, y, equal_nan=True), k
+
+
+@pytest.mark.parametrize("kw", [dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_frz=2), dict(iopt_btr=2, iopt_crs=2, idveg=5)],
+                         ids=["dveg2_run3_stc2_frz2", "btr2_crs2_dveg5"])
+def test_runtime_compiled_kernels_bit_identical(engine, tables, kw):
+    """Option sets without an ahead-of-time specialised kernel: with "jit_option_kernels" the engine compiles one at the first
+    call (hiprtc) -- it must return the bits of the generic kernel, mixed tile and class ranges alike."""
+    import torch
+    cfg = ModelConfig(**kw)
+    s = synth.mixed_small(tables[1], ni=128, nj=12, glacier_frac=0.06, seed=59, cfg=cfg)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
+    res = {}
+    for jit in (0, 1):
+        engine.set_option("jit_option_kernels", jit)
+        try:
+            tile, srt = s.to_device("cuda:0"), s.to_device("cuda:0")
+            engine.sort_store(srt, tsk_bin=0)
+            for it in range(1, 5):
+                assert engine.noahmplsm(tile, it, 2000, 180.0).code == 0
+                assert engine.noahmplsm(srt, it, 2000, 180.0).code == 0
+            res[jit] = (tile.to_host(), srt.to_host())
+            if jit:
+                msg = engine.lib.noahmp_hip_last_error().decode()
+                assert "generic kernel used" not in msg, msg          # the run-time compiled kernels really ran
+        finally:
+            engine.set_option("jit_option_kernels", 0)
+    for which in (0, 1):
+        _check(res[0][which], res[1][which], engine, steps=4, fields=_outs(res[0][which]))
