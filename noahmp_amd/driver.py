@@ -7,6 +7,7 @@ HIP engine -- nothing else.  A fatal column raises :class:`NoahMPFatal` (the ref
 wrf_error_fatal, util/module_wrf_utilities.F:12-24).
 """
 import ctypes as C
+import os
 
 from . import abi
 from .state import DeviceColumnStore
@@ -34,6 +35,8 @@ class Engine:
         if rc:
             raise RuntimeError("noahmp_hip_set_tables: " + self.lib.noahmp_hip_last_error().decode())
         self.last_status = abi.Status()
+        if os.environ.get("NMP_JIT") in ("0", "1"):          # run-time specialisation for every option set (noahmp_jit.hip)
+            self.set_option("jit_option_kernels", int(os.environ["NMP_JIT"]))
 
     @property
     def exact_libm(self):
