@@ -1,17 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: column-steps/s of the Noah-MP column engine on MI355X.
 
-A "step" is one noahmplsm call (reference drv:11) over one batch of synthetic land columns that is
-already resident in HBM.  N=1 workload = BASELINE.json configs[1]: 1 048 576 synthetic land
-columns, 4 soil / 0 snow layers, dynamic_veg off (DVEG=1), namelist-default physics options.
-N>1: one process per GPU, every rank advances its own tile of the same size (weak scaling, the
-columns are independent: no data-path collective); value = all ranks' columns x K / max-rank time.
+A "step" is one noahmplsm call (reference drv:11) over one batch of synthetic columns that is already resident in HBM.
 
-Prints ONE JSON line on rank 0 (metric contract of the driver) with `roofline` and `cpu_baseline`.
+N = 1 workload (default) = BASELINE.json configs[2]: the CONUS-1-km-like grid, 4608 x 1536 = 7 077 888 columns, 4 soil /
+up to 3 snow layers (30 % of the columns carry snow: ISNOW 0..-3), 2 % urban, 1 % land ice, the reference's namelist options;
+state device-resident and sorted by (class, vegetation type, snow-layer count, skin-temperature bin) on the device, re-sorted
+when snow layers appear or vanish, forcing delivered in tile order and permuted into the sorted working set every step --
+sort, staleness checks and permutation all INSIDE the timed region.
+
+N > 1 workload (default) = BASELINE.json configs[3]: the SAME grid with OPT_RUN = 5 cut into N tiles by the reference's
+mpp_land_partition_calc rule (mpp:227-288; 4 x 2 at N = 8), one process per GPU; every STEPWTD steps WTABLE_mmf_noahmp
+(gw:14) runs after the 1-cell ZWTXY ring has been exchanged between neighbouring ranks (RCCL send/recv over xGMI) -- the only
+data-path exchange.  Total work is fixed: STRONG scaling.  `--workload config4 --gpus 1` gives the N = 1 point of that curve,
+`--workload config3 --gpus N` the collective-free split of the N = 1 workload, `--workload config2` round 1's 1 M-column case.
+
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (children are started before anything
+touches the GPU).  Prints ONE JSON line on rank 0 (metric contract of the driver) with `roofline` and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,54 +30,222 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_COLSTEP = 824          # 87 reads + 119 writes x 4 B at the noahmplsm ABI
+GW_BYTES_PER_CELL = 216              # gw_head_kernel 24 B + gw_column_kernel 192 B per WTABLE_mmf_noahmp call
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec
+SIMDS, CLOCK_GHZ = 1024, 2.4         # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU op issues over 2 cycles
+FKEYS = ("coszin", "swdown", "glw", "t3d", "rainbl")     # what the diurnal forcing changes from hour to hour
 
 
-def cpu_baseline(tables_struct, tb, ncol=32768, nsteps=24):
-    """Time the CPU path on this box's host cores: the compiled reference (oracle/_ref, -O2) when
-    its .so travelled with the repo, else the C restatement.  One process per core, each on its own
-    `ncol`-column sample of the bench workload, `nsteps` hourly steps (bounded: ~10-30 s of CPU)."""
+# ------------------------------------------------------------------------------------------------ CPU leg
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, ncol=32768, nsteps=24):
+    """Time the CPU path on this box's host cores: the compiled reference (oracle/_ref, -O2) when its .so travelled with the
+    repo, else the C restatement.  One process per core, each on its own `ncol`-column sample of the bench workload (same
+    generator, same class / snow mix), `nsteps` hourly steps (bounded: ~10-30 s of CPU)."""
     import multiprocessing as mp
     from oracle import reflib
     kind = "reference" if reflib.available("O2") else "port"
     cores = max(1, min(os.cpu_count() or 1, 64))
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(kind, ncol, nsteps, r) for r in range(cores)])
+        res = pool.map(_cpu_worker, [(kind, workload, ncol, nsteps, r) for r in range(cores)])
     wall = max(r[0] for r in res)
-    single = res[0][1]
-    total = cores * ncol * nsteps
-    return {"value": total / wall, "unit": "column-steps/s", "cores": cores, "kind": kind,
-            "single_core": single,
-            "sample": "%d procs x %d columns x %d hourly steps of the config-2 workload (%s, float32)"
-                      % (cores, ncol, nsteps, "reference Fortran flang -O2" if kind == "reference" else "C restatement gcc -O2")}
+    quiet = _cpu_worker((kind, workload, 4096, nsteps, 1000))
+    what = {"config2": "config-2", "config3": "config-3 (30 % snow, 2 % urban, 1 % land ice)",
+            "config4": "config-4 (config-3 mix, OPT_RUN=5; column step only)"}[workload]
+    return {"value": cores * ncol * nsteps / wall, "unit": "column-steps/s", "cores": cores, "kind": kind,
+            "cpu_model": cpu_model(),
+            "single_core_while_all_cores_run": res[0][1], "single_core_alone": quiet[1],
+            "sample": "%d procs x %d columns x %d hourly steps of the %s workload (%s, float32), the noahmplsm call only"
+                      % (cores, ncol, nsteps, what,
+                         "reference Fortran flang -O2" if kind == "reference" else "C restatement gcc -O2")}
 
 
 def _cpu_worker(arg):
-    kind, ncol, nsteps, r = arg
-    import numpy as np  # noqa: F401
+    kind, workload, ncol, nsteps, r = arg
     from noahmp_amd import synth
+    from noahmp_amd.state import ModelConfig
     from noahmp_amd.tables import load_tables
     T, tb = load_tables("usgs")
-    s = synth.config2(tb, ni=ncol // 8, nj=8, seed=100 + r)
+    if workload == "config2":
+        s = synth.config2(tb, ni=ncol // 8, nj=8, seed=100 + r, cfg=ModelConfig(idveg=1))
+    else:
+        s = synth.config3(tb, ni=ncol // 8, nj=8, seed=100 + r, cfg=ModelConfig(iopt_run=5 if workload == "config4" else 1))
+        if workload == "config4":
+            synth.groundwater_fields(s, tb, seed=200 + r)
     synth.first_step_fixups(s)
     if kind == "reference":
         from oracle.reflib import RefLib
         lib = RefLib("O2")
-        lib.set_tables(T)
-        step = lambda it: lib.noahmplsm(s, it, 2000, 180.0)          # noqa: E731
     else:
         from oracle.portlib import PortLib
         lib = PortLib(autobuild=False)
-        lib.set_tables(T)
-        step = lambda it: lib.noahmplsm(s, it, 2000, 180.0)          # noqa: E731
+    lib.set_tables(T)
     dt = 0.0
     for it in range(1, nsteps + 1):
         synth.diurnal_forcing(s, (it + 5) % 24, t_offset=s.t_offset)     # forcing prep is not timed
         t0 = time.perf_counter()
-        step(it)                                                          # the noahmplsm call only
+        lib.noahmplsm(s, it, 2000, 180.0)                                 # the noahmplsm call only
         dt += time.perf_counter() - t0
     return dt, ncol * nsteps / dt
+
+
+# ------------------------------------------------------------------------------------------------ N ranks without torchrun
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children -- this process never touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+class Run:
+    """One rank's share of a workload: setup() builds the device-resident state, step(it) enqueues one timestep,
+    collect() waits and returns the tallies."""
+
+    def __init__(self, args, workload, comm, eng, tb, dev):
+        import torch
+        from noahmp_amd import synth
+        from noahmp_amd.partition import tile_geometry
+        from noahmp_amd.state import ModelConfig
+        self.torch, self.args, self.workload, self.comm, self.eng, self.dev = torch, args, workload, comm, eng, dev
+        self.lateral = workload == "config4"
+        self.sorted = not self.lateral and not args.no_sort
+        gx, gy = args.ni, args.nj
+        if workload == "config2":
+            cfg = ModelConfig(idveg=1)
+        else:
+            cfg = ModelConfig(iopt_run=5 if self.lateral else 1, idveg=args.dveg)
+        self.cfg = cfg
+        geom = tile_geometry(gx, gy, comm.world, comm.rank, halo=1 if self.lateral else 0)
+        self.geom = geom
+        nx, ny = geom["ime"] - geom["ims"] + 1, geom["jme"] - geom["jms"] + 1
+        if workload == "config2":
+            assert comm.world == 1, "config2 is the single-GPU case of round 1"
+            s = synth.config2(tb, ni=gx, nj=gy, seed=2, cfg=cfg)
+        else:       # this rank's memory block (tile + ring) cut from ONE global grid
+            s = synth.config3_tile(tb, gx, gy, geom["ims"] - 1, geom["jms"] - 1, nx, ny, cfg=cfg, groundwater=self.lateral)
+        s.set_index(**{k: geom[k] for k in ("ids", "ide", "jds", "jde", "ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")})
+        synth.first_step_fixups(s)
+        self.ni, self.nj = s.ni, s.nj
+        self.tile_cells = (geom["ite"] - geom["its"] + 1) * (geom["jte"] - geom["jts"] + 1)
+        # 24 hourly forcing sets in tile order, resident in HBM (as a driver would have staged them)
+        self.forcing = []
+        for h in range(24):
+            synth.diurnal_forcing(s, h, t_offset=s.t_offset)
+            self.forcing.append({k: torch.from_numpy(s.a[k].copy()).to(dev) for k in FKEYS})
+        self.d = d = s.to_device(dev)
+        self.stepwtd = max(int(cfg.wtddt * 60.0 / cfg.dt + 0.5), 1)                 # hdrv:1227 NINT
+        self.ts = torch.cuda.Stream(device=dev)                                     # every kernel and exchange of the run
+        self.sp = self.ts.cuda_stream
+        self.kernel_ms = 0.0
+        self.class_ms = [0.0, 0.0, 0.0]
+        self.n_adv = 0
+        self.n_land = 0
+        self.resorts = 0
+        self.stale_seen = []
+        self.halo_events = []
+        self.gw_calls = 0
+        if self.sorted:
+            # Layout in HBM (DESIGN.md section 3): state sorted on the device; forcing arrives in tile order and is permuted
+            # into the sorted working set every step
+            self.perm = eng.sort_store(d, tsk_bin=args.tsk_bin)
+            self._bind_sorted()
+        else:
+            self.sargs = []
+            for h in range(24):                                                      # a step just points the block at the hour's set
+                d.a.update(self.forcing[h])
+                self.sargs.append(d.step_args(1, 2000, 180.0))
+            if self.lateral:
+                self.wargs = d.wtable_args()
+                with torch.cuda.stream(self.ts):                                     # static planes of the stencil: once
+                    comm.exchange_halo([d.a["fdepth"], d.a["topo"]], geom)
+                    comm.exchange_halo([d.a["isltyp"]], geom)
+                self.ts.synchronize()
+
+    def _bind_sorted(self):
+        torch, d, eng = self.torch, self.d, self.eng
+        self.work = {k: d.a[k] for k in FKEYS}
+        self.scat = eng.scatter([self.work[k] for k in FKEYS], [self.forcing[0][k] for k in FKEYS], self.perm, self.ni, self.nj)
+        self.sarg = d.step_args(1, 2000, 180.0)
+
+    def step(self, it):
+        h = (it + 5) % 24
+        if self.sorted:
+            self.scat.set_sources([self.forcing[h][k] for k in FKEYS])
+            self.scat(self.sp)
+            self.sarg.itimestep = it
+            self.eng.noahmplsm_async(self.sarg, self.sp)
+            if self.args.resort_every and it % self.args.resort_every == 0:
+                self.maybe_resort()
+            return
+        sa = self.sargs[h]
+        sa.itimestep = it
+        self.eng.noahmplsm_async(sa, self.sp)
+        if self.lateral and it % self.stepwtd == 0:
+            torch = self.torch
+            with torch.cuda.stream(self.ts):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.comm.exchange_halo([self.d.a["zwtxy"]], self.geom)              # ZWTXY ring before every call (gw:231-252)
+                e1.record()
+            self.halo_events.append((e0, e1))
+            self.eng.wtable_mmf_async(self.wargs, self.sp)
+            self.gw_calls += 1
+
+    def collect(self):
+        st, bad = self.eng.sync()                       # waits for the pending steps; tallies and kernel times summed over them
+        self.kernel_ms += st.kernel_ms
+        cm, _ = self.eng.sync_timing()
+        for c in range(3):
+            self.class_ms[c] += cm[c]
+        self.n_adv += st.n_land + st.n_glacier
+        self.n_land += st.n_land
+        return st
+
+    def maybe_resort(self):
+        """Every `resort_every` steps: how many columns left the bucket they were sorted into (snow layers appeared or
+        vanished)?  Above the threshold the state is sorted again on the device -- all of it inside the timed region."""
+        self.collect()
+        stale = self.eng.sort_staleness(self.d)
+        self.stale_seen.append(stale)
+        if stale > self.args.resort_frac * self.d.ncol:
+            self.perm = self.eng.sort_store(self.d, tsk_bin=self.args.tsk_bin)
+            self._bind_sorted()
+            self.resorts += 1
+
+    def reset_counters(self):
+        self.kernel_ms, self.class_ms, self.n_adv, self.n_land, self.resorts, self.stale_seen = 0.0, [0.0, 0.0, 0.0], 0, 0, 0, []
+        self.halo_events, self.gw_calls = [], 0
+
+
+WORKLOAD_TEXT = {
+    "config2": "BASELINE configs[1]: %(cols)d synthetic land columns (%(ni)dx%(nj)d tile), 4 soil / 0 snow layers, DVEG=1 (dynamic_veg off), "
+               "opt_run=1",
+    "config3": "BASELINE configs[2]: CONUS-1-km-like grid %(ni)dx%(nj)d = %(cols)d columns, 4 soil / up to 3 snow layers (30 %% snow-covered, "
+               "ISNOW 0..-3), 2 %% urban, 1 %% land ice, reference namelist options (DVEG=%(dveg)d, opt_run=1)",
+    "config4": "BASELINE configs[3]: the config-3 grid %(ni)dx%(nj)d = %(cols)d columns with OPT_RUN=5 cut into %(world)d tile(s) by "
+               "mpp_land_partition_calc, WTABLE_mmf_noahmp every %(stepwtd)d step(s) after the ZWTXY ring exchange, tile order",
+}
 
 
 def main():
@@ -74,72 +253,57 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--ni", type=int, default=1024)
-    ap.add_argument("--nj", type=int, default=1024)
+    ap.add_argument("--workload", choices=("config2", "config3", "config4"), default=None)
+    ap.add_argument("--ni", type=int, default=None)
+    ap.add_argument("--nj", type=int, default=None)
+    ap.add_argument("--dveg", type=int, default=3)
+    ap.add_argument("--tsk-bin", type=float, default=1.0, help="skin-temperature bin of the sort key [K], 0 = off")
+    ap.add_argument("--resort-every", type=int, default=24, help="steps between staleness checks of the sorted layout (0 = never)")
+    ap.add_argument("--resort-frac", type=float, default=0.01, help="re-sort when this share of the columns left their bucket")
+    ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.cpu_baseline_only:              # child process: never touches the GPU
-        from noahmp_amd.tables import load_tables
-        T, tb = load_tables("usgs")
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(T, tb)))
-        return
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_baseline_only)))
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    workload = args.workload or ("config3" if world == 1 else "config4")
+    if args.ni is None:
+        args.ni, args.nj = (1024, 1024) if workload == "config2" else (4608, 1536)
 
     from noahmp_amd.tables import load_tables
     T, tb = load_tables("usgs")
-
-    cpu = None
     import torch
-    from noahmp_amd import synth
     from noahmp_amd.driver import Engine
-    from noahmp_amd.state import ModelConfig
-
     from noahmp_amd.parallel import Comm
-    torch.cuda.set_device(local_rank)
-    comm = Comm()                                           # one process per GPU; "nccl" = RCCL when world > 1
-
-    eng = Engine(T, device=local_rank, lib_path=os.environ.get("NMP_LIB"))
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("bench.py: no GPU visible (the engine has no CPU path)")
+    dev_index = local_rank % ndev            # several ranks on one GPU: only with NMP_DIST_BACKEND=gloo (1-GPU check of the N>1 path)
+    torch.cuda.set_device(dev_index)
+    comm = Comm(device_index=dev_index)      # one process per GPU; "nccl" = RCCL when world > 1
+    dev = torch.device("cuda", dev_index)
+    eng = Engine(T, device=dev_index, lib_path=os.environ.get("NMP_LIB"))
     if os.environ.get("NMP_BLOCK"):
         eng.set_option("block", int(os.environ["NMP_BLOCK"]))
-    cfg = ModelConfig(idveg=1)                              # "dynamic_veg off", config 2
-    s = synth.config2(tb, ni=args.ni, nj=args.nj, seed=2 + rank, cfg=cfg)
-    synth.first_step_fixups(s)
-    # 24 hourly forcing sets, resident in HBM; a step just points the argument block at the hour's set
-    fkeys = ("coszin", "swdown", "glw", "t3d", "rainbl")
-    forcing = []
-    for h in range(24):
-        synth.diurnal_forcing(s, h, t_offset=s.t_offset)
-        forcing.append({k: torch.from_numpy(s.a[k].copy()).cuda(local_rank) for k in fkeys})
-    d = s.to_device("cuda:%d" % local_rank)
-    ncol = s.ncol
 
-    # Layout in HBM: the device-resident state is kept sorted by (class, vegetation type, 1-K skin-temperature bin) so that a
-    # wavefront holds columns that take the same branches.  Forcing arrives in tile order (as a driver would deliver it)
-    # and is permuted into the sorted working set every step, INSIDE the timed region.
-    perm = eng.sort_store(d)
-    work = {k: torch.empty_like(forcing[0][k]) for k in fkeys}
-    d.a.update(work)
-    gather = eng.scatter([work[k] for k in fkeys], [forcing[0][k] for k in fkeys], perm, s.ni, s.nj)
-    # One argument block, built once; a step swaps the forcing record, permutes it and enqueues the kernel
-    # (noahmp_hip_step_async: device-resident state, nothing to wait for until output is due).
-    sargs = d.step_args(1, 2000, 180.0)
-
-    def step(it):
-        gather.set_sources([forcing[(it + 5) % 24][k] for k in fkeys])
-        gather()
-        sargs.itimestep = it
-        eng.noahmplsm_async(sargs)
+    t_setup = time.perf_counter()
+    run = Run(args, workload, comm, eng, tb, dev)
+    t_setup = time.perf_counter() - t_setup
 
     it = 0
     for _ in range(args.warmup):
         it += 1
-        step(it)
-    st, _ = eng.sync()
+        run.step(it)
+    run.collect()
+    run.reset_counters()
 
     def barrier():
         comm.barrier()
@@ -149,68 +313,89 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         it += 1
-        step(it)
-    st, bad_step = eng.sync()                   # waits for the K steps; tallies and device time summed over them
+        run.step(it)
+    run.collect()
     barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = st.kernel_ms
-    n_land = st.n_land
-    dt = comm.reduce_max(dt)                    # MAX over ranks
-    n_land_all = comm.reduce_sum(n_land)        # columns advanced by the whole job
+    dt_local = time.perf_counter() - t0
+    dt = comm.reduce_max(dt_local)                      # MAX over ranks
+    n_adv_all = comm.reduce_sum(run.n_adv)              # column-steps advanced by the whole job (land + land ice, not the skips)
+    halo_ms = sum(e0.elapsed_time(e1) for e0, e1 in run.halo_events)
+    halo_ms_max = comm.reduce_max(halo_ms)
+    kernel_ms_max = comm.reduce_max(run.kernel_ms)
 
+    cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU leg: after the timed GPU region, in a child process that never initialises the GPU
-        # (the 64 forked workers would otherwise disturb the GPU timing and are not fork-safe here)
-        import subprocess
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"],
-                           capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", workload], capture_output=True, text=True)
         for line in r.stdout.splitlines():
             if line.startswith("CPU_BASELINE "):
                 cpu = json.loads(line[len("CPU_BASELINE "):])
 
     if rank == 0:
-        value = n_land_all / dt
-        k_avg_ms = kernel_ms / args.steps
-        achieved = ALG_BYTES_PER_COLSTEP * (n_land / args.steps) / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
-        valu = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        K = args.steps
+        value = n_adv_all / dt
+        # dominant kernel: the land range of the sorted layout (the mixed kernel of a tile-order run); its own event pair per step
+        dom_ms = run.class_ms[0] / K
+        dom_cols = (run.n_land if run.sorted else run.n_adv) / K       # columns one launch of that kernel advances
+        achieved = ALG_BYTES_PER_COLSTEP * dom_cols / (dom_ms * 1e-3) / 1e9
+        traffic, valu = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
-            try:
+            try:    # PMC counters come from separate rocprofv3 --pmc passes of this very command (tools/run_profile.sh)
                 prof = json.load(open(tpath))
-                # PMC counters come from a separate rocprofv3 --pmc pass of this very workload (tools/run_profile.sh)
-                same = prof.get("columns_per_launch") == ncol
-                traffic = prof.get("hbm_bytes_per_launch") if same else None
-                dv = prof.get("derived") if same else None
-                if dv:      # what actually binds this kernel (same PMC passes): VALU issue, 2 waves per SIMD
-                    valu = {"insts_per_column_step": dv["valu_insts_per_column_step"], "lane_utilisation": dv["lane_utilisation"],
-                            "simd_issue_utilisation": 2.0 * dv["valu_active_share_of_wave_cycles"], "waves_per_simd": 2}
+                if prof.get("workload") == workload and prof.get("columns_per_launch") == int(dom_cols) and world == 1:
+                    traffic = prof.get("hbm_bytes_per_launch")
+                    dv = prof.get("derived") or {}
+                    if dv.get("valu_wave_insts_per_launch"):
+                        # VALU-issue roofline: wave64 VALU instructions x 2 issue cycles / (SIMDs x clock x kernel time)
+                        frac = dv["valu_wave_insts_per_launch"] * 2.0 / (SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3)
+                        valu = {"bound": "valu_issue", "wave_insts_per_launch": dv["valu_wave_insts_per_launch"],
+                                "insts_per_column_step_wave": dv.get("valu_insts_per_column_step"),
+                                "lane_utilisation": dv.get("lane_utilisation"), "cycles_per_inst": 2, "simds": SIMDS,
+                                "clock_ghz": CLOCK_GHZ, "frac": frac,
+                                "note": "fraction of the chip's wave64 VALU issue slots the kernel's instruction count fills"}
             except Exception:
-                traffic = None
+                traffic, valu = None, None
+        desc = WORKLOAD_TEXT[workload] % dict(cols=args.ni * args.nj, ni=args.ni, nj=args.nj, dveg=args.dveg, world=world,
+                                              stepwtd=run.stepwtd)
+        if run.sorted:
+            desc += ("; state resident in HBM, sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature "
+                     "bin), staleness check every %d steps (re-sort above %g %% stale), hourly diurnal forcing permuted per step; "
+                     "all of it inside the timed region" % (args.tsk_bin, args.resort_every, args.resort_frac * 100))
+        else:
+            desc += "; state resident in HBM, hourly diurnal forcing"
         out = {
             "metric": "column-steps/sec", "value": value, "unit": "column-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic land columns per GPU (%dx%d tile), "
-                                   "4 soil / 0 snow layers, DVEG=1 (dynamic_veg off), opt_run=1, hourly "
-                                   "diurnal forcing, state resident in HBM sorted by (vegetation type, skin-temperature bin), forcing permuted "
-                                   "per step inside the timed region" % (ncol, args.ni, args.nj),
-                       "columns_per_gpu": ncol, "parallelism": "columns split %d-way, no collective" % world},
+            "config": {"workload": desc, "grid": [args.ni, args.nj], "columns_per_gpu": run.tile_cells,
+                       "parallelism": ("1 GPU" if world == 1 else "%d tiles (mpp_land_partition_calc), one rank per GPU%s"
+                                       % (world, ", RCCL ZWTXY ring exchange" if run.lateral else ", no collective"))},
+            "timed_region_s": dt, "setup_s": t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "noahmp_column_kernel", "kernel_ms_avg": k_avg_ms,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * ncol, "valu": valu,
-                         "note": "824 B/column-step x columns / HIP-event kernel time; the kernel is VALU-issue and "
-                                 "divergence bound (23 k VALU instructions per column-step wave, 90 % lane utilisation, SIMD issue 92 % busy: "
-                                 "profiles/r01_profile.md), not HBM bound (SURVEY 8d)"},
-            "kernel_only_column_steps_per_s": (n_land / args.steps) / (k_avg_ms * 1e-3) * world,
+                         "kernel": "noahmp_column_kernel (%s)" % ("land range of the sorted layout" if run.sorted else "mixed tile"),
+                         "kernel_ms_avg": dom_ms, "columns_per_launch": int(dom_cols),
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * int(dom_cols), "valu": valu,
+                         "note": "824 B/column-step x columns of the launch / HIP-event time of that kernel; the kernel is VALU-issue "
+                                 "and divergence bound, not HBM bound (SURVEY 8d) -- see `valu`"},
+            "column_kernels_ms_per_step": {"land_or_mixed": run.class_ms[0] / K, "land_ice": run.class_ms[1] / K,
+                                           "skipped": run.class_ms[2] / K, "all_max_over_ranks": kernel_ms_max / K},
+            "kernel_only_column_steps_per_s": n_adv_all / (kernel_ms_max * 1e-3) if kernel_ms_max else None,
         }
+        if run.sorted:
+            out["sort"] = {"resorts_in_timed_region": run.resorts, "stale_columns_seen": run.stale_seen}
+        if run.lateral:
+            out["groundwater"] = {"calls": run.gw_calls, "stepwtd": run.stepwtd,
+                                  "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
+                                  "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     comm.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,34 +1,75 @@
-"""Build the in-tree HIP engine for gfx950 (cross-compiles without a GPU)."""
+"""Build the in-tree HIP engine for gfx950 (cross-compiles without a GPU).
+
+Every translation unit is compiled to its own object (in parallel, rebuilt only when it or a header changed) and the
+objects are linked into noahmp_amd/csrc/libnoahmp_hip.so."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libnoahmp_hip.so")
-SOURCES = ["noahmp_engine.hip", "noahmp_groundwater.hip", "noahmp_init.hip", "noahmp_forcing.hip", "noahmp_engine_d1_r1.hip", "noahmp_engine_d3_r1.hip", "noahmp_engine_d3_r5.hip", "noahmp_engine_d4_r1.hip", "noahmp_engine_d4_r3.hip", "noahmp_jit.hip"]
+SOURCES = ["noahmp_engine.hip", "noahmp_groundwater.hip", "noahmp_init.hip", "noahmp_forcing.hip", "noahmp_engine_d1_r1.hip",
+           "noahmp_engine_d3_r1.hip", "noahmp_engine_d3_r5.hip", "noahmp_engine_d4_r1.hip", "noahmp_engine_d4_r3.hip",
+           "noahmp_jit.hip", "noahmp_sort.hip", "noahmp_halo.hip"]
+
+
 def _headers():
     return [f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))] + ["../../include/noahmp_hip.h"]
+
+
 # -ffp-contract=off: keep the reference's a*b+c rounding (no FMA contraction); no fast-math.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wno-unused-value", "-I" + os.path.join(_HERE, "..", "include")]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + _headers())
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def needs_build():
+    return _stale(LIB, _sources() + _headers())
+
+
+def build(force=False, verbose=False, extra_flags=(), lib=None, jobs=None):
+    """extra_flags / lib: experiment builds (e.g. -DNMP_TRUNC=3 into another .so); they get their own object directory."""
+    lib = lib or LIB
+    if not force and not extra_flags and not needs_build():
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-lhiprtc", "-ldl"]
+    objdir = OBJ if lib == LIB else lib + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    flags = FLAGS + list(extra_flags)
+    stamp = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    hdrs = _headers()
+
+    def one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if force or not same_flags or _stale(obj, [src] + hdrs):
+            cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(jobs or min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, _sources()))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib, "-lhiprtc", "-ldl", "-lpthread"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ struct Engine {
   noahmp_tables* d_tables = nullptr;
   unsigned long long* d_err = nullptr;
   int* d_counts = nullptr;
+  int* d_gw_counts = nullptr;            // tallies of asynchronous groundwater calls (not reported)
   unsigned long long* h_err = nullptr;   // pinned
   int* h_counts = nullptr;               // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -42,6 +43,8 @@ struct Engine {
   std::vector<hipStream_t> async_streams;
   std::vector<hipEvent_t> async_events;     // start/end of each pending step's kernel   // every stream that carries pending asynchronous steps
   int async_nti = 1, async_its = 1, async_jts = 1;
+  float sync_class_ms[3] = {0.f, 0.f, 0.f};   // noahmp_hip_sync_timing
+  int sync_steps = 0;
   // host-memory path: row-chunk pipeline H2D | kernel | D2H on three streams, optional pinning of the caller's arrays
   hipStream_t s_up = nullptr, s_dn = nullptr;
   std::vector<hipEvent_t> pipe_events;
@@ -88,6 +91,7 @@ void launch_fixed_d4_r3(const LaunchDesc& d, int mode, hipStream_t s);
 // noahmp_jit.hip: the same for any option set o[12] = (DVEG, CRS, BTR, RUN, SFC, FRZ, INF, RAD, ALB, SNF, TBOT, STC), compiled on first use
 bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s);
 void jit_finalize();
+void sort_finalize();     // noahmp_sort.hip
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \

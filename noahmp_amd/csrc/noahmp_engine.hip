@@ -260,17 +260,22 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
   hipLaunchKernelGGL((noahmp_column_kernel<256, true, MODE>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k);
 }
 
-static void launch_any(const KArgs& k, hipStream_t s) {
+// class_ranges: the call is a whole device-resident tile, the only kind of call the declared class ranges can describe
+// mid: two events recorded after the land range and after the land-ice range (per-class kernel times of noahmp_hip_sync_timing)
+static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false, hipEvent_t* mid = nullptr) {
   const long ncol = (long)k.nti * k.ntj;
   if (ncol <= 0) return;
   // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
-  if (g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
+  if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
       g.block == 256 && g.use_lds) {
     launch_range<1>(k, 0, g.sorted_land, s);
+    if (mid) hipEventRecord(mid[0], s);
     launch_range<2>(k, g.sorted_land, g.sorted_glacier, s);
+    if (mid) hipEventRecord(mid[1], s);
     launch_range<3>(k, g.sorted_land + g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s);
     return;
   }
+  struct MidAtEnd { hipEvent_t* m; hipStream_t s; ~MidAtEnd() { if (m) { hipEventRecord(m[0], s); hipEventRecord(m[1], s); } } } at_end{mid, s};
   if (g.block == 256 && g.use_lds && fixed_level(k)) { launch_range<0>(k, 0, ncol, s); return; }
   if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
   else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
@@ -535,7 +540,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
   HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
   HIPCHK(hipEventRecord(g.ev0, s));
-  launch_any(k, s);
+  launch_any(k, s, mem == NOAHMP_MEM_DEVICE);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -586,15 +591,16 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
   // one event pair per step: kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
   // else the caller puts on the stream between them
-  while ((int)g.async_events.size() < 2 * (g.async_pending + 1)) {
+  while ((int)g.async_events.size() < 4 * (g.async_pending + 1)) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
     g.async_events.push_back(e);
   }
-  HIPCHK(hipEventRecord(g.async_events[2 * g.async_pending], s));
-  launch_any(k, s);
+  // events of a step: start | after the land (or mixed) kernel | after the land-ice kernel | end
+  HIPCHK(hipEventRecord(g.async_events[4 * g.async_pending], s));
+  launch_any(k, s, true, &g.async_events[4 * g.async_pending + 1]);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.async_events[2 * g.async_pending + 1], s));
+  HIPCHK(hipEventRecord(g.async_events[4 * g.async_pending + 3], s));
   g.async_pending++;
   g.async_stream = s;
   bool known = false;
@@ -621,11 +627,18 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   int code = 0;
   if (st) {
     float ms = 0.f;
+    for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f;
     for (int i = 0; i < nsteps; i++) {
       float one = 0.f;
-      hipEventElapsedTime(&one, g.async_events[2 * i], g.async_events[2 * i + 1]);
+      hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 3]);
       ms += one;
+      for (int c = 0; c < 3; c++) {
+        one = 0.f;
+        hipEventElapsedTime(&one, g.async_events[4 * i + c], g.async_events[4 * i + c + 1]);
+        g.sync_class_ms[c] += one;
+      }
     }
+    g.sync_steps = nsteps;
     st->kernel_ms = ms;
     int cnt[4];
     nmp_host::sum_counts(cnt);
@@ -638,6 +651,47 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
     if (st) { st->code = code; st->i = g.async_its + (int)(t % g.async_nti); st->j = g.async_jts + (int)(t / g.async_nti); }
   }
   return code;
+}
+
+int noahmp_hip_stream_sync(void* stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : g.own_stream));
+  return 0;
+}
+
+// dst column p <- src column perm[p] for every array of the step block ((re-)sorting a device-resident run)
+int noahmp_hip_permute_step_arrays(const noahmp_step_args* src, const noahmp_step_args* dst, const int32_t* perm, void* stream) {
+  int rc = ensure_init();
+  if (rc) return rc;
+  if (src->ims != dst->ims || src->ime != dst->ime || src->jms != dst->jms || src->jme != dst->jme || src->nsoil != dst->nsoil ||
+      src->kms != dst->kms || src->kme != dst->kme) {
+    g.last_error = "noahmp_hip_permute_step_arrays: the two blocks have different extents";
+    return -105;
+  }
+  const int ni = src->ime - src->ims + 1, nj = src->jme - src->jms + 1;
+  void* d[32]; const void* s[32]; int nl[32];
+  int n = 0;
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    s[n] = *(void* const*)((const char*)src + fd.off);
+    d[n] = *(void* const*)((const char*)dst + fd.off);
+    if (s[n] == d[n]) { g.last_error = std::string("noahmp_hip_permute_step_arrays: src and dst share array ") + fd.name; return -105; }
+    nl[n] = (int)(field_elems(fd, src) / ((size_t)ni * nj));
+    if (++n == 32 || f == kNumFields - 1) {
+      rc = noahmp_hip_gather_fields(n, d, s, nl, perm, ni, nj, stream);
+      if (rc) return rc;
+      n = 0;
+    }
+  }
+  return 0;
+}
+
+// Kernel time of the steps the last noahmp_hip_sync collected, by class range: out[0] = land kernel (or the mixed kernel of an
+// unsorted tile), out[1] = land-ice kernel, out[2] = skipped-cell kernel [ms, summed over the steps]; returns the number of steps.
+int noahmp_hip_sync_timing(float* out, int n) {
+  for (int c = 0; c < n && c < 3; c++) out[c] = g.sync_class_ms[c];
+  return g.sync_steps;
 }
 
 const char* noahmp_hip_error_string(int code) {
@@ -688,6 +742,7 @@ void noahmp_hip_finalize(void) {
 #ifndef NMP_NO_FIXED_KERNELS
   nmp_host::jit_finalize();
 #endif
+  nmp_host::sort_finalize();
   for (auto& p : g.gw_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto e : g.async_events) hipEventDestroy(e);
@@ -700,6 +755,7 @@ void noahmp_hip_finalize(void) {
   if (g.d_tables) hipFree(g.d_tables);
   if (g.d_err) hipFree(g.d_err);
   if (g.d_counts) hipFree(g.d_counts);
+  if (g.d_gw_counts) hipFree(g.d_gw_counts);
   if (g.h_err) hipHostFree(g.h_err);
   if (g.h_counts) hipHostFree(g.h_counts);
   if (g.ev0) hipEventDestroy(g.ev0);

@@ -72,10 +72,16 @@ extern "C" {
 
 size_t noahmp_hip_sizeof_wtable_args(void) { return sizeof(noahmp_wtable_args); }
 
-static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater);
+static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only = false);
 
 int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, false, 0);
+}
+
+// The same call for device-resident arrays without the host wait: the two kernels are enqueued on `stream` (ordered after the
+// column steps and the halo exchange the caller put there) and the call returns; its tallies are not reported.
+int noahmp_hip_wtable_mmf_async(const noahmp_wtable_args* a, void* stream) {
+  return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true);
 }
 
 int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int mem, void* stream, noahmp_status* st) {
@@ -84,7 +90,7 @@ int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int me
 
 }  // extern "C"
 
-static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater) {
+static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only) {
   if (st) memset(st, 0, sizeof(*st));
   int rc = nmp_host::ensure_init();
   if (rc) return rc;
@@ -129,6 +135,10 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   k.head = g.gw_head;
   k.err = g.d_err;
   k.counts = g.d_counts;
+  if (enqueue_only) {        // pending asynchronous column steps own d_counts: this call's tallies go to a buffer nobody reads
+    if (!g.d_gw_counts) HIPCHK(hipMalloc(&g.d_gw_counts, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int)));
+    k.counts = g.d_gw_counts;
+  }
 
   if (mem == NOAHMP_MEM_HOST) {
     // a resident column state (noahmp_hip_step, "resident_state") shares SMOIS / SH2O / ZWTXY ... with this call: bring the host
@@ -146,8 +156,10 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     }
   }
 
-  HIPCHK(hipMemsetAsync(g.d_counts, 0, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), s));
-  HIPCHK(hipEventRecord(g.ev0, s));
+  if (!enqueue_only) {
+    HIPCHK(hipMemsetAsync(g.d_counts, 0, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), s));
+    HIPCHK(hipEventRecord(g.ev0, s));
+  }
   const int hni = k.hi1 - k.hi0 + 1, hnj = k.hj1 - k.hj0 + 1;
   const int tni = a->ite - a->its + 1, tnj = a->jte - a->jts + 1;
   if (hni > 0 && hnj > 0)
@@ -161,6 +173,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   } else if (tni > 0 && tnj > 0)
     hipLaunchKernelGGL(gw_column_kernel, dim3((tni + BX - 1) / BX, (tnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
   HIPCHK(hipGetLastError());
+  if (enqueue_only) return 0;
   HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
   if (mem == NOAHMP_MEM_HOST) {

@@ -1,0 +1,203 @@
+// Column order of a device-resident tile: sort key, stable radix sort, staleness count and the
+// per-step forcing-scatter plan, all on the device.  BASELINE.json north_star: "option-branch divergence handled by
+// sorting columns by (vegetation type, snow-layer count) before launch".  The reference has no counterpart (its ILOOP
+// visits columns in (i,j) order, drv:397-424); columns are independent for every option except the MMF lateral flow,
+// so which lane computes which column is the engine's choice.  The snow-layer count changes while a run accumulates
+// or melts snow (lsm:7044 COMBINE, 7110 DIVIDE, 7177 COMBO, 7294-7343 SNOWH2O), so a run re-sorts when
+// noahmp_hip_sort_staleness() says enough columns left their bucket.
+#include <string.h>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "noahmp_hip.h"
+#include "nmp_engine_host.hpp"
+
+using nmp_host::g;
+
+namespace {
+
+struct KeyArgs {
+  const float* xland; const float* xice; const float* tsk;
+  const int* ivgtyp; const int* isnow;
+  float xice_thres, inv_bin;
+  int isice, flags;
+  long n;
+};
+
+// key = class(2) | a(6) | b(6) | tsk bin(8): class 0 land, 1 land ice, 2 skipped (the classification of drv:426-441);
+// a/b = vegetation type and snow-layer count in the order the flags ask for; skipped columns carry no sub-key.
+__device__ __forceinline__ unsigned column_key(const KeyArgs& k, long p) {
+  const float xland = k.xland[p], xice = k.xice[p];
+  const int ivg = k.ivgtyp[p];
+  const unsigned cls = ((xland - 1.5f) >= 0.f || xice >= k.xice_thres) ? 2u : (ivg == k.isice ? 1u : 0u);
+  if (cls == 2u) return 2u << 20;
+  unsigned veg = 0, sn = 0, tb = 0;
+  if (cls == 0u && (k.flags & NOAHMP_SORT_VEG)) veg = (unsigned)min(max(ivg, 0), 63);
+  if (k.flags & NOAHMP_SORT_SNOW) sn = (unsigned)min(max(-k.isnow[p], 0), 3);
+  if (k.inv_bin > 0.f) {
+    float t = k.tsk[p];
+    if (!(t == t)) t = 250.f;
+    tb = (unsigned)min(max((int)((t - 230.0f) * k.inv_bin), 0), 255);
+  }
+  const unsigned hi = (k.flags & NOAHMP_SORT_SNOW_FIRST) ? (sn << 6 | veg) : (veg << 6 | sn);
+  return cls << 20 | hi << 8 | tb;
+}
+constexpr unsigned kTskMask = 0xFFu;
+constexpr int kKeyBits = 22;
+
+__global__ void __launch_bounds__(256) sort_key_kernel(const KeyArgs k, unsigned* keys, int* idx) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= k.n) return;
+  keys[p] = column_key(k, p);
+  idx[p] = (int)p;
+}
+
+// number of columns whose key (without the temperature bin) differs from the key they were sorted by
+__global__ void __launch_bounds__(256) sort_stale_kernel(const KeyArgs k, const unsigned* sorted_keys, unsigned long long* slots) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool changed = false;
+  if (p < k.n) changed = ((column_key(k, p) ^ sorted_keys[p]) & ~kTskMask) != 0;
+  const unsigned long long m = __ballot(changed);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&slots[blockIdx.x & 255], (unsigned long long)__popcll(m));
+}
+
+// class boundaries of the sorted keys: out[0] = land columns, out[1] = land-ice columns
+__global__ void sort_bounds_kernel(const unsigned* keys, long n, long* out) {
+  if (threadIdx.x > 1) return;
+  const unsigned want = (threadIdx.x + 1u) << 20;          // first key >= want
+  long lo = 0, hi = n;
+  while (lo < hi) { const long mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
+  out[threadIdx.x] = lo;
+}
+
+__global__ void __launch_bounds__(256) invert_perm_kernel(const int* perm, int* inv, long n) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) inv[perm[p]] = (int)p;
+}
+
+// Scatter plan (noahmp_hip_scatter_fields): per chunk of 1024 consecutive tile columns, the columns ordered by their
+// destination in the sorted layout.  One workgroup sorts one chunk in LDS.
+constexpr int kChunk = 1024;
+__global__ void __launch_bounds__(256) scatter_plan_kernel(const int* inv, long n, unsigned short* order, int* dpos) {
+  using Sort = rocprim::block_radix_sort<int, 256, kChunk / 256, unsigned short>;
+  __shared__ typename Sort::storage_type st;
+  const long base = (long)blockIdx.x * kChunk;
+  int key[kChunk / 256];
+  unsigned short val[kChunk / 256];
+#pragma unroll
+  for (int r = 0; r < kChunk / 256; r++) {
+    const int off = threadIdx.x * (kChunk / 256) + r;
+    const long q = base + off;
+    key[r] = q < n ? inv[q] : 0x7FFFFFFF;
+    val[r] = (unsigned short)off;
+  }
+  Sort().sort(key, val, st);
+#pragma unroll
+  for (int r = 0; r < kChunk / 256; r++) {
+    const long q = base + threadIdx.x * (kChunk / 256) + r;
+    if (q < n) { order[q] = val[r]; dpos[q] = key[r] == 0x7FFFFFFF ? -1 : key[r]; }
+  }
+}
+
+int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_mk) {
+  if (a->ims != a->its || a->ime != a->ite || a->jms != a->jts || a->jme != a->jte) {
+    g.last_error = "column sort: the memory block must be the tile (a tile that carries a halo keeps its (i,j) order)";
+    return -105;
+  }
+  k.xland = a->xland; k.xice = a->xice; k.tsk = a->tsk; k.ivgtyp = a->ivgtyp; k.isnow = a->isnowxy;
+  k.xice_thres = a->xice_thres; k.isice = a->isice; k.flags = flags;
+  k.inv_bin = tsk_bin_mk > 0 ? 1000.0f / (float)tsk_bin_mk : 0.f;
+  k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
+  return 0;
+}
+
+struct SortScratch {
+  unsigned* keys_in = nullptr; int* idx_in = nullptr; unsigned* keys_out = nullptr; void* tmp = nullptr; int* inv = nullptr;
+  size_t keys_in_b = 0, idx_in_b = 0, keys_out_b = 0, tmp_b = 0, inv_b = 0;
+  unsigned long long* slots = nullptr;      // 256 staleness counters
+  long* h_bounds = nullptr;                 // pinned: 2 class boundaries + 256 staleness slots
+  long* d_bounds = nullptr;
+} sc;
+
+}  // namespace
+
+namespace nmp_host {
+void sort_finalize() {
+  hipFree(sc.keys_in); hipFree(sc.idx_in); hipFree(sc.keys_out); hipFree(sc.tmp); hipFree(sc.inv); hipFree(sc.slots); hipFree(sc.d_bounds);
+  if (sc.h_bounds) hipHostFree(sc.h_bounds);
+  sc = SortScratch();
+}
+}  // namespace nmp_host
+
+extern "C" {
+
+int noahmp_hip_sort_columns(const noahmp_step_args* a, int flags, int tsk_bin_mk, int32_t* perm_out, uint32_t* keys_out,
+                            int64_t* class_counts, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  KeyArgs k;
+  rc = fill_key_args(k, a, flags, tsk_bin_mk);
+  if (rc) return rc;
+  if (!perm_out) { g.last_error = "noahmp_hip_sort_columns: perm_out is required"; return -105; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  const long n = k.n;
+  if (n <= 0) { if (class_counts) class_counts[0] = class_counts[1] = class_counts[2] = 0; return 0; }
+  if (n > 0x7FFFFFFFL) { g.last_error = "noahmp_hip_sort_columns: more than 2^31 columns"; return -105; }
+  if ((rc = nmp_host::ensure_bytes((void**)&sc.keys_in, &sc.keys_in_b, n * 4))) return rc;
+  if ((rc = nmp_host::ensure_bytes((void**)&sc.idx_in, &sc.idx_in_b, n * 4))) return rc;
+  unsigned* kout = keys_out;
+  if (!kout) { if ((rc = nmp_host::ensure_bytes((void**)&sc.keys_out, &sc.keys_out_b, n * 4))) return rc; kout = sc.keys_out; }
+  if (!sc.d_bounds) { HIPCHK(hipMalloc(&sc.d_bounds, 2 * sizeof(long))); HIPCHK(hipHostMalloc((void**)&sc.h_bounds, 258 * sizeof(long), hipHostMallocDefault)); }
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(sort_key_kernel, dim3(nb), dim3(256), 0, s, k, sc.keys_in, sc.idx_in);
+  size_t need = 0;
+  HIPCHK(rocprim::radix_sort_pairs(nullptr, need, sc.keys_in, kout, sc.idx_in, perm_out, (size_t)n, 0, kKeyBits, s));
+  if ((rc = nmp_host::ensure_bytes(&sc.tmp, &sc.tmp_b, need))) return rc;
+  HIPCHK(rocprim::radix_sort_pairs(sc.tmp, need, sc.keys_in, kout, sc.idx_in, perm_out, (size_t)n, 0, kKeyBits, s));   // LSD radix: stable
+  if (class_counts) {
+    hipLaunchKernelGGL(sort_bounds_kernel, dim3(1), dim3(64), 0, s, kout, n, sc.d_bounds);
+    HIPCHK(hipMemcpyAsync(sc.h_bounds, sc.d_bounds, 2 * sizeof(long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    class_counts[0] = sc.h_bounds[0];
+    class_counts[1] = sc.h_bounds[1] - sc.h_bounds[0];
+    class_counts[2] = n - sc.h_bounds[1];
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int noahmp_hip_sort_staleness(const noahmp_step_args* a, int flags, const uint32_t* sorted_keys, int64_t* changed, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  KeyArgs k;
+  rc = fill_key_args(k, a, flags, 0);
+  if (rc) return rc;
+  if (!sorted_keys || !changed) { g.last_error = "noahmp_hip_sort_staleness: sorted_keys and changed are required"; return -105; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  *changed = 0;
+  if (k.n <= 0) return 0;
+  if (!sc.slots) HIPCHK(hipMalloc(&sc.slots, 256 * sizeof(unsigned long long)));
+  if (!sc.d_bounds) { HIPCHK(hipMalloc(&sc.d_bounds, 2 * sizeof(long))); HIPCHK(hipHostMalloc((void**)&sc.h_bounds, 258 * sizeof(long), hipHostMallocDefault)); }
+  HIPCHK(hipMemsetAsync(sc.slots, 0, 256 * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(sort_stale_kernel, dim3((unsigned)((k.n + 255) / 256)), dim3(256), 0, s, k, sorted_keys, sc.slots);
+  HIPCHK(hipMemcpyAsync(sc.h_bounds + 2, sc.slots, 256 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  long tot = 0;
+  for (int i = 0; i < 256; i++) tot += sc.h_bounds[2 + i];
+  *changed = tot;
+  return 0;
+}
+
+int noahmp_hip_scatter_plan(const int32_t* perm, int ni, int nj, uint16_t* order_out, int32_t* dpos_out, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  const long n = (long)ni * nj;
+  if (n <= 0) return 0;
+  if ((rc = nmp_host::ensure_bytes((void**)&sc.inv, &sc.inv_b, n * 4))) return rc;
+  hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, sc.inv, n);
+  hipLaunchKernelGGL(scatter_plan_kernel, dim3((unsigned)((n + kChunk - 1) / kChunk)), dim3(256), 0, s, sc.inv, n, order_out, dpos_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

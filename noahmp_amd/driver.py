@@ -101,6 +101,12 @@ class Engine:
             raise RuntimeError("noahmp_hip_wtable_mmf: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return st
 
+    def wtable_mmf_async(self, wargs, stream=None):
+        """Enqueue one WTABLE_mmf_noahmp call described by a prepared WtableArgs block (store.wtable_args(), device pointers)."""
+        rc = self.lib.noahmp_hip_wtable_mmf_async(C.byref(wargs), stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_wtable_mmf_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+
     def forcing_prep(self, store, lon, rain_rate, iday, ihour, iminute=0, isecond=0, scale_vegfra=False, stream=None,
                      first_step=False, wait=True):
         """Device-resident forcing preparation (reference hdrv:336-354 + CALC_DECLIN): `lon` and `rain_rate` are
@@ -164,38 +170,72 @@ class Engine:
             if rc:
                 raise RuntimeError("noahmp_hip_gather_fields: rc=%d" % rc)
 
-    def sort_store(self, store, tsk_bin=1.0):
-        """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, skin-temperature
-        bin) are adjacent (stable, so tile order is kept inside a group) and return the permutation as an int32
-        device tensor: sorted position p holds the column that was at linear tile index perm[p].  Columns are
-        independent (every option except the MMF lateral flow), so this only changes which lane computes which
-        column; wavefronts then hold columns that take the same branches: class and vegetation type select code
-        paths and are static, the skin temperature (`tsk_bin` K wide bins, 0 = off) is a cheap proxy for the
-        stability / freezing regime a column is in.  Forcing that arrives in tile order goes through `gather`."""
+    def stream_sync(self, stream=None):
+        """Wait for `stream` (None: the engine's own stream)."""
+        rc = self.lib.noahmp_hip_stream_sync(stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_stream_sync: " + self.lib.noahmp_hip_last_error().decode())
+
+    def sort_store(self, store, tsk_bin=1.0, veg=True, snow=True, snow_first=False, allow_lateral=False):
+        """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, snow-layer count,
+        skin-temperature bin) are adjacent, and return the permutation as an int32 device tensor: sorted position p holds the
+        column that sits at linear tile index perm[p] of the ORIGINAL tile order (a second call on an already sorted
+        store re-sorts it and returns the composed permutation).  Key, stable radix sort and the permutation of every
+        array run on the device (noahmp_hip_sort_columns / noahmp_hip_permute_step_arrays).  Columns are independent
+        (every option except the MMF lateral flow), so this only changes which lane computes which column; wavefronts
+        then hold columns that take the same branches: class and vegetation type select code paths and are static, the
+        snow-layer count bounds the layer loops and changes slowly (see sort_staleness), the skin temperature (`tsk_bin`
+        K wide bins, 0 = off) is a cheap proxy for the stability / freezing regime a column is in.  Forcing that arrives
+        in tile order goes through `scatter`."""
         import numpy as np
         import torch
         assert isinstance(store, DeviceColumnStore)
-        ivg = store.a["ivgtyp"].cpu().numpy().ravel().astype(np.int64)
-        xland = store.a["xland"].cpu().numpy().ravel()
-        xice = store.a["xice"].cpu().numpy().ravel()
-        cls = np.where((xland - 1.5 >= 0) | (xice >= store.cfg.xice_thres), 2, np.where(ivg == store.cfg.isice, 1, 0))
-        key = cls * 64 + np.where(cls == 0, np.clip(ivg, 0, 63), 0)
-        if tsk_bin:
-            tsk = np.nan_to_num(store.a["tsk"].cpu().numpy().ravel().astype(np.float64), nan=250.0)
-            key = key * 256 + np.clip(((tsk - 230.0) / tsk_bin).astype(np.int64), 0, 255)
-        perm = torch.from_numpy(np.argsort(key, kind="stable").astype(np.int32)).to(store.device)
+        # the stencil of WTABLE_mmf_noahmp needs the (i,j) neighbourhood: a sorted OPT_RUN=5 store must return its planes to
+        # tile order around every groundwater call (Engine.wtable_mmf_sorted)
+        assert store.cfg.iopt_run != 5 or allow_lateral, "OPT_RUN=5 needs the (i,j) order for WTABLE_mmf_noahmp"
+        n = store.ncol
+        flags = (abi.SORT_VEG if veg else 0) | (abi.SORT_SNOW if snow else 0) | (abi.SORT_SNOW_FIRST if snow_first else 0)
+        a = store.step_args(1, 2000, 1.0)
+        perm = torch.empty(n, dtype=torch.int32, device=store.device)
+        keys = torch.empty(n, dtype=torch.int32, device=store.device)
+        counts = (C.c_int64 * 3)()
+        torch.cuda.current_stream().synchronize()          # tensors written by torch kernels are read on the engine's stream
+        rc = self.lib.noahmp_hip_sort_columns(C.byref(a), flags, int(round(tsk_bin * 1000)) if tsk_bin else 0,
+                                              perm.data_ptr(), keys.data_ptr(), counts, None)
+        if rc:
+            raise RuntimeError("noahmp_hip_sort_columns: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        new = {k: (v if isinstance(v, np.ndarray) else torch.empty_like(v)) for k, v in store.a.items()}
+        old = store.a
+        store.a = new
+        b = store.step_args(1, 2000, 1.0)
+        rc = self.lib.noahmp_hip_permute_step_arrays(C.byref(a), C.byref(b), perm.data_ptr(), None)
+        if rc:
+            store.a = old
+            raise RuntimeError("noahmp_hip_permute_step_arrays: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        extra = [k for k in old if k not in abi.FIELD_INFO and not isinstance(old[k], np.ndarray)]    # e.g. the MMF planes
+        for i in range(0, len(extra), 32):
+            chunk = extra[i:i + 32]
+            Engine.Gather(self.lib, [new[k] for k in chunk], [old[k] for k in chunk], perm, store.ni, store.nj)()
+        prev = getattr(store, "sort_perm", None)
+        if prev is not None:                                 # already sorted: compose with the earlier permutation
+            total = torch.empty_like(perm)
+            Engine.Gather(self.lib, [total], [prev], perm, store.ni, store.nj)()
+            perm = total
+        self.stream_sync()
         # classes are contiguous now: land, land ice, skipped -- each range gets its own kernel (noahmp_engine.hip, launch_any)
-        store.class_ranges = (int((cls == 0).sum()), int((cls == 1).sum()))
-        names = [k for k, v in store.a.items() if not isinstance(v, np.ndarray)]
-        for i in range(0, len(names), 32):
-            chunk = names[i:i + 32]
-            src = [store.a[k] for k in chunk]
-            dst = [torch.empty_like(t) for t in src]
-            Engine.Gather(self.lib, dst, src, perm, store.ni, store.nj)()
-            torch.cuda.synchronize()
-            for k, t in zip(chunk, dst):
-                store.a[k] = t
+        store.class_ranges = (int(counts[0]), int(counts[1]))
+        store.sort_perm, store.sort_keys, store.sort_flags = perm, keys, flags
         return perm
+
+    def sort_staleness(self, store):
+        """Number of columns of a sorted store whose (class, vegetation type, snow-layer count) no longer is what they were
+        sorted by -- snow layers that appeared or vanished (lsm:7044, 7110, 7177, 7294-7343).  Waits for the engine's stream."""
+        a = store.step_args(1, 2000, 1.0)
+        changed = C.c_int64(0)
+        rc = self.lib.noahmp_hip_sort_staleness(C.byref(a), store.sort_flags, store.sort_keys.data_ptr(), C.byref(changed), None)
+        if rc:
+            raise RuntimeError("noahmp_hip_sort_staleness: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        return int(changed.value)
 
     def gather(self, dst, src, perm, ni, nj):
         return Engine.Gather(self.lib, dst, src, perm, ni, nj)
@@ -205,23 +245,21 @@ class Engine:
         to use for records that arrive every step."""
 
         def __init__(self, lib, dst, src, perm, ni, nj):
-            import numpy as np
-            import torch
             Engine.Gather.__init__(self, lib, dst, src, perm, ni, nj)
-            chunk = lib.noahmp_hip_scatter_chunk()
-            p = perm.cpu().numpy().astype(np.int64)
-            n = p.size
-            inv = np.empty(n, dtype=np.int64)
-            inv[p] = np.arange(n)                                   # inv[g] = sorted position of tile column g
-            npad = (n + chunk - 1) // chunk * chunk
-            invp = np.full(npad, np.iinfo(np.int64).max, dtype=np.int64)
-            invp[:n] = inv
-            invp = invp.reshape(-1, chunk)
-            order = np.argsort(invp, axis=1, kind="stable")
-            dpos = np.take_along_axis(invp, order, axis=1)
-            dpos[dpos == np.iinfo(np.int64).max] = -1
-            self.order = torch.from_numpy(order.astype(np.uint16).view(np.int16).ravel()[:n].copy()).to(perm.device)
-            self.dpos = torch.from_numpy(dpos.astype(np.int32).ravel()[:n].copy()).to(perm.device)
+            self.set_perm(perm)
+
+        def set_perm(self, perm):
+            """(Re)build the plan for `perm` on the device (noahmp_hip_scatter_plan); waits for it."""
+            import torch
+            n = perm.numel()
+            self.perm = perm
+            self.order = torch.empty(n, dtype=torch.int16, device=perm.device)
+            self.dpos = torch.empty(n, dtype=torch.int32, device=perm.device)
+            rc = self.lib.noahmp_hip_scatter_plan(perm.data_ptr(), self.ni, self.nj, self.order.data_ptr(), self.dpos.data_ptr(), None)
+            if rc == 0:
+                rc = self.lib.noahmp_hip_stream_sync(None)
+            if rc:
+                raise RuntimeError("noahmp_hip_scatter_plan: rc=%d" % rc)
 
         def __call__(self, stream=None):
             rc = self.lib.noahmp_hip_scatter_fields(self.n, self.dst, self.src, self.nlev, self.order.data_ptr(),
@@ -265,6 +303,12 @@ class Engine:
         if rc > 0 and check:
             raise NoahMPFatal(rc, st.i, st.j, "step +%d: %s" % (step.value, self.lib.noahmp_hip_error_string(rc).decode()))
         return st, step.value
+
+    def sync_timing(self):
+        """(land-or-mixed, land-ice, skipped) kernel ms summed over the steps of the last sync(), and their number."""
+        out = (C.c_float * 3)()
+        n = self.lib.noahmp_hip_sync_timing(out, 3)
+        return [float(x) for x in out], n
 
     def finalize(self):
         self.lib.noahmp_hip_finalize()

@@ -12,11 +12,15 @@ from .partition import partition, neighbours, tile_geometry
 
 
 class Comm:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, device_index=None):
+        """device_index: the GPU of this rank (default LOCAL_RANK); several ranks may share one GPU under gloo only
+        (a 1-GPU box exercising the N>1 code path)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.device_index = self.local_rank if device_index is None else int(device_index)
         self.dist = None
+        self.backend = None
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -24,8 +28,8 @@ class Comm:
             backend = backend or os.environ.get("NMP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                kw["device_id"] = torch.device("cuda", self.local_rank)
+                torch.cuda.set_device(self.device_index)
+                kw["device_id"] = torch.device("cuda", self.device_index)
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
             self.backend = backend
@@ -71,6 +75,8 @@ class Comm:
                 continue
             for p in planes:
                 sbuf = p[send_ix].contiguous()
+                if self.backend == "gloo" and sbuf.is_cuda:      # gloo has no device send/recv: stage through the host
+                    sbuf = sbuf.cpu()
                 rbuf = sbuf.new_empty(sbuf.shape)
                 ops.append(dist.P2POp(dist.isend, sbuf, peer))
                 ops.append(dist.P2POp(dist.irecv, rbuf, peer))
@@ -78,14 +84,14 @@ class Comm:
         if not ops:
             return
         for w in dist.batch_isend_irecv(ops):
-            w.wait()
+            w.wait()                                             # RCCL: orders the current stream after the transfer, no host wait
         for p, recv_ix, rbuf in landing:
-            p[recv_ix] = rbuf
+            p[recv_ix] = rbuf.to(p.device, non_blocking=True) if rbuf.device != p.device else rbuf
 
     # ---- timing / metric plumbing
     def _dev(self):
         import torch
-        return torch.device("cuda", self.local_rank) if (self.dist and self.backend == "nccl") else torch.device("cpu")
+        return torch.device("cuda", self.device_index) if (self.dist and self.backend == "nccl") else torch.device("cpu")
 
     def barrier(self):
         if self.dist:

@@ -150,7 +150,7 @@ def mixed_small(tables, ni=64, nj=8, seed=7, cfg=None, **kw):
                    glacier_frac=kw.get("glacier_frac", 0.05))
 
 
-def groundwater_fields(store, tables_dict, seed=4, area=1.0e6, stress=0.0, water_frac=0.03):
+def groundwater_fields(store, tables_dict, seed=4, area=1.0e6, stress=0.0, water_frac=0.03, x0=0, y0=0):
     """MMF planes for OPT_RUN=5: FDEPTH~U(50,200), TOPO = smooth random field,
     EQZWT~U(-20,-1), RIVERCOND~U(0,1e-2), RIVERBED=EQZWT-1, PEXP=1, AREA=dx*dx.
 
@@ -164,7 +164,7 @@ def groundwater_fields(store, tables_dict, seed=4, area=1.0e6, stress=0.0, water
     a = store.a
     nj, ni = store.nj, store.ni
     shp = (nj, ni)
-    y, x = np.meshgrid(np.arange(nj, dtype=np.float64), np.arange(ni, dtype=np.float64), indexing="ij")
+    y, x = np.meshgrid(np.arange(nj, dtype=np.float64) + y0, np.arange(ni, dtype=np.float64) + x0, indexing="ij")   # global cell indices
     topo = 300.0 + 40.0 * np.sin(x / 17.0 + 0.3) * np.cos(y / 23.0) + 15.0 * np.sin((x + 2 * y) / 7.0)
     a["topo"][...] = (topo + r.normal(0.0, 0.5, size=shp)).astype(F)
     a["fdepth"][...] = r.uniform(50.0, 200.0, size=shp).astype(F)
@@ -194,6 +194,36 @@ def groundwater_fields(store, tables_dict, seed=4, area=1.0e6, stress=0.0, water
     wat = r.random(size=shp) < water_frac
     a["xland"][wat] = 2.0
     return store
+
+
+ROW_BLOCK = 64
+
+
+def config3_tile(tables, gx, gy, x0=0, y0=0, nx=None, ny=None, seed=3, cfg=None, groundwater=False, **kw):
+    """Cells [x0, x0+nx) x [y0, y0+ny) (0-based) of ONE global gx x gy config-3 grid (config-4 grid with `groundwater`: the MMF
+    planes of groundwater_fields on top).  The grid is generated in blocks of ROW_BLOCK full rows, block b from the Philox key
+    (seed, b), so a tile is the same cells whatever the decomposition: what N ranks cut (mpp_land_partition_calc, mpp:227-288,
+    plus the 1-cell ring of gw:231-252) is what one rank holds.  -> ColumnStore of nx x ny cells with .t_offset."""
+    cfg = cfg or ModelConfig()
+    nx = gx - x0 if nx is None else nx
+    ny = gy - y0 if ny is None else ny
+    assert 0 <= x0 and x0 + nx <= gx and 0 <= y0 and y0 + ny <= gy
+    out = _base_store(nx, ny, cfg)
+    if groundwater:
+        out.add_groundwater()
+    out.t_offset = np.zeros((ny, nx), dtype=F)
+    for b in range(y0 // ROW_BLOCK, (y0 + ny - 1) // ROW_BLOCK + 1):
+        r0 = b * ROW_BLOCK
+        rows = min(ROW_BLOCK, gy - r0)
+        blk = config3(tables, ni=gx, nj=rows, seed=[seed, b], cfg=cfg, **kw)
+        if groundwater:
+            groundwater_fields(blk, tables, seed=[seed + 1, b], y0=r0)
+        lo, hi = max(y0, r0), min(y0 + ny, r0 + rows)
+        for k, v in blk.a.items():
+            if k != "dzs":
+                out.a[k][lo - y0:hi - y0] = v[lo - r0:hi - r0, ..., x0:x0 + nx]
+        out.t_offset[lo - y0:hi - y0] = blk.t_offset[lo - r0:hi - r0, x0:x0 + nx]
+    return out
 
 
 SNOW_EDGES = (0.025, 0.05, 0.10, 0.20, 0.25, 0.45)     # layer create / divide / combine depths [m] of SNOW_INIT, DIVIDE, COMBINE

@@ -13,6 +13,14 @@
 #ifndef NOAHMP_ORACLE_H
 #define NOAHMP_ORACLE_H
 #include "noahmp_hip.h"
+#include <math.h>
+/* EXP of the restatement = the pinned build of glibc's expf (nmp_pin_expf.c: the host libm picks one of two builds that differ
+ * at two arguments; the checker must not depend on the host it runs on) */
+float nmp_pin_expf(float x);
+int nmp_pin_expf_host_variant_is_pinned(void);
+#ifndef NMP_PIN_EXPF_IMPL
+#define expf nmp_pin_expf
+#endif
 
 typedef float real;
 

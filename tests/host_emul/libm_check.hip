@@ -166,3 +166,29 @@ extern "C" long libm_gpu_check(int fn, uint32_t start, uint32_t stride, long n, 
   }
   return bad;
 }
+
+// one argument, host compilation of the device header: the result's bit pattern (fn as in libm_check_unary)
+extern "C" uint32_t libm_eval_unary(int fn, uint32_t xbits) {
+  const float x = asfloat(xbits);
+  float r = 0.f;
+  switch (fn) {
+    case 0: r = expf_(x); break;
+    case 1: r = logf_(x); break;
+    case 2: r = log10f_(x); break;
+    case 3: r = atanf_(x); break;
+    case 4: r = tanhf_(x); break;
+    case 5: r = expm1f_(x); break;
+  }
+  return asuint(r);
+}
+
+// one argument evaluated on the GPU: the result's bit pattern, -1 on a HIP error
+extern "C" long libm_gpu_eval_unary(int fn, uint32_t xbits) {
+  float* d_out = nullptr;
+  float out = 0.f;
+  if (hipMalloc(&d_out, sizeof(float)) != hipSuccess) return -1;
+  hipLaunchKernelGGL(libm_eval_kernel, dim3(1), dim3(64), 0, 0, fn, xbits, 0u, 1L, (const float*)nullptr, d_out);
+  if (hipMemcpy(&out, d_out, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  hipFree(d_out);
+  return (long)asuint(out);
+}

@@ -148,9 +148,8 @@ def parity_check(ref, test, steps=1, frac=0.04, frac_medium=0.02, fields=None, m
 
 
 def exact_check(ref, test, fields=None, skip=(), allow_cols=0):
-    """Bit-for-bit comparison (NaN == NaN).  Returns (ok, lines); `allow_cols` columns may differ (used only
-    at >= 1e6 columns, where the 2-in-2^32 arguments on which this machine's FMA variant of libm expf rounds
-    differently from the plain-multiply-add evaluation can show up)."""
+    """Bit-for-bit comparison (NaN == NaN).  Returns (ok, lines).  `allow_cols` is 0 everywhere in the suite: the one host-dependent
+    operation, libm's expf (two builds that differ at two arguments), is pinned on both sides (oracle/nmp_pin_expf.c)."""
     import numpy as np
     from noahmp_amd.abi import FIELD_INFO
     names = fields or [k for k in ref.a if k in FIELD_INFO and FIELD_INFO[k][2] != "in"]
