@@ -233,6 +233,30 @@ class Run:
             self._bind_sorted()
             self.resorts += 1
 
+    def dump(self, path):
+        """The rank's INOUT / OUT arrays in tile order without the ring (tests compare decompositions with them)."""
+        import numpy as np
+        from noahmp_amd.abi import FIELD_INFO
+        self.ts.synchronize()
+        h = self.d.to_host()
+        g = self.geom
+        j0, j1 = g["jts"] - g["jms"], g["jte"] - g["jms"] + 1
+        i0, i1 = g["its"] - g["ims"], g["ite"] - g["ims"] + 1
+        inv = None
+        if self.sorted:
+            p = self.perm.cpu().numpy().astype(np.int64)
+            inv = np.empty_like(p)
+            inv[p] = np.arange(p.size)
+        out = {"geom": np.array([g["its"], g["ite"], g["jts"], g["jte"]])}
+        for k, v in h.a.items():
+            if k == "dzs" or (k in FIELD_INFO and FIELD_INFO[k][2] == "in"):
+                continue
+            if inv is not None:                      # sorted position -> tile order
+                v = (v.transpose(1, 0, 2).reshape(v.shape[1], -1)[:, inv].reshape(v.shape[1], v.shape[0], v.shape[2]).transpose(1, 0, 2)
+                     if v.ndim == 3 else v.reshape(-1)[inv].reshape(v.shape))
+            out[k] = v[j0:j1, ..., i0:i1]
+        np.savez(path, **out)
+
     def reset_counters(self):
         self.kernel_ms, self.class_ms, self.n_adv, self.n_land, self.resorts, self.stale_seen = 0.0, [0.0, 0.0, 0.0], 0, 0, 0, []
         self.halo_events, self.gw_calls = [], 0
@@ -262,6 +286,7 @@ def main():
     ap.add_argument("--resort-frac", type=float, default=0.01, help="re-sort when this share of the columns left their bucket")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default=None, help="write every rank's tile (tile order, without the ring) to DUMP.rank<r>.npz after the run")
     ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -322,6 +347,9 @@ def main():
     halo_ms = sum(e0.elapsed_time(e1) for e0, e1 in run.halo_events)
     halo_ms_max = comm.reduce_max(halo_ms)
     kernel_ms_max = comm.reduce_max(run.kernel_ms)
+
+    if args.dump:
+        run.dump(args.dump + ".rank%d.npz" % rank)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

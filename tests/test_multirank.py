@@ -176,3 +176,112 @@ def test_groundwater_halo_exchange_matches_single_domain(world, port, tables):
         for k in GW_OUT:
             want = g.a[k][geo["jts"] - 1:geo["jte"], ..., geo["its"] - 1:geo["ite"]]
             np.testing.assert_array_equal(want, part[k], err_msg="%s tile its=%d jts=%d" % (k, geo["its"], geo["jts"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# The N > 1 path of bench.py itself: every rank cuts its memory block (tile + ring) from ONE global grid
+# (synth.config3_tile), steps it and runs WTABLE_mmf_noahmp after the ZWTXY ring exchange.  Parity target: one rank.
+def _cfg4_worker(rank, world, port, gx, gy, nsteps, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    from noahmp_amd.parallel import Comm
+    from noahmp_amd.state import ModelConfig
+    from noahmp_amd.tables import load_tables
+    from oracle.portlib import PortLib
+    comm = Comm(backend="gloo")
+    T, tb = load_tables("usgs")
+    port_ = PortLib(autobuild=False)
+    port_.set_tables(T)
+    cfg = ModelConfig(iopt_run=5)
+    geo = comm.my_geometry(gx, gy)                          # the geometry bench.py's Run uses (partition.tile_geometry, halo 1)
+    nx, ny = geo["ime"] - geo["ims"] + 1, geo["jme"] - geo["jms"] + 1
+    s = synth.config3_tile(tb, gx, gy, geo["ims"] - 1, geo["jms"] - 1, nx, ny, cfg=cfg, groundwater=True)
+    s.set_index(**{k: geo[k] for k in ("ids", "ide", "jds", "jde", "ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")})
+    synth.first_step_fixups(s)
+    ring = np.ones((ny, nx), dtype=bool)
+    ring[geo["jts"] - geo["jms"]:geo["jte"] - geo["jms"] + 1, geo["its"] - geo["ims"]:geo["ite"] - geo["ims"] + 1] = False
+    for k in ("zwtxy", "fdepth", "topo"):                   # only the exchange may provide the ring
+        s.a[k][ring] = np.nan
+    s.a["isltyp"][ring] = -7
+    comm.exchange_halo([torch.from_numpy(s.a[k]) for k in ("fdepth", "topo", "isltyp")], geo)
+    for it in range(1, nsteps + 1):
+        synth.diurnal_forcing(s, (it + 5) % 24, t_offset=s.t_offset)
+        assert port_.noahmplsm(s, it, 2000, 180.0).code == 0
+        comm.exchange_halo([torch.from_numpy(s.a["zwtxy"])], geo)
+        port_.wtable_mmf(s)
+    j0, j1 = geo["jts"] - geo["jms"], geo["jte"] - geo["jms"] + 1
+    i0, i1 = geo["its"] - geo["ims"], geo["ite"] - geo["ims"] + 1
+    part = {k: v[j0:j1, ..., i0:i1].copy() for k, v in s.a.items() if k != "dzs" and (k not in FIELD_INFO or FIELD_INFO[k][2] != "in")}
+    parts = comm.gather_to_root((geo, part))
+    if rank == 0:
+        q.put(parts)
+    comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_config4_ranks_cut_one_global_grid(world, port, tables):
+    gx, gy, nsteps = 70, 130, 3                           # three row blocks of the generator, uneven tiles
+    from noahmp_amd.state import ModelConfig
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = _free_port()
+    procs = [ctx.Process(target=_cfg4_worker, args=(r, world, p, gx, gy, nsteps, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    parts = q.get(timeout=300)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    g = synth.config3_tile(tables[1], gx, gy, cfg=ModelConfig(iopt_run=5), groundwater=True)
+    synth.first_step_fixups(g)
+    for it in range(1, nsteps + 1):
+        synth.diurnal_forcing(g, (it + 5) % 24, t_offset=g.t_offset)
+        assert port.noahmplsm(g, it, 2000, 180.0).code == 0
+        port.wtable_mmf(g)
+    assert (g.a["qslat"] != 0).any()
+    for geo, part in parts:
+        for k, v in part.items():
+            want = g.a[k][geo["jts"] - 1:geo["jte"], ..., geo["its"] - 1:geo["ite"]]
+            assert np.array_equal(want, v, equal_nan=True), "%s tile its=%d jts=%d" % (k, geo["its"], geo["jts"])
+
+
+def _run_bench(extra, tmp, tag):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NMP_DIST_BACKEND="gloo")          # two ranks on ONE GPU: host-staged ring exchange
+    env.pop("WORLD_SIZE", None)
+    dump = os.path.join(tmp, tag)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ni", "96", "--nj", "130", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--dump", dump] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    return json.loads(line[0]), dump
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config4", "config3"])
+def test_bench_two_ranks_equal_one_rank(workload, tmp_path):
+    """`bench.py --gpus 2` starts its two ranks itself (here both on the one GPU, ring exchange staged through the host) and
+    prints n_gpus: 2; the union of the ranks' tiles equals the single-rank run of the same global grid bit for bit -- the
+    config-4 groundwater step included (parity target: the single domain)."""
+    one, d1 = _run_bench(["--gpus", "1", "--workload", workload], str(tmp_path), "one")
+    two, d2 = _run_bench(["--gpus", "2", "--workload", workload], str(tmp_path), "two")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    if workload == "config4":
+        assert two["groundwater"]["calls"] == 5 and "RCCL" in two["config"]["parallelism"]
+    whole = np.load(d1 + ".rank0.npz")
+    seen = 0
+    for r in range(2):
+        part = np.load(d2 + ".rank%d.npz" % r)
+        its, ite, jts, jte = part["geom"]
+        for k in part.files:
+            if k == "geom":
+                continue
+            want = whole[k][jts - 1:jte, ..., its - 1:ite]
+            assert np.array_equal(want, part[k], equal_nan=True), "%s rank %d" % (k, r)
+        seen += (ite - its + 1) * (jte - jts + 1)
+    assert seen == 96 * 130
