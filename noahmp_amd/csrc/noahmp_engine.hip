@@ -408,21 +408,22 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
   fill_kargs(k, a);
   if (g.mirror_host.empty()) g.mirror_host.assign(kNumFields, nullptr);
   bool valid = g.resident_valid;
-  for (int f = 0; f < kNumFields; f++) {
+  for (int f = 0; f < kNumFields; f++) {       // pass 1: are these the arrays (and extents) of the resident state?
     const FieldDesc& fd = kFields[f];
-    const size_t bytes = field_elems(fd, a) * 4;
-    const void* host = *(void* const*)((const char*)a + fd.off);
+    if (g.mirror_bytes[f] != field_elems(fd, a) * 4 || g.mirror_host[f] != *(void* const*)((const char*)a + fd.off)) valid = false;
+  }
+  if (!valid && g.resident_dirty) {            // other arrays than last time while results are still only on the device:
+    int rc = noahmp_hip_fetch(nullptr);        // bring the PREVIOUS call's host arrays up to date before any mirror is touched
+    if (rc) return rc;
+  }
+  for (int f = 0; f < kNumFields; f++) {       // pass 2: only now may the mirrors change size
+    const size_t bytes = field_elems(kFields[f], a) * 4;
     if (g.mirror_bytes[f] != bytes) {
       if (g.mirror[f]) HIPCHK(hipFree(g.mirror[f]));
+      g.mirror[f] = nullptr; g.mirror_bytes[f] = 0;
       HIPCHK(hipMalloc(&g.mirror[f], bytes));
       g.mirror_bytes[f] = bytes;
-      valid = false;
     }
-    if (g.mirror_host[f] != host) valid = false;
-  }
-  if (!valid && g.resident_dirty) {            // other arrays than last time while results are still only on the device
-    int rc = noahmp_hip_fetch(nullptr);
-    if (rc) return rc;
   }
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];

@@ -106,6 +106,7 @@ def fetch(engine, store, names, perm=None, mask=()):
     if perm is not None:
         inv = torch.empty_like(perm)
         inv[perm.long()] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
+        torch.cuda.current_stream().synchronize()      # `inv` is written on torch's stream and read on the engine's own stream
     veg = store.a["ivgtyp"]
     for i in range(0, len(names), 32):
         chunk = names[i:i + 32]

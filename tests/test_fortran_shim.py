@@ -28,14 +28,52 @@ def test_shim_compiles_and_links():
     assert "noahmp_hip_step" in und and "noahmp_hip_set_tables" in und
 
 
+def _reference_signatures():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "signatures.json")))
+
+
+def _shim_dummies(src, name):
+    up = src.upper()
+    at = up.index("SUBROUTINE %s(" % name.upper())
+    head = up[at:up.index("USE ISO_C_BINDING", at)]
+    return [x.strip().lower() for x in head[head.index("(") + 1:head.rindex(")")].replace("&", "").replace("\n", "").split(",")]
+
+
 def test_shim_signature_matches_reference_order():
-    """Dummy-argument order of the generated noahmplsm == drv:11-44 (as recorded in abi_spec)."""
-    from noahmp_amd.abi_spec import STEP_FIELDS
-    src = open(os.path.join(os.path.dirname(abi.__file__), "fortran", "module_sf_noahmpdrv_hip.F90")).read().upper()
-    head = src[src.index("SUBROUTINE NOAHMPLSM("):src.index("USE ISO_C_BINDING", src.index("SUBROUTINE NOAHMPLSM("))]
-    names = [x.strip() for x in head[head.index("(") + 1:head.rindex(")")].replace("&", "").replace("\n", "").split(",")]
-    assert names == [n.upper() for n, k, l, io, ln in STEP_FIELDS]
-    assert names[:5] == ["ITIMESTEP", "YR", "JULIAN", "COSZIN", "XLATIN"] and names[-1] == "KTE"
+    """Dummy-argument lists of the generated noahmplsm / WTABLE_mmf_noahmp == the reference's own (drv:11-44 without the
+    WRF_HYDRO block, which is off by default: configure:55-61; gw:14-22) as parsed out of /root/reference by
+    tests/golden/make_signatures.py -- not as recorded by the builder's abi_spec."""
+    ref = _reference_signatures()
+    src = open(os.path.join(os.path.dirname(abi.__file__), "fortran", "module_sf_noahmpdrv_hip.F90")).read()
+    names = _shim_dummies(src, "noahmplsm")
+    assert names == ref["noahmplsm"]["dummies"] and len(names) == 158
+    assert ref["noahmplsm"]["conditional"] == {"WRF_HYDRO": ["accprcp", "accecan", "accetran", "accedir", "sfcheadrt", "infxsrt", "soldrain"]}
+    assert _shim_dummies(src, "WTABLE_mmf_noahmp") == ref["wtable_mmf_noahmp"]["dummies"]
+
+
+def test_abi_blocks_follow_the_reference_dummy_lists():
+    """noahmp_step_args / noahmp_wtable_args have one member per dummy argument, in the reference's order."""
+    from noahmp_amd.abi_spec import STEP_FIELDS, WTABLE_FIELDS
+    ref = _reference_signatures()
+    assert [n for n, k, l, io, ln in STEP_FIELDS] == ref["noahmplsm"]["dummies"]
+    assert [n for n, k, l, io, ln in WTABLE_FIELDS] == ref["wtable_mmf_noahmp"]["dummies"]
+    assert [n for n, _ in abi.StepArgs._fields_] == ref["noahmplsm"]["dummies"]
+
+
+def test_signature_fixture_is_current():
+    """In the dev container (where /root/reference exists) the committed fixture equals a fresh parse."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("no /root/reference here")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_signatures", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_signatures.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ref = _reference_signatures()
+    for key, rel, sub in (("noahmplsm", "phys/module_sf_noahmpdrv.F90", "noahmplsm"),
+                          ("wtable_mmf_noahmp", "phys/module_sf_noahmp_groundwater.F90", "WTABLE_mmf_noahmp")):
+        plain, cond, span = m.dummy_list(os.path.join("/root/reference", rel), sub)
+        assert plain == ref[key]["dummies"] and cond == ref[key]["conditional"]
 
 
 @pytest.mark.gpu

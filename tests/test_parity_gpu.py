@@ -547,6 +547,36 @@ def test_resident_host_path_lazy_download(engine, port, tables):
     _check(plain, other, engine, steps=nsteps + 1, fields=_outs(plain))
 
 
+def test_resident_host_path_alternating_tiles_of_different_size(engine, tables):
+    """Two tiles (nests) of different extents advanced alternately with "resident_state" + "lazy_download": a call with other
+    arrays first brings the previous tile's host arrays up to date from the still intact mirrors, and only then re-sizes the
+    mirrors -- every tile ends with the bits of the ordinary host path."""
+    big = synth.mixed_small(tables[1], ni=160, nj=12, seed=61)
+    small = synth.mixed_small(tables[1], ni=48, nj=5, seed=62)
+    for s in (big, small):
+        synth.first_step_fixups(s)
+    want = {}
+    for name, s in (("big", big), ("small", small)):
+        p = s.copy()
+        for it in (1, 2):
+            synth.diurnal_forcing(p, 11 + it, t_offset=s.t_offset)
+            engine.noahmplsm(p, it, 2000, 180.0)
+        want[name] = p
+    try:
+        engine.set_option("resident_state", 1)
+        engine.set_option("lazy_download", 1)
+        for it in (1, 2):
+            for s in (big, small):                       # big, small, big, small: every call meets the other tile's mirrors
+                synth.diurnal_forcing(s, 11 + it, t_offset=s.t_offset)
+                assert engine.noahmplsm(s, it, 2000, 180.0).code == 0
+        engine.fetch()
+    finally:
+        engine.set_option("lazy_download", 0)
+        engine.set_option("resident_state", 0)
+    _check(want["big"], big, engine, steps=2, fields=_outs(big))
+    _check(want["small"], small, engine, steps=2, fields=_outs(small))
+
+
 @pytest.mark.parametrize("dveg,run", [(1, 1), (3, 1), (4, 1), (4, 3), (2, 1)])
 def test_option_specialised_kernels_bit_identical(engine, tables, dveg, run):
     """Calls whose options are the reference's namelist values (DVEG 1 or 3) run kernels compiled with those options as

@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -19,7 +19,8 @@ KERN = "noahmp_column_kernel"
 stats = (glob.glob(os.path.join(src, "trace", "*_kernel_stats.csv")) +
          glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))[0]
 shutil.copy(stats, os.path.join(dst, "%s_kernel_stats.csv" % tag))
-krow = [r for r in csv.DictReader(open(stats)) if KERN in r["Name"]][0]
+krow = max([r for r in csv.DictReader(open(stats)) if KERN in r["Name"]], key=lambda r: float(r["TotalDurationNs"]))
+KNAME = krow["Name"]                 # the dominant instantiation (land range of the sorted layout)
 
 pmc = {}
 meta = {}
@@ -29,7 +30,7 @@ for d in ("fetch", "write", "sq", "sq2"):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if KERN in r["Kernel_Name"]:
+        if r["Kernel_Name"] == KNAME:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
                                       "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
@@ -37,7 +38,7 @@ for d in ("fetch", "write", "sq", "sq2"):
         pmc[k] = sum(v) / len(v)
 
 bench = json.loads(open(os.path.join(src, "bench_plain.json")).read())
-ncol = bench["config"]["columns_per_gpu"]
+ncol = bench["roofline"]["columns_per_launch"]           # columns one launch of the dominant kernel advances
 alg = 824 * ncol
 # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies each 128-B request at 64 B -> x2; both counters are in KiB.
 # The read pattern here (one dword per lane, 256 B contiguous per wave instruction) is not one of the
@@ -47,7 +48,8 @@ write_b = pmc.get("WRITE_SIZE", 0) * 1024
 traffic = fetch_b + write_b
 waves = pmc.get("SQ_WAVES", 1)
 out = {
-    "round": tag, "kernel": krow["Name"], "calls": int(krow["Calls"]),
+    "round": tag, "workload": "config3" if "configs[2]" in bench["config"]["workload"] else ("config2" if "configs[1]" in bench["config"]["workload"] else "config4"),
+    "kernel": krow["Name"], "calls": int(krow["Calls"]),
     "avg_kernel_ns": float(krow["AverageNs"]), "min_ns": float(krow["MinNs"]), "max_ns": float(krow["MaxNs"]),
     "launch": meta, "columns_per_launch": ncol,
     "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_launch": traffic,
@@ -56,6 +58,7 @@ out = {
     "pmc_mean_per_launch": pmc,
     "derived": {
         "valu_insts_per_column_step": pmc.get("SQ_INSTS_VALU", 0) / waves,
+        "valu_wave_insts_per_launch": pmc.get("SQ_INSTS_VALU", 0),
         "salu_insts_per_wave": pmc.get("SQ_INSTS_SALU", 0) / waves,
         "lane_utilisation": pmc.get("SQ_THREAD_CYCLES_VALU", 0) / max(pmc.get("SQ_ACTIVE_INST_VALU", 1) * 64, 1),
         "valu_active_share_of_wave_cycles": pmc.get("SQ_ACTIVE_INST_VALU", 0) / max(pmc.get("SQ_WAVE_CYCLES", 1), 1),
@@ -64,14 +67,14 @@ out = {
     "bench_line": bench,
 }
 json.dump(out, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
-L = ["# %s profile: `python3 bench.py` under rocprofv3 (MI355X, 1 GPU, config 2: %d columns/launch)" % (tag, ncol), "",
+L = ["# %s profile: `python3 bench.py` under rocprofv3 (MI355X, 1 GPU, %s: %d columns per launch of the dominant kernel)" % (tag, out["workload"], ncol), "",
      "## `rocprofv3 --kernel-trace --stats` (copied: %s_kernel_stats.csv)" % tag, "",
      "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
 for r in csv.DictReader(open(stats)):
     L.append("| %s | %s | %.0f | %s | %s | %s |" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
 L += ["", "Launch: grid %(Grid_Size)s, workgroup %(Workgroup_Size)s, LDS %(LDS_Block_Size)s B/block, scratch %(Scratch_Size)s B/lane, "
       "VGPR %(VGPR_Count)s, AGPR %(Accum_VGPR_Count)s, SGPR %(SGPR_Count)s (rocprofv3's fields; the compiler's "
-      "`-Rpass-analysis=kernel-resource-usage` report for this kernel is 256 unified VGPRs, 2 spilled (option-specialised land-only kernel; 136 in the generic one), 2 waves/SIMD)." % meta, "",
+      "`-Rpass-analysis=kernel-resource-usage` report for this kernel is 255 unified VGPRs, 4 spilled, 32 B/lane scratch (option-specialised land-only kernel), 2 waves/SIMD)." % meta, "",
       "## PMC (separate `--pmc` passes, mean per launch of the column kernel)", "", "| counter | mean per launch |", "|---|---|"]
 for k in sorted(pmc):
     L.append("| %s | %.4g |" % (k, pmc[k]))
@@ -82,7 +85,9 @@ L += ["", "## Derived", "",
       "- VALU instructions per column-step (per wave) = %.0f; lane utilisation %.1f %%; VALU-active %.0f %% and waiting %.0f %% of wave cycles"
       % (out["derived"]["valu_insts_per_column_step"], 100 * out["derived"]["lane_utilisation"],
          100 * out["derived"]["valu_active_share_of_wave_cycles"], 100 * out["derived"]["wait_any_share_of_wave_cycles"]),
-      "- the kernel is VALU-issue / divergence bound, not HBM bound (SURVEY.md 8d): ~5 flop-equivalents per byte with long dependent chains",
+      "- VALU-issue roofline: %.4g wave64 VALU instructions per launch x 2 issue cycles / (1024 SIMDs x 2.4 GHz x %.3f ms) = **%.1f %%** of the chip's VALU issue slots (two waves per SIMD, each issuing at most every 4 cycles)"
+      % (pmc.get("SQ_INSTS_VALU", 0), float(krow["AverageNs"]) / 1e6, 100 * pmc.get("SQ_INSTS_VALU", 0) * 2 / (1024 * 2.4e9 * float(krow["AverageNs"]) * 1e-9)),
+      "- the kernel is VALU-issue / register-occupancy bound, not HBM bound (SURVEY.md 8d): ~5 flop-equivalents per byte with long dependent chains",
       "", "## bench.py line of the same build (un-profiled run)", "", "```", json.dumps(bench), "```", ""]
 # ---- MMF groundwater kernels (tools/gw_check.py perf, 4608 x 1536 cells)
 gws = glob.glob(os.path.join(src, "gw", "*_kernel_stats.csv"))

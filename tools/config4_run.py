@@ -25,7 +25,7 @@ comm = Comm()
 T, tb = load_tables("usgs")
 eng = Engine(T, device=comm.local_rank)
 cfg = ModelConfig(iopt_run=5)
-stepwtd = max(int(round(cfg.wtddt * 60.0 / cfg.dt)), 1)              # hdrv:1227
+stepwtd = max(int(cfg.wtddt * 60.0 / cfg.dt + 0.5), 1)               # hdrv:1227 NINT (round half away from zero)
 if comm.world == 1:
     s = synth.config3(tb, ni=gni, nj=gnj, cfg=cfg)
     geom = None
@@ -46,6 +46,7 @@ if geom is not None:
 
 
 def step(it):
+    eng.stream_sync()                                      # the previous step's kernel may still read the planes overwritten below
     for k, v in forc[(it - 1) % 24].items():
         d.a[k].copy_(v)
     torch.cuda.current_stream().synchronize()

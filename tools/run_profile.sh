@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/: run ON THE GPU BOX from the repo root, e.g.
 #   gpurun --timeout 1500 -- 'bash tools/run_profile.sh'
-# then, back in the dev container:  python tools/collect_profile.py r01
+# then, back in the dev container:  python tools/collect_profile.py r02
 # Counters are collected in their own passes (never together with a trace), as the guide prescribes.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
