@@ -285,6 +285,9 @@ def main():
     ap.add_argument("--resort-every", type=int, default=24, help="steps between staleness checks of the sorted layout (0 = never)")
     ap.add_argument("--resort-frac", type=float, default=0.01, help="re-sort when this share of the columns left their bucket")
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--halo", choices=("torch", "rccl", "tcp"), default=os.environ.get("NMP_HALO", "torch"),
+                    help="who moves the groundwater ring: torch.distributed send/recv (RCCL under the nccl backend), or the engine's "
+                         "C-ABI exchange noahmp_hip_exchange_halo with its RCCL or socket transport")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="write every rank's tile (tile order, without the ring) to DUMP.rank<r>.npz after the run")
     ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)
@@ -313,7 +316,7 @@ def main():
         raise RuntimeError("bench.py: no GPU visible (the engine has no CPU path)")
     dev_index = local_rank % ndev            # several ranks on one GPU: only with NMP_DIST_BACKEND=gloo (1-GPU check of the N>1 path)
     torch.cuda.set_device(dev_index)
-    comm = Comm(device_index=dev_index)      # one process per GPU; "nccl" = RCCL when world > 1
+    comm = Comm(device_index=dev_index, halo=args.halo)      # one process per GPU; "nccl" = RCCL when world > 1
     dev = torch.device("cuda", dev_index)
     eng = Engine(T, device=dev_index, lib_path=os.environ.get("NMP_LIB"))
     if os.environ.get("NMP_BLOCK"):
@@ -399,7 +402,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "grid": [args.ni, args.nj], "columns_per_gpu": run.tile_cells,
                        "parallelism": ("1 GPU" if world == 1 else "%d tiles (mpp_land_partition_calc), one rank per GPU%s"
-                                       % (world, ", RCCL ZWTXY ring exchange" if run.lateral else ", no collective"))},
+                                       % (world, (", RCCL ZWTXY ring exchange (%s)" % {"torch": "torch.distributed send/recv", "rccl": "noahmp_hip_exchange_halo, RCCL transport",
+                                                                          "tcp": "noahmp_hip_exchange_halo, socket transport"}[args.halo])
+                                          if run.lateral else ", no collective"))},
             "timed_region_s": dt, "setup_s": t_setup,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -60,7 +60,7 @@ struct Engine {
   bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
   std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call
   noahmp_step_args resident_args;                        // the argument block of that call (for fetch)
-  int jit_kernels = 0;          // compile a specialised kernel at run time (hiprtc) for option sets without an ahead-of-time one
+  int jit_kernels = 1;          // compile a specialised kernel at run time (hiprtc, cached on disk) for option sets without an ahead-of-time one
   int jit_compile_only = 0;     // test hook: compile, do not load or launch (works without a GPU)
   int fixed_kernels = 1;        // use the option-specialised kernels when a call's options are the reference's namelist values
   long sorted_land = -1, sorted_glacier = -1;   // class ranges of a sorted device-resident layout (-1: not declared)
@@ -91,6 +91,8 @@ void launch_fixed_d4_r3(const LaunchDesc& d, int mode, hipStream_t s);
 // noahmp_jit.hip: the same for any option set o[12] = (DVEG, CRS, BTR, RUN, SFC, FRZ, INF, RAD, ALB, SNF, TBOT, STC), compiled on first use
 bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s);
 void jit_finalize();
+void jit_stats(int* out);
+std::string cache_dir_public();
 void sort_finalize();     // noahmp_sort.hip
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \

@@ -1,0 +1,365 @@
+// Halo exchange of the MMF lateral-flow ring through the C-ABI: noahmp_hip_halo_init / noahmp_hip_exchange_halo.
+//
+// LATERALFLOW (gw:231-292) reads WTD, FDEPTH, TOPO and ISLTYP on the 1-cell ring around a rank's tile, corners included.  The
+// reference fills such rings with mpp_land_comlr_real followed by mpp_land_comub_real, flag 99 (mpp:344-369, 603-642): first
+// left/right over the tile's rows, then down/up over whole memory rows, which by then carry the columns received in the first
+// phase -- corners arrive without diagonal messages.  This file does the same for a caller with one rank per GPU
+// (mpp_land_get_nprocsxy's rank grid, mpp:124-141; neighbours as mpp:93-107) and needs neither MPI nor torch:
+//   * rendezvous over TCP (rank 0 listens on master_addr:master_port; every rank learns its neighbours' listeners);
+//   * transport NOAHMP_HALO_RCCL: ncclSend / ncclRecv of packed edges in one group per phase on the caller's stream
+//     (RCCL over xGMI, GPU-direct; librccl is loaded with dlopen at init, its unique id travels over the rendezvous);
+//   * transport NOAHMP_HALO_TCP: the packed edges travel over the rendezvous sockets (host planes directly, device planes through a
+//     pinned staging buffer) -- the form the CPU tests and single-GPU checks use, and a fallback where RCCL is not available.
+// <= 4 messages of one tile edge per phase and plane set (~25 KB at the config-4 grid on 8 ranks): latency-bound, so all planes of a
+// call share the messages of a phase.
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <time.h>
+#include <unistd.h>
+#include <string>
+#include <vector>
+#include "noahmp_hip.h"
+#include "nmp_engine_host.hpp"
+
+using nmp_host::g;
+
+namespace {
+
+// ---- RCCL entry points (resolved at run time: the library is not a link dependency)
+typedef struct { char internal[128]; } NcclUniqueId;
+typedef void* NcclComm;
+struct Rccl {
+  void* handle = nullptr;
+  int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+  int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(NcclComm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclInt32 = 2;      // ncclInt32 / ncclInt (nccl.h ncclDataType_t): planes travel as 4-byte words
+
+struct Halo {
+  bool up = false;
+  int rank = 0, nranks = 1, npx = 1, npy = 1, transport = NOAHMP_HALO_TCP;
+  int nb[4] = {-1, -1, -1, -1};          // left, right, down, up
+  int sock[4] = {-1, -1, -1, -1};
+  Rccl rccl;
+  NcclComm comm = nullptr;
+  // staging
+  uint32_t* d_send = nullptr; uint32_t* d_recv = nullptr; size_t d_words = 0;
+  uint32_t* h_send = nullptr; uint32_t* h_recv = nullptr; size_t h_words = 0; bool h_pinned = false;
+  void** d_planes = nullptr; int d_planes_cap = 0;
+} H;
+
+int fail(const std::string& m, int rc = -109) { g.last_error = "noahmp_hip_halo: " + m; return rc; }
+
+// ---- sockets
+bool send_all(int fd, const void* p, size_t n) {
+  const char* c = (const char*)p;
+  while (n) { ssize_t k = ::send(fd, c, n, MSG_NOSIGNAL); if (k <= 0) { if (errno == EINTR) continue; return false; } c += k; n -= k; }
+  return true;
+}
+bool recv_all(int fd, void* p, size_t n) {
+  char* c = (char*)p;
+  while (n) { ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; } c += k; n -= k; }
+  return true;
+}
+int listen_on(int port, int* port_out) {
+  int fd = socket(AF_INET, SOCK_STREAM, 0);
+  if (fd < 0) return -1;
+  int one = 1;
+  setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
+  sockaddr_in a; memset(&a, 0, sizeof a);
+  a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_ANY); a.sin_port = htons((uint16_t)port);
+  if (bind(fd, (sockaddr*)&a, sizeof a) || listen(fd, 64)) { close(fd); return -1; }
+  socklen_t l = sizeof a;
+  getsockname(fd, (sockaddr*)&a, &l);
+  if (port_out) *port_out = ntohs(a.sin_port);
+  return fd;
+}
+int connect_to(uint32_t ip_be, int port, double timeout_s) {
+  const double t0 = (double)time(nullptr);
+  for (;;) {
+    int fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) return -1;
+    sockaddr_in a; memset(&a, 0, sizeof a);
+    a.sin_family = AF_INET; a.sin_addr.s_addr = ip_be; a.sin_port = htons((uint16_t)port);
+    if (connect(fd, (sockaddr*)&a, sizeof a) == 0) { int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one); return fd; }
+    close(fd);
+    if ((double)time(nullptr) - t0 > timeout_s) return -1;
+    usleep(50000);                         // the master may not be listening yet
+  }
+}
+uint32_t resolve(const char* host) {
+  in_addr a;
+  if (inet_aton(host, &a)) return a.s_addr;
+  hostent* he = gethostbyname(host);
+  if (he && he->h_addrtype == AF_INET) return *(uint32_t*)he->h_addr_list[0];
+  return htonl(INADDR_LOOPBACK);
+}
+
+// mpp_land_get_nprocsxy (mpp:124-141): most-square factorisation, first best wins
+void nprocs_xy(int n, int& nx, int& ny) {
+  int best = n; nx = n; ny = 1;
+  for (int j = 1; j <= n; j++) if (n % j == 0) { const int i = n / j; const int d = i > j ? i - j : j - i; if (d < best) { best = d; nx = i; ny = j; } }
+}
+
+struct Peer { uint32_t ip; int port; };
+
+// ---- edge packing.  An edge = `count` words of a plane starting at `first`, `stride` apart; n planes share a message.
+struct EdgeDesc { long first, stride; int count; long buf_off; };     // buf_off: word offset of plane 0's copy in the staging buffer
+struct PackArgs { void* const* planes; int n; EdgeDesc e[2]; int nedge; };
+
+__global__ void __launch_bounds__(256) halo_pack_kernel(const PackArgs k, uint32_t* buf, int unpack) {
+  const int per = k.e[0].count;                     // both edges of a phase have the same length
+  const long total = (long)k.nedge * k.n * per;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int q = (int)(t % per), p = (int)((t / per) % k.n), ed = (int)(t / ((long)per * k.n));
+  const EdgeDesc& e = k.e[ed];
+  uint32_t* plane = (uint32_t*)k.planes[p];
+  uint32_t* slot = buf + e.buf_off + (long)p * per + q;
+  if (unpack) plane[e.first + (long)q * e.stride] = *slot;
+  else *slot = plane[e.first + (long)q * e.stride];
+}
+
+void host_pack(const PackArgs& k, uint32_t* buf, int unpack, void* const* planes) {
+  for (int ed = 0; ed < k.nedge; ed++)
+    for (int p = 0; p < k.n; p++) {
+      uint32_t* plane = (uint32_t*)planes[p];
+      uint32_t* slot = buf + k.e[ed].buf_off + (long)p * k.e[ed].count;
+      for (int q = 0; q < k.e[ed].count; q++) {
+        if (unpack) plane[k.e[ed].first + (long)q * k.e[ed].stride] = slot[q];
+        else slot[q] = plane[k.e[ed].first + (long)q * k.e[ed].stride];
+      }
+    }
+}
+
+int ensure_staging(size_t words, bool device) {
+  if (H.h_words < words) {
+    if (H.h_send) { if (H.h_pinned) { hipHostFree(H.h_send); hipHostFree(H.h_recv); } else { free(H.h_send); free(H.h_recv); } }
+    H.h_send = H.h_recv = nullptr; H.h_words = 0;
+    if (device) {
+      HIPCHK(hipHostMalloc((void**)&H.h_send, words * 4, hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void**)&H.h_recv, words * 4, hipHostMallocDefault));
+      H.h_pinned = true;
+    } else {
+      H.h_send = (uint32_t*)malloc(words * 4); H.h_recv = (uint32_t*)malloc(words * 4); H.h_pinned = false;
+      if (!H.h_send || !H.h_recv) return fail("out of memory");
+    }
+    H.h_words = words;
+  }
+  if (device && H.d_words < words) {
+    if (H.d_send) { hipFree(H.d_send); hipFree(H.d_recv); }
+    H.d_send = H.d_recv = nullptr; H.d_words = 0;
+    HIPCHK(hipMalloc((void**)&H.d_send, words * 4));
+    HIPCHK(hipMalloc((void**)&H.d_recv, words * 4));
+    H.d_words = words;
+  }
+  return 0;
+}
+
+// one phase: exchange edge `a` with neighbour slot na and edge `b` with slot nb_ (either may be absent)
+int phase(int n, void* const* planes, void* const* d_planes, bool device, hipStream_t s, int slot_a, const EdgeDesc& send_a,
+          const EdgeDesc& recv_a, int slot_b, const EdgeDesc& send_b, const EdgeDesc& recv_b) {
+  const int per = send_a.count;
+  if (per <= 0) return 0;
+  const size_t words = (size_t)2 * n * per;
+  int rc = ensure_staging(words, device);
+  if (rc) return rc;
+  const int slots[2] = {slot_a, slot_b};
+  PackArgs pk; memset(&pk, 0, sizeof pk);
+  PackArgs up; memset(&up, 0, sizeof up);
+  pk.planes = up.planes = device ? d_planes : planes; pk.n = up.n = n;
+  const EdgeDesc snd[2] = {send_a, send_b}, rcv[2] = {recv_a, recv_b};
+  long off[2] = {0, (long)n * per};
+  for (int i = 0; i < 2; i++) {
+    if (H.nb[slots[i]] < 0) continue;
+    pk.e[pk.nedge] = snd[i]; pk.e[pk.nedge].buf_off = off[i]; pk.nedge++;
+    up.e[up.nedge] = rcv[i]; up.e[up.nedge].buf_off = off[i]; up.nedge++;
+  }
+  if (!pk.nedge) return 0;
+  const unsigned nb = (unsigned)(((long)pk.nedge * n * per + 255) / 256);
+  if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, s, pk, H.d_send, 0);
+  else host_pack(pk, H.h_send, 0, planes);
+  if (H.transport == NOAHMP_HALO_RCCL) {
+    if (!device) return fail("the RCCL transport exchanges device-resident planes");
+    int e = H.rccl.GroupStart();
+    for (int i = 0; i < 2 && !e; i++) {
+      const int peer = H.nb[slots[i]];
+      if (peer < 0) continue;
+      e = H.rccl.Send(H.d_send + off[i], (size_t)n * per, kNcclInt32, peer, H.comm, s);
+      if (!e) e = H.rccl.Recv(H.d_recv + off[i], (size_t)n * per, kNcclInt32, peer, H.comm, s);
+    }
+    const int e2 = H.rccl.GroupEnd();
+    if (e || e2) return fail(std::string("RCCL send/recv: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e ? e : e2) : "error"));
+  } else {
+    if (device) {
+      HIPCHK(hipMemcpyAsync(H.h_send, H.d_send, words * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    for (int i = 0; i < 2; i++) {                    // lower rank sends first: a total order, no deadlock with blocking sockets
+      const int peer = H.nb[slots[i]];
+      if (peer < 0) continue;
+      const int fd = H.sock[slots[i]];
+      const size_t bytes = (size_t)n * per * 4;
+      bool ok;
+      if (H.rank < peer) ok = send_all(fd, H.h_send + off[i], bytes) && recv_all(fd, H.h_recv + off[i], bytes);
+      else ok = recv_all(fd, H.h_recv + off[i], bytes) && send_all(fd, H.h_send + off[i], bytes);
+      if (!ok) return fail("socket transfer with rank " + std::to_string(peer) + " failed");
+    }
+    if (device) HIPCHK(hipMemcpyAsync(H.d_recv, H.h_recv, words * 4, hipMemcpyHostToDevice, s));
+  }
+  if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, s, up, H.d_recv, 1);
+  else host_pack(up, H.h_recv, 1, planes);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int master_port, int transport) {
+  if (H.up) noahmp_hip_halo_finalize();
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
+  if (transport != NOAHMP_HALO_TCP && transport != NOAHMP_HALO_RCCL) return fail("unknown transport");
+  H.rank = rank; H.nranks = nranks; H.transport = transport;
+  nprocs_xy(nranks, H.npx, H.npy);
+  const int ipx = rank % H.npx, ipy = rank / H.npx;                               // rank = iprocy*nprocx + iprocx (mpp:93-107)
+  H.nb[0] = ipx > 0 ? rank - 1 : -1; H.nb[1] = ipx < H.npx - 1 ? rank + 1 : -1;
+  H.nb[2] = ipy > 0 ? rank - H.npx : -1; H.nb[3] = ipy < H.npy - 1 ? rank + H.npx : -1;
+  H.up = true;
+  if (nranks == 1) return 0;
+  // ---- rendezvous: every rank opens a listener; rank 0 collects (ip, port) of all and hands the table out
+  int my_port = 0;
+  const int lfd = listen_on(0, &my_port);
+  if (lfd < 0) return fail("cannot open a listening socket");
+  std::vector<Peer> table(nranks);
+  NcclUniqueId uid; memset(&uid, 0, sizeof uid);
+  if (transport == NOAHMP_HALO_RCCL) {
+    H.rccl.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!H.rccl.handle) H.rccl.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!H.rccl.handle) { close(lfd); return fail("librccl.so not found (dlopen)"); }
+#define NMP_SYM(field, name) *(void**)&H.rccl.field = dlsym(H.rccl.handle, name); if (!H.rccl.field) { close(lfd); return fail(std::string("librccl: no symbol ") + name); }
+    NMP_SYM(GetUniqueId, "ncclGetUniqueId") NMP_SYM(CommInitRank, "ncclCommInitRank") NMP_SYM(CommDestroy, "ncclCommDestroy")
+    NMP_SYM(GroupStart, "ncclGroupStart") NMP_SYM(GroupEnd, "ncclGroupEnd") NMP_SYM(Send, "ncclSend") NMP_SYM(Recv, "ncclRecv")
+#undef NMP_SYM
+    *(void**)&H.rccl.GetErrorString = dlsym(H.rccl.handle, "ncclGetErrorString");
+    if (rank == 0 && H.rccl.GetUniqueId(&uid)) { close(lfd); return fail("ncclGetUniqueId"); }
+  }
+  if (rank == 0) {
+    const int mfd = listen_on(master_port, nullptr);
+    if (mfd < 0) { close(lfd); return fail("rank 0 cannot listen on the master port " + std::to_string(master_port)); }
+    table[0] = Peer{htonl(INADDR_LOOPBACK), my_port};
+    std::vector<int> fds(nranks, -1);
+    for (int i = 1; i < nranks; i++) {
+      sockaddr_in a; socklen_t l = sizeof a;
+      const int fd = accept(mfd, (sockaddr*)&a, &l);
+      int hello[2];
+      if (fd < 0 || !recv_all(fd, hello, sizeof hello) || hello[0] < 1 || hello[0] >= nranks) { close(mfd); close(lfd); return fail("rendezvous: bad hello"); }
+      fds[hello[0]] = fd;
+      table[hello[0]] = Peer{a.sin_addr.s_addr, hello[1]};
+    }
+    // rank 0 as the others see it: the master address they connected to
+    table[0].ip = resolve(master_addr && *master_addr ? master_addr : "127.0.0.1");
+    for (int i = 1; i < nranks; i++) {
+      const bool ok = send_all(fds[i], table.data(), sizeof(Peer) * nranks) && send_all(fds[i], &uid, sizeof uid);
+      close(fds[i]);
+      if (!ok) { close(mfd); close(lfd); return fail("rendezvous: table send"); }
+    }
+    close(mfd);
+  } else {
+    const int fd = connect_to(resolve(master_addr && *master_addr ? master_addr : "127.0.0.1"), master_port, 120.0);
+    if (fd < 0) { close(lfd); return fail("cannot reach rank 0 at " + std::string(master_addr ? master_addr : "127.0.0.1") + ":" + std::to_string(master_port)); }
+    int hello[2] = {rank, my_port};
+    const bool ok = send_all(fd, hello, sizeof hello) && recv_all(fd, table.data(), sizeof(Peer) * nranks) && recv_all(fd, &uid, sizeof uid);
+    close(fd);
+    if (!ok) { close(lfd); return fail("rendezvous: table receive"); }
+  }
+  // ---- neighbour links (TCP transport; also a liveness check for RCCL): connect to lower-ranked neighbours, accept the higher ones
+  int expect = 0;
+  for (int d = 0; d < 4; d++) if (H.nb[d] > rank) expect++;
+  for (int d = 0; d < 4; d++) {
+    if (H.nb[d] < 0 || H.nb[d] > rank) continue;
+    const int fd = connect_to(table[H.nb[d]].ip, table[H.nb[d]].port, 120.0);
+    if (fd < 0 || !send_all(fd, &rank, sizeof rank)) { close(lfd); return fail("cannot connect to neighbour " + std::to_string(H.nb[d])); }
+    H.sock[d] = fd;
+  }
+  for (int i = 0; i < expect; i++) {
+    const int fd = accept(lfd, nullptr, nullptr);
+    int who = -1;
+    if (fd < 0 || !recv_all(fd, &who, sizeof who)) { close(lfd); return fail("neighbour accept"); }
+    int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+    bool placed = false;
+    for (int d = 0; d < 4; d++) if (H.nb[d] == who && H.sock[d] < 0) { H.sock[d] = fd; placed = true; break; }
+    if (!placed) { close(fd); close(lfd); return fail("unexpected neighbour " + std::to_string(who)); }
+  }
+  close(lfd);
+  if (transport == NOAHMP_HALO_RCCL) {
+    int rc = nmp_host::ensure_init();
+    if (rc) return rc;
+    const int e = H.rccl.CommInitRank(&H.comm, nranks, uid, rank);
+    if (e) return fail(std::string("ncclCommInitRank: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e) : "error"));
+  }
+  return 0;
+}
+
+int noahmp_hip_exchange_halo(int n, void* const* planes, const int32_t* index8, int mem, void* stream) {
+  if (!H.up) return fail("noahmp_hip_halo_init has not been called");
+  if (n <= 0 || H.nranks == 1) return 0;
+  if (n > 64) return fail("at most 64 planes per call");
+  const int ims = index8[0], ime = index8[1], jms = index8[2], jme = index8[3], its = index8[4], ite = index8[5], jts = index8[6], jte = index8[7];
+  const long ni = ime - ims + 1;
+  const int i0 = its - ims, i1 = ite - ims, j0 = jts - jms, j1 = jte - jms;
+  // a side that has a neighbour must have its ring cell inside the memory block
+  if ((H.nb[0] >= 0 && i0 < 1) || (H.nb[1] >= 0 && ite + 1 > ime) || (H.nb[2] >= 0 && j0 < 1) || (H.nb[3] >= 0 && jte + 1 > jme))
+    return fail("the memory block (ims:ime, jms:jme) does not hold the 1-cell ring towards every neighbour", -103);
+  const bool device = mem == NOAHMP_MEM_DEVICE;
+  hipStream_t s = nullptr;
+  void** d_planes = nullptr;
+  if (device) {
+    int rc = nmp_host::ensure_init();
+    if (rc) return rc;
+    s = stream ? (hipStream_t)stream : g.own_stream;
+    if (H.d_planes_cap < n) { if (H.d_planes) hipFree(H.d_planes); HIPCHK(hipMalloc((void**)&H.d_planes, 64 * sizeof(void*))); H.d_planes_cap = 64; }
+    HIPCHK(hipMemcpyAsync(H.d_planes, planes, n * sizeof(void*), hipMemcpyHostToDevice, s));
+    d_planes = H.d_planes;
+  }
+  const int nrow = j1 - j0 + 1;
+  // phase 1 (mpp_land_comlr_real): columns its / ite of the tile rows -> the neighbour's ring column
+  EdgeDesc sl{(long)j0 * ni + i0, ni, nrow, 0}, rl{(long)j0 * ni + i0 - 1, ni, nrow, 0};
+  EdgeDesc sr{(long)j0 * ni + i1, ni, nrow, 0}, rr{(long)j0 * ni + i1 + 1, ni, nrow, 0};
+  int rc = phase(n, planes, d_planes, device, s, 0, sl, rl, 1, sr, rr);
+  if (rc) return rc;
+  // phase 2 (mpp_land_comub_real, flag 99): whole memory rows jts / jte, including the columns just received
+  EdgeDesc sd{(long)j0 * ni, 1, (int)ni, 0}, rd{(long)(j0 - 1) * ni, 1, (int)ni, 0};
+  EdgeDesc su{(long)j1 * ni, 1, (int)ni, 0}, ru{(long)(j1 + 1) * ni, 1, (int)ni, 0};
+  rc = phase(n, planes, d_planes, device, s, 2, sd, rd, 3, su, ru);
+  if (rc) return rc;
+  if (device) HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int noahmp_hip_halo_finalize(void) {
+  for (int d = 0; d < 4; d++) { if (H.sock[d] >= 0) close(H.sock[d]); H.sock[d] = -1; }
+  if (H.comm && H.rccl.CommDestroy) H.rccl.CommDestroy(H.comm);
+  H.comm = nullptr;
+  if (H.d_send) { hipFree(H.d_send); hipFree(H.d_recv); }
+  if (H.d_planes) hipFree(H.d_planes);
+  if (H.h_send) { if (H.h_pinned) { hipHostFree(H.h_send); hipHostFree(H.h_recv); } else { free(H.h_send); free(H.h_recv); } }
+  H = Halo();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,16 +1,24 @@
-// Run-time specialisation of the column kernel (opt-in: set_option("jit_option_kernels", 1)).
+// Run-time specialisation of the column kernel (default on; set_option("jit_option_kernels", 0) switches it off).
 //
-// The kernels of noahmp_engine_d*_r*.hip are the physics compiled with the OPT_* integers as constants -- 22 % faster than the
-// generic kernel because the code of every other alternative, and the registers it costs, are gone.  They exist ahead of time
-// for five option sets; for any other set this file compiles the same headers once more with hiprtc at the first call that
-// brings it (about 20 s, then cached for the life of the process).  Same source, same flags (-O3 -ffp-contract=off), hence the
-// same arithmetic; tests compare a run-time compiled kernel with the generic one bit for bit.  Any failure on the way leaves
-// the call with the generic kernel.
+// The kernels of noahmp_engine_d*_r*.hip are the physics compiled with the OPT_* integers (noahmp_options, lsm:9352-9388; the
+// twelve arguments of drv:15-17) as constants -- 22 % faster than the generic kernel because the code of every other alternative,
+// and the registers it costs, are gone.  They exist ahead of time for five option sets; for any other set this file compiles the
+// same headers once more with hiprtc at the first call that brings it (3-10 s) and keeps the code object on disk, keyed by the
+// twelve options, a hash of every source file and build macro that goes into the kernel, the hiprtc version and the GPU
+// architecture -- so only the first process that ever meets an option set pays for the compilation.  Cache directory:
+// $NOAHMP_HIP_CACHE_DIR, else jit_cache/ next to this library if it is writable, else ~/.cache/noahmp_hip.  Same source, same
+// flags (-O3 -ffp-contract=off), same build macros, hence the same arithmetic; tests compare a run-time compiled kernel with the
+// generic one bit for bit.  Any failure on the way leaves the call with the generic kernel and says so once on stderr.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <dirent.h>
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -25,6 +33,7 @@ namespace {
 
 struct JitKernels { hipModule_t mod = nullptr; hipFunction_t fn[2] = {nullptr, nullptr}; bool failed = false; };
 std::map<std::string, JitKernels> cache;
+struct JitStats { int compiled = 0, disk_hits = 0, fallbacks = 0; } stats;
 
 std::string source_dir() {                      // the headers live next to this library (noahmp_amd/csrc)
   Dl_info info;
@@ -36,10 +45,142 @@ std::string source_dir() {                      // the headers live next to this
 
 const char* kNames[12] = {"DVEG", "CRS", "BTR", "RUN", "SFC", "FRZ", "INF", "RAD", "ALB", "SNF", "TBOT", "STC"};
 
+#define NMP_STR2(x) #x
+#define NMP_STR(x) NMP_STR2(x)
+// the build macros that change the kernel's arithmetic or resources: the run-time compiled kernels get this library's values
+#ifndef NMP_EXACT_LIBM
+#define NMP_EXACT_LIBM 1
+#endif
+#ifndef NMP_WAVES_PER_EU
+#define NMP_WAVES_PER_EU 2
+#endif
+#ifndef NMP_LIBM_LDS
+#define NMP_LIBM_LDS 1
+#endif
+const char* kBuildMacros =
+    "#define NMP_EXACT_LIBM " NMP_STR(NMP_EXACT_LIBM) "\n"
+    "#define NMP_WAVES_PER_EU " NMP_STR(NMP_WAVES_PER_EU) "\n"
+    "#define NMP_LIBM_LDS " NMP_STR(NMP_LIBM_LDS) "\n";
+const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+
+uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* c = (const unsigned char*)p;
+  for (size_t i = 0; i < n; i++) { h ^= c[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+bool read_file(const std::string& path, std::vector<char>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  const long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(n > 0 ? n : 0);
+  const bool ok = n > 0 && fread(out.data(), 1, n, f) == (size_t)n;
+  fclose(f);
+  return ok;
+}
+
+// hash of everything the kernel is compiled from: every header next to the library (sorted by name), the C-ABI header, the
+// build macros, the compiler flags and the hiprtc version.  0 = the sources are not there (no run-time compilation possible).
+uint64_t source_hash() {
+  static uint64_t h = 0;
+  static bool done = false;
+  if (done) return h;
+  done = true;
+  const std::string dir = source_dir();
+  std::vector<std::string> files;
+  if (DIR* d = opendir(dir.c_str())) {
+    while (dirent* e = readdir(d)) {
+      const std::string n = e->d_name;
+      if ((n.size() > 4 && n.substr(n.size() - 4) == ".hpp") || (n.size() > 4 && n.substr(n.size() - 4) == ".inc")) files.push_back(dir + "/" + n);
+    }
+    closedir(d);
+  }
+  std::sort(files.begin(), files.end());
+  files.push_back(dir + "/../../include/noahmp_hip.h");
+  uint64_t acc = fnv1a(kBuildMacros, strlen(kBuildMacros));
+  for (const char* f : kCompileFlags) acc = fnv1a(f, strlen(f), acc);
+  int major = 0, minor = 0;
+  hiprtcVersion(&major, &minor);
+  acc = fnv1a(&major, sizeof major, acc);
+  acc = fnv1a(&minor, sizeof minor, acc);
+  bool kernel_seen = false;
+  std::vector<char> buf;
+  for (const std::string& f : files) {
+    if (!read_file(f, buf)) { if (f.find("noahmp_hip.h") != std::string::npos) return h = 0; continue; }
+    if (f.find("nmp_kernel.hpp") != std::string::npos) kernel_seen = true;
+    acc = fnv1a(buf.data(), buf.size(), acc);
+  }
+  return h = kernel_seen ? (acc ? acc : 1) : 0;
+}
+
+bool writable_dir(const std::string& d) {
+  mkdir(d.c_str(), 0755);
+  return access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+std::string cache_dir() {
+  static std::string dir;
+  static bool done = false;
+  if (done) return dir;
+  done = true;
+  if (const char* e = getenv("NOAHMP_HIP_CACHE_DIR")) { if (*e && writable_dir(e)) return dir = e; }
+  const std::string local = source_dir() + "/jit_cache";
+  if (writable_dir(local)) return dir = local;
+  if (const char* home = getenv("HOME")) {
+    const std::string c = std::string(home) + "/.cache";
+    mkdir(c.c_str(), 0755);
+    if (writable_dir(c + "/noahmp_hip")) return dir = c + "/noahmp_hip";
+  }
+  return dir = "";
+}
+
+std::string cache_file(const int* o) {
+  const std::string d = cache_dir();
+  const uint64_t h = source_hash();
+  if (d.empty() || !h) return "";
+  char name[160];
+  snprintf(name, sizeof name, "/nmp_gfx950_o%d_%d_%d_%d_%d_%d_%d_%d_%d_%d_%d_%d_%016llx.hsaco", o[0], o[1], o[2], o[3], o[4], o[5], o[6],
+           o[7], o[8], o[9], o[10], o[11], (unsigned long long)h);
+  return d + name;
+}
+
+void store_code(const std::string& path, const std::vector<char>& code) {
+  if (path.empty()) return;
+  char tmp[64];
+  snprintf(tmp, sizeof tmp, ".tmp%d", (int)getpid());
+  const std::string t = path + tmp;
+  FILE* f = fopen(t.c_str(), "wb");
+  if (!f) return;
+  const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+  fclose(f);
+  if (ok) rename(t.c_str(), path.c_str());        // atomic: concurrent ranks may compile the same set
+  else unlink(t.c_str());
+}
+
+bool load_module(const std::vector<char>& code, JitKernels& out, std::string& log) {
+  if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) { log = "hipModuleLoadData"; (void)hipGetLastError(); return false; }
+  if (hipModuleGetFunction(&out.fn[0], out.mod, "nmp_jit_m0") != hipSuccess ||
+      hipModuleGetFunction(&out.fn[1], out.mod, "nmp_jit_m1") != hipSuccess) { log = "hipModuleGetFunction"; (void)hipGetLastError(); return false; }
+  return true;
+}
+
 bool compile(const int* o, JitKernels& out, std::string& log) {
+  const std::string cpath = cache_file(o);
+  std::vector<char> code;
+  if (!cpath.empty() && read_file(cpath, code)) {            // another process (or an earlier run) compiled this set already
+    stats.disk_hits++;
+    if (g.jit_compile_only) { log = "cached " + std::to_string(code.size()) + " bytes"; return true; }
+    if (load_module(code, out, log)) return true;
+    code.clear();                                            // unreadable / stale object: compile again
+    out = JitKernels();
+  }
+  if (!source_hash()) { log = "kernel sources not found next to the library (" + source_dir() + ")"; return false; }
   std::string src =
       "using __hip_internal::int8_t; using __hip_internal::uint8_t; using __hip_internal::int16_t; using __hip_internal::uint16_t;\n"
       "using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;\n";
+  src += kBuildMacros;
   for (int i = 0; i < 12; i++) src += std::string("#define NMP_FIXED_") + kNames[i] + " " + std::to_string(o[i]) + "\n";
   src +=
       "#include \"nmp_kernel.hpp\"\n"
@@ -51,7 +192,7 @@ bool compile(const int* o, JitKernels& out, std::string& log) {
   if (hiprtcCreateProgram(&prog, src.c_str(), "nmp_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram"; return false; }
   const std::string dir = source_dir();
   const std::string i1 = "-I" + dir, i2 = "-I" + dir + "/../../include";
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", i1.c_str(), i2.c_str()};
+  const char* opts[] = {kCompileFlags[0], kCompileFlags[1], kCompileFlags[2], kCompileFlags[3], i1.c_str(), i2.c_str()};
   const hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
@@ -64,14 +205,13 @@ bool compile(const int* o, JitKernels& out, std::string& log) {
   }
   size_t n = 0;
   hiprtcGetCodeSize(prog, &n);
-  std::vector<char> code(n);
+  code.resize(n);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  stats.compiled++;
+  store_code(cpath, code);
   if (g.jit_compile_only) { log = "compiled " + std::to_string(n) + " bytes"; return true; }
-  if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) { log = "hipModuleLoadData"; (void)hipGetLastError(); return false; }
-  if (hipModuleGetFunction(&out.fn[0], out.mod, "nmp_jit_m0") != hipSuccess ||
-      hipModuleGetFunction(&out.fn[1], out.mod, "nmp_jit_m1") != hipSuccess) { log = "hipModuleGetFunction"; (void)hipGetLastError(); return false; }
-  return true;
+  return load_module(code, out, log);
 }
 
 }  // namespace
@@ -86,7 +226,11 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
   if (it == cache.end()) {
     JitKernels jk;
     std::string log;
-    if (!compile(o, jk, log)) { jk.failed = true; g.last_error = "option-specialised kernel not available (" + log + "): generic kernel used"; }
+    if (!compile(o, jk, log)) {
+      jk.failed = true;
+      g.last_error = "option-specialised kernel not available (" + log + "): generic kernel used";
+      if (!stats.fallbacks++) fprintf(stderr, "noahmp_hip: %s\n", g.last_error.c_str());      // say it once, then only in last_error
+    }
     else if (g.jit_compile_only) { jk.failed = true; g.last_error = log; }
     it = cache.emplace(key, jk).first;
   }
@@ -103,6 +247,8 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
   return true;
 }
 
+std::string cache_dir_public() { return cache_dir(); }
+
 bool jit_compile_probe(const int* o, std::string& log) {
   const int keep = g.jit_compile_only;
   g.jit_compile_only = 1;
@@ -111,6 +257,9 @@ bool jit_compile_probe(const int* o, std::string& log) {
   g.jit_compile_only = keep;
   return ok;
 }
+
+// out[0] = option sets compiled by this process, out[1] = loaded from the on-disk cache, out[2] = fell back to the generic kernel
+void jit_stats(int* out) { out[0] = stats.compiled; out[1] = stats.disk_hits; out[2] = stats.fallbacks; }
 
 void jit_finalize() {
   for (auto& kv : cache) if (kv.second.mod) hipModuleUnload(kv.second.mod);
@@ -128,4 +277,12 @@ extern "C" int noahmp_hip_jit_compile_check(const int32_t* options12, char* log,
   const bool ok = nmp_host::jit_compile_probe(o, msg);
   if (log && cap) { strncpy(log, msg.c_str(), cap - 1); log[cap - 1] = 0; }
   return ok ? 0 : 1;
+}
+
+// {compiled by this process, loaded from the on-disk cache, fell back to the generic kernel}; returns the cache directory ("" = none)
+extern "C" const char* noahmp_hip_jit_cache_info(int32_t* counts3) {
+  static std::string dir;
+  dir = nmp_host::cache_dir_public();
+  if (counts3) { int c[3]; nmp_host::jit_stats(c); for (int i = 0; i < 3; i++) counts3[i] = c[i]; }
+  return dir.c_str();
 }

@@ -310,5 +310,11 @@ class Engine:
         n = self.lib.noahmp_hip_sync_timing(out, 3)
         return [float(x) for x in out], n
 
+    def jit_cache_info(self):
+        """(cache directory, option sets compiled by this process, loaded from the disk cache, fallen back to the generic kernel)."""
+        c = (C.c_int32 * 3)()
+        d = self.lib.noahmp_hip_jit_cache_info(c)
+        return (d.decode() if d else ""), int(c[0]), int(c[1]), int(c[2])
+
     def finalize(self):
         self.lib.noahmp_hip_finalize()

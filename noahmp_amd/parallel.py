@@ -12,15 +12,28 @@ from .partition import partition, neighbours, tile_geometry
 
 
 class Comm:
-    def __init__(self, backend=None, device_index=None):
+    def __init__(self, backend=None, device_index=None, halo="torch", halo_port=None):
         """device_index: the GPU of this rank (default LOCAL_RANK); several ranks may share one GPU under gloo only
-        (a 1-GPU box exercising the N>1 code path)."""
+        (a 1-GPU box exercising the N>1 code path).  halo: who moves the LATERALFLOW ring -- "torch" (torch.distributed
+        send/recv: RCCL for device planes under the nccl backend), or the engine's own C-ABI exchange noahmp_hip_exchange_halo
+        ("rccl": ncclSend / ncclRecv issued by the library; "tcp": its socket transport), which is what a Fortran / MPI caller
+        binds."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.device_index = self.local_rank if device_index is None else int(device_index)
         self.dist = None
         self.backend = None
+        self.halo = halo
+        self.halo_lib = None
+        if halo != "torch" and self.world > 1:
+            from . import abi
+            self.halo_lib = abi.load_library()
+            port = halo_port or int(os.environ.get("NMP_HALO_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+            rc = self.halo_lib.noahmp_hip_halo_init(self.rank, self.world, os.environ.get("MASTER_ADDR", "127.0.0.1").encode(), port,
+                                                    abi.HALO_RCCL if halo == "rccl" else abi.HALO_TCP)
+            if rc:
+                raise RuntimeError("noahmp_hip_halo_init: rc=%d %s" % (rc, self.halo_lib.noahmp_hip_last_error().decode()))
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -55,6 +68,8 @@ class Comm:
         GPU-direct), CPU tensors over gloo.  <= 4 messages of a tile edge each per plane: latency-bound, so
         all planes of a phase go out as one batch.
         """
+        if self.halo_lib is not None:
+            return self._exchange_cabi(planes, geom)
         if not self.dist:
             return
         nb = self.my_neighbours()
@@ -66,6 +81,24 @@ class Comm:
         full = slice(None)
         self._exchange(planes, [(nb["down"], (j0, full), (j0 - 1, full)),
                                 (nb["up"], (j1, full), (j1 + 1, full))])
+
+    def _exchange_cabi(self, planes, geom):
+        """The same two-phase exchange done by the engine library (noahmp_hip_exchange_halo): device planes on torch's current
+        stream, host planes (numpy arrays / CPU tensors) over its socket transport."""
+        import ctypes as C
+        import numpy as np
+        from . import abi
+        n = len(planes)
+        ptrs = (C.c_void_p * n)(*[(p.ctypes.data if isinstance(p, np.ndarray) else p.data_ptr()) for p in planes])
+        idx = (C.c_int32 * 8)(*[geom[k] for k in ("ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")])
+        cuda = (not isinstance(planes[0], np.ndarray)) and planes[0].is_cuda
+        stream = None
+        if cuda:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        rc = self.halo_lib.noahmp_hip_exchange_halo(n, ptrs, idx, abi.MEM_DEVICE if cuda else abi.MEM_HOST, stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_exchange_halo: rc=%d %s" % (rc, self.halo_lib.noahmp_hip_last_error().decode()))
 
     def _exchange(self, planes, legs):
         dist = self.dist
@@ -122,5 +155,8 @@ class Comm:
         return out
 
     def close(self):
+        if self.halo_lib is not None:
+            self.halo_lib.noahmp_hip_halo_finalize()
+            self.halo_lib = None
         if self.dist:
             self.dist.destroy_process_group()

@@ -127,13 +127,31 @@ def test_store_layout_is_fortran_image():
     assert flat[((1 - 1) * 4 + (3 - 1)) * 5 + (2 - 1)] == 42.0
 
 
-def test_runtime_specialisation_compiles_without_gpu():
+def test_runtime_specialisation_compiles_without_gpu_and_fills_the_disk_cache(tmp_path):
     """noahmp_jit.hip: the column kernel compiled by hiprtc for an option set that has no ahead-of-time kernel (the compile step
-    needs no GPU; loading and launching are covered by the GPU tests)."""
-    import ctypes as C
-    lib = abi.load_library()
-    opts = (C.c_int32 * 12)(2, 2, 2, 3, 1, 2, 2, 1, 1, 3, 1, 2)
-    log = C.create_string_buffer(4096)
-    rc = lib.noahmp_hip_jit_compile_check(opts, log, 4096)
-    assert rc == 0, log.value.decode()[:2000]
-    assert log.value.decode().startswith("compiled ")
+    needs no GPU; loading and launching are covered by the GPU tests).  The code object lands in the on-disk cache, keyed by
+    the options and the source hash; a second process finds it there instead of compiling."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "from noahmp_amd import abi\n"
+        "lib = abi.load_library()\n"
+        "opts = (C.c_int32 * 12)(2, 2, 2, 3, 1, 2, 2, 1, 1, 3, 1, 2)\n"
+        "log = C.create_string_buffer(4096)\n"
+        "rc = lib.noahmp_hip_jit_compile_check(opts, log, 4096)\n"
+        "c = (C.c_int32 * 3)()\n"
+        "d = lib.noahmp_hip_jit_cache_info(c)\n"
+        "print('RESULT', rc, log.value.decode()[:200].replace('\\n', ' '), '|', d.decode(), list(c))\n")
+    env = dict(os.environ, NOAHMP_HIP_CACHE_DIR=str(tmp_path), PYTHONPATH=ROOT)
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert line, r.stdout + r.stderr
+        outs.append(line[0])
+    assert outs[0].startswith("RESULT 0 compiled ") and outs[0].endswith("[1, 0, 0]"), outs[0]
+    assert outs[1].startswith("RESULT 0 cached ") and outs[1].endswith("[0, 1, 0]"), outs[1]
+    files = os.listdir(str(tmp_path))
+    assert len(files) == 1 and files[0].startswith("nmp_gfx950_o2_2_2_3_1_2_2_1_1_3_1_2_") and files[0].endswith(".hsaco")
+    assert str(tmp_path) in outs[0]

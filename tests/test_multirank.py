@@ -263,16 +263,20 @@ def _run_bench(extra, tmp, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["config4", "config3"])
+@pytest.mark.parametrize("workload", ["config4", "config3", "config4-cabi"])
 def test_bench_two_ranks_equal_one_rank(workload, tmp_path):
     """`bench.py --gpus 2` starts its two ranks itself (here both on the one GPU, ring exchange staged through the host) and
     prints n_gpus: 2; the union of the ranks' tiles equals the single-rank run of the same global grid bit for bit -- the
     config-4 groundwater step included (parity target: the single domain)."""
+    extra = []
+    if workload == "config4-cabi":              # the ring moved by the engine's own C-ABI exchange (socket transport, device planes)
+        workload, extra = "config4", ["--halo", "tcp"]
     one, d1 = _run_bench(["--gpus", "1", "--workload", workload], str(tmp_path), "one")
-    two, d2 = _run_bench(["--gpus", "2", "--workload", workload], str(tmp_path), "two")
+    two, d2 = _run_bench(["--gpus", "2", "--workload", workload] + extra, str(tmp_path), "two")
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     if workload == "config4":
-        assert two["groundwater"]["calls"] == 5 and "RCCL" in two["config"]["parallelism"]
+        assert two["groundwater"]["calls"] == 5 and "ring exchange" in two["config"]["parallelism"]
+        assert ("noahmp_hip_exchange_halo" in two["config"]["parallelism"]) == bool(extra)
     whole = np.load(d1 + ".rank0.npz")
     seen = 0
     for r in range(2):
@@ -285,3 +289,51 @@ def test_bench_two_ranks_equal_one_rank(workload, tmp_path):
             assert np.array_equal(want, part[k], equal_nan=True), "%s rank %d" % (k, r)
         seen += (ite - its + 1) * (jte - jts + 1)
     assert seen == 96 * 130
+
+
+# ------------------------------------------------------------------------------------------------
+# The C-ABI halo exchange (noahmp_hip_halo_init / noahmp_hip_exchange_halo, socket transport) on host planes: no torch.distributed,
+# no gloo, no GPU -- what a Fortran / MPI caller binds.  Parity target: the ring cells equal the neighbours' tile cells of ONE
+# global field, corners included (mpp_land_comlr_real + comub_real flag 99, mpp:344-369, 603-642).
+def _cabi_worker(rank, world, port, gx, gy, q):
+    import ctypes as C
+    from noahmp_amd import abi
+    from noahmp_amd.partition import tile_geometry
+    lib = abi.load_library()
+    rc = lib.noahmp_hip_halo_init(rank, world, b"127.0.0.1", port, abi.HALO_TCP)
+    assert rc == 0, lib.noahmp_hip_last_error().decode()
+    geo = tile_geometry(gx, gy, world, rank, halo=1)
+    y, x = np.meshgrid(np.arange(gy), np.arange(gx), indexing="ij")
+    gf = (1000.0 * y + x).astype(np.float32)                 # global fields: the value names the cell
+    gi = (7 * y + 3 * x).astype(np.int32)
+    sl = (slice(geo["jms"] - 1, geo["jme"]), slice(geo["ims"] - 1, geo["ime"]))
+    f, i = gf[sl].copy(), gi[sl].copy()
+    ring = np.ones(f.shape, dtype=bool)
+    ring[geo["jts"] - geo["jms"]:geo["jte"] - geo["jms"] + 1, geo["its"] - geo["ims"]:geo["ite"] - geo["ims"] + 1] = False
+    f[ring] = np.nan
+    i[ring] = -1
+    idx = (C.c_int32 * 8)(*[geo[k] for k in ("ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")])
+    for _ in range(3):                                       # repeated calls reuse links and staging buffers
+        ptrs = (C.c_void_p * 2)(f.ctypes.data, i.ctypes.data)
+        rc = lib.noahmp_hip_exchange_halo(2, ptrs, idx, abi.MEM_HOST, None)
+        assert rc == 0, lib.noahmp_hip_last_error().decode()
+    ok = bool(np.array_equal(f, gf[sl]) and np.array_equal(i, gi[sl]))
+    lib.noahmp_hip_halo_finalize()
+    q.put((rank, ok, int(ring.sum())))
+
+
+@pytest.mark.parametrize("world", [2, 4, 6])
+def test_cabi_halo_exchange_on_host_planes(world):
+    gx, gy = 41, 29
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = _free_port()
+    procs = [ctx.Process(target=_cabi_worker, args=(r, world, p, gx, gy, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(n > 0 for _, _, n in res)

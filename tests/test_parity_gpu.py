@@ -618,14 +618,16 @@ def test_option_specialised_kernels_bit_identical(engine, tables, dveg, run):
 @pytest.mark.parametrize("kw", [dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_frz=2), dict(iopt_btr=2, iopt_crs=2, idveg=5)],
                          ids=["dveg2_run3_stc2_frz2", "btr2_crs2_dveg5"])
 def test_runtime_compiled_kernels_bit_identical(engine, tables, kw):
-    """Option sets without an ahead-of-time specialised kernel: with "jit_option_kernels" the engine compiles one at the first
-    call (hiprtc) -- it must return the bits of the generic kernel, mixed tile and class ranges alike."""
+    """Option sets without an ahead-of-time specialised kernel: by default ("jit_option_kernels" = 1) the engine compiles one at the
+    first call (hiprtc, or loads it from the on-disk cache) -- it must return the bits of the generic kernel, mixed tile and class
+    ranges alike."""
     import torch
     cfg = ModelConfig(**kw)
     s = synth.mixed_small(tables[1], ni=128, nj=12, glacier_frac=0.06, seed=59, cfg=cfg)
     synth.first_step_fixups(s)
     synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
     res = {}
+    assert engine.set_option("jit_option_kernels", -1) == 1          # the default (reading: an invalid value changes nothing)
     for jit in (0, 1):
         engine.set_option("jit_option_kernels", jit)
         try:
@@ -638,7 +640,9 @@ def test_runtime_compiled_kernels_bit_identical(engine, tables, kw):
             if jit:
                 msg = engine.lib.noahmp_hip_last_error().decode()
                 assert "generic kernel used" not in msg, msg          # the run-time compiled kernels really ran
+                d, compiled, hits, fallbacks = engine.jit_cache_info()
+                assert d and compiled + hits >= 1 and fallbacks == 0, (d, compiled, hits, fallbacks)
         finally:
-            engine.set_option("jit_option_kernels", 0)
+            engine.set_option("jit_option_kernels", 1)
     for which in (0, 1):
         _check(res[0][which], res[1][which], engine, steps=4, fields=_outs(res[0][which]))
