@@ -57,6 +57,13 @@ struct Engine {
   // resident host path: the device mirrors ARE the state between calls; only IN arrays are uploaded, INOUT / OUT arrays come back
   // on request (noahmp_hip_fetch) unless lazy_download is off
   int resident_state = 0, lazy_download = 0;
+  int static_inputs = 0;        // resident path: static IN arrays (XLATIN, IVGTYP, ... DZ8W) are uploaded only when the state is rebuilt
+  int deferred_status = 0;      // resident + lazy path: a call returns once its forcing is uploaded; its status comes with the next call / fetch
+  bool deferred_pending = false;
+  unsigned resident_calls = 0;
+  std::vector<void*> mirror_b;                           // second buffer of the IN arrays (deferred_status)
+  std::vector<size_t> mirror_b_bytes;
+  hipEvent_t ev_up = nullptr, ev_kdone = nullptr;
   bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
   std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call
   noahmp_step_args resident_args;                        // the argument block of that call (for fetch)

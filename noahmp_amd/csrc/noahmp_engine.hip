@@ -180,6 +180,14 @@ int noahmp_hip_set_option(const char* key, int value) {
       g.lazy_download = value;
     }
   }
+  else if (!strcmp(key, "static_inputs")) { prev = g.static_inputs; if (value == 0 || value == 1) g.static_inputs = value; }
+  else if (!strcmp(key, "deferred_status")) {
+    prev = g.deferred_status;
+    if (value == 0 || value == 1) {
+      if (g.deferred_pending || g.resident_dirty) noahmp_hip_fetch(nullptr);
+      g.deferred_status = value; g.resident_valid = false;
+    }
+  }
   else if (!strcmp(key, "exact_libm")) prev = NMP_EXACT_LIBM;   // read-only: how this library was built
   return prev;
 }
@@ -403,57 +411,21 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
 // arrays (forcing and static fields) and, with "lazy_download" = 1, copy nothing back: noahmp_hip_fetch() does that when the
 // caller needs the arrays (output / restart times, hdrv:440-441, 588).  The caller promises not to modify INOUT / OUT
 // arrays in between without switching the option off and on again.
-static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_status* st) {
-  KArgs k;
-  fill_kargs(k, a);
-  if (g.mirror_host.empty()) g.mirror_host.assign(kNumFields, nullptr);
-  bool valid = g.resident_valid;
-  for (int f = 0; f < kNumFields; f++) {       // pass 1: are these the arrays (and extents) of the resident state?
-    const FieldDesc& fd = kFields[f];
-    if (g.mirror_bytes[f] != field_elems(fd, a) * 4 || g.mirror_host[f] != *(void* const*)((const char*)a + fd.off)) valid = false;
-  }
-  if (!valid && g.resident_dirty) {            // other arrays than last time while results are still only on the device:
-    int rc = noahmp_hip_fetch(nullptr);        // bring the PREVIOUS call's host arrays up to date before any mirror is touched
-    if (rc) return rc;
-  }
-  for (int f = 0; f < kNumFields; f++) {       // pass 2: only now may the mirrors change size
-    const size_t bytes = field_elems(kFields[f], a) * 4;
-    if (g.mirror_bytes[f] != bytes) {
-      if (g.mirror[f]) HIPCHK(hipFree(g.mirror[f]));
-      g.mirror[f] = nullptr; g.mirror_bytes[f] = 0;
-      HIPCHK(hipMalloc(&g.mirror[f], bytes));
-      g.mirror_bytes[f] = bytes;
-    }
-  }
-  for (int f = 0; f < kNumFields; f++) {
-    const FieldDesc& fd = kFields[f];
-    const size_t bytes = field_elems(fd, a) * 4;
-    void* host = *(void* const*)((const char*)a + fd.off);
-    maybe_pin(host, bytes);
-    if (!valid || fd.io == 0) HIPCHK(hipMemcpyAsync(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
-    g.mirror_host[f] = host;
-    *(void**)((char*)&k.a + fd.off) = g.mirror[f];
-  }
-  g.out_mirror_valid = false;
-  *g.h_err = ~0ULL;
-  HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
-  HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
-  HIPCHK(hipEventRecord(g.ev0, s));
-  launch_any(k, s);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.ev1, s));
-  HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
-  if (!g.lazy_download)
-    for (int f = 0; f < kNumFields; f++) {
-      const FieldDesc& fd = kFields[f];
-      if (fd.io == 0) continue;
-      HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
-    }
-  HIPCHK(hipStreamSynchronize(s));
-  g.resident_valid = true;
-  g.resident_dirty = g.lazy_download != 0;
-  g.resident_args = *a;
+// IN arrays a driver sets once (hdrv:250-300: static fields and DZ8W = 2 ZLVL): with "static_inputs" they are uploaded only when the
+// resident state is (re)built.  What the HRLDAS loop rewrites between calls (hdrv:331-415) -- forcing, COSZEN, VEGFRA -- always travels.
+static bool is_static_in(const FieldDesc& fd) {
+  static const char* const names[] = {"xlatin", "ivgtyp", "isltyp", "vegmax", "tmn", "xland", "xice", "dz8w"};
+  for (const char* n : names) if (!strcmp(fd.name, n)) return true;
+  return false;
+}
+// atmospheric arrays of which the kernel reads level 1 only (drv:449-466; P8W3D is read at two levels): the resident path uploads that level
+static bool level1_only(const FieldDesc& fd) {
+  static const char* const names[] = {"t3d", "qv3d", "u_phy", "v_phy", "dz8w"};
+  for (const char* n : names) if (!strcmp(fd.name, n)) return true;
+  return false;
+}
+
+static void fill_status(const noahmp_step_args* a, int nti, noahmp_status* st, int* code_out) {
   float ms = 0.f;
   hipEventElapsedTime(&ms, g.ev0, g.ev1);
   int code = 0;
@@ -466,8 +438,112 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);
     const long t = (long)(*g.h_err >> 8) - 1;
-    if (st) { st->code = code; st->i = a->its + (int)(t % k.nti); st->j = a->jts + (int)(t / k.nti); }
+    if (st) { st->code = code; st->i = a->its + (int)(t % nti); st->j = a->jts + (int)(t / nti); }
   }
+  *code_out = code;
+}
+
+// "deferred_status": wait for the step the previous resident call left running and report it
+static int resident_collect(noahmp_status* st, int* code_out) {
+  *code_out = 0;
+  if (!g.deferred_pending) return 0;
+  HIPCHK(hipEventSynchronize(g.ev_kdone));
+  g.deferred_pending = false;
+  fill_status(&g.resident_args, g.resident_args.ite - g.resident_args.its + 1, st, code_out);
+  return 0;
+}
+
+static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_status* st) {
+  KArgs k;
+  fill_kargs(k, a);
+  if (g.mirror_host.empty()) g.mirror_host.assign(kNumFields, nullptr);
+  if (g.mirror_b.empty()) { g.mirror_b.assign(kNumFields, nullptr); g.mirror_b_bytes.assign(kNumFields, 0); }
+  const bool defer = g.deferred_status && g.lazy_download;
+  bool valid = g.resident_valid;
+  for (int f = 0; f < kNumFields; f++) {       // pass 1: are these the arrays (and extents) of the resident state?
+    const FieldDesc& fd = kFields[f];
+    if (g.mirror_bytes[f] != field_elems(fd, a) * 4 || g.mirror_host[f] != *(void* const*)((const char*)a + fd.off)) valid = false;
+  }
+  if (!valid && (g.resident_dirty || g.deferred_pending)) {   // other arrays than last time while results are still only on the device:
+    int rc = noahmp_hip_fetch(nullptr);        // bring the PREVIOUS call's host arrays up to date before any mirror is touched
+    if (rc) return rc;
+  }
+  for (int f = 0; f < kNumFields; f++) {       // pass 2: only now may the mirrors change size
+    const size_t bytes = field_elems(kFields[f], a) * 4;
+    if (g.mirror_bytes[f] != bytes) {
+      if (g.mirror[f]) HIPCHK(hipFree(g.mirror[f]));
+      g.mirror[f] = nullptr; g.mirror_bytes[f] = 0;
+      HIPCHK(hipMalloc(&g.mirror[f], bytes));
+      g.mirror_bytes[f] = bytes;
+    }
+    if (defer && kFields[f].io == 0 && g.mirror_b_bytes[f] != bytes) {      // second buffer of the IN arrays: step n+1 uploads while step n computes
+      if (g.mirror_b[f]) HIPCHK(hipFree(g.mirror_b[f]));
+      g.mirror_b[f] = nullptr; g.mirror_b_bytes[f] = 0;
+      HIPCHK(hipMalloc(&g.mirror_b[f], bytes));
+      g.mirror_b_bytes[f] = bytes;
+      valid = false;
+    }
+  }
+  if (defer && !g.s_up) { HIPCHK(hipStreamCreateWithFlags(&g.s_up, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&g.s_dn, hipStreamNonBlocking)); }
+  if (defer && !g.ev_up) { HIPCHK(hipEventCreate(&g.ev_up)); HIPCHK(hipEventCreate(&g.ev_kdone)); }
+  hipStream_t up = defer ? g.s_up : s;
+  const bool second = defer && (g.resident_calls & 1);
+  const size_t ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1, nka = a->kme - a->kms + 1;
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    const size_t bytes = field_elems(fd, a) * 4;
+    void* host = *(void* const*)((const char*)a + fd.off);
+    maybe_pin(host, bytes);
+    const bool stat = fd.io == 0 && is_static_in(fd);
+    // static IN arrays and the state live in `mirror`; the IN arrays that change per call alternate between the two buffers
+    void* target = (second && fd.io == 0 && !(g.static_inputs && stat)) ? g.mirror_b[f] : g.mirror[f];
+    if (!valid || (fd.io == 0 && !(g.static_inputs && stat))) {
+      if (valid && fd.lev == 1 && nka > 1 && level1_only(fd)) {            // only the level the kernel reads
+        const size_t off = (size_t)k.k1 * ni * 4;
+        HIPCHK(hipMemcpy2DAsync((char*)target + off, nka * ni * 4, (const char*)host + off, nka * ni * 4, ni * 4, nj, hipMemcpyHostToDevice, up));
+      } else {
+        HIPCHK(hipMemcpyAsync(target, host, bytes, hipMemcpyHostToDevice, up));
+      }
+    }
+    g.mirror_host[f] = host;
+    *(void**)((char*)&k.a + fd.off) = target;
+  }
+  g.out_mirror_valid = false;
+  int prev_code = 0;
+  if (defer) {
+    HIPCHK(hipEventRecord(g.ev_up, up));
+    int rc = resident_collect(st, &prev_code);      // the previous step ran under this call's upload: wait for it, report it
+    if (rc) return rc;
+    HIPCHK(hipStreamWaitEvent(s, g.ev_up, 0));
+  }
+  *g.h_err = ~0ULL;
+  HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
+  HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
+  HIPCHK(hipEventRecord(g.ev0, s));
+  launch_any(k, s);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(g.ev1, s));
+  HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
+  g.resident_calls++;
+  g.resident_args = *a;
+  g.resident_valid = true;
+  g.resident_dirty = g.lazy_download != 0;
+  if (defer) {                                   // return as soon as the caller may overwrite its forcing arrays; the kernel keeps running
+    HIPCHK(hipEventRecord(g.ev_kdone, s));
+    g.deferred_pending = true;
+    HIPCHK(hipEventSynchronize(g.ev_up));
+    return prev_code;
+  }
+  if (!g.lazy_download)
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      if (fd.io == 0) continue;
+      HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+    }
+  HIPCHK(hipStreamSynchronize(s));
+  int code = 0;
+  fill_status(a, k.nti, st, &code);
   return code;
 }
 
@@ -479,6 +555,9 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
   int rc = ensure_init();
   if (rc) return rc;
   if (!g.resident_valid) { if (g.resident_dirty) { g.last_error = "noahmp_hip_fetch: no resident state"; return -108; } return 0; }
+  int pending_code = 0;
+  rc = resident_collect(nullptr, &pending_code);         // "deferred_status": the last step may still be running
+  if (rc) return rc;
   const noahmp_step_args* r = &g.resident_args;
   if (a)
     for (int f = 0; f < kNumFields; f++)
@@ -486,7 +565,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
         g.last_error = "noahmp_hip_fetch: these are not the arrays of the resident state";
         return -108;
       }
-  if (!g.resident_dirty) return 0;
+  if (!g.resident_dirty) return pending_code;
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];
     if (fd.io == 0) continue;
@@ -494,7 +573,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
   }
   HIPCHK(hipStreamSynchronize(g.own_stream));
   g.resident_dirty = false;
-  return 0;
+  return pending_code;              // a fatal column of the step that was still running (0 = none)
 }
 
 int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
@@ -506,6 +585,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   if (g.async_pending) { g.last_error = "noahmp_hip_step: asynchronous steps are pending, call noahmp_hip_sync() first"; return -106; }
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
   if (mem == NOAHMP_MEM_HOST && g.resident_state) return step_host_resident(a, s, st);
+  if (mem == NOAHMP_MEM_HOST && (g.deferred_pending || g.resident_dirty)) { rc = noahmp_hip_fetch(nullptr); if (rc < 0) return rc; }
   if (mem == NOAHMP_MEM_HOST) g.resident_valid = false;
   // the row-chunk pipeline only pays with pinned arrays (pageable asynchronous copies are staged and serialise)
   if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && g.host_chunks > 1 &&
@@ -737,6 +817,9 @@ int noahmp_hip_debug_phase_ticks(unsigned long long* out, int n) {
 
 void noahmp_hip_finalize(void) {
   for (auto& p : g.mirror) { if (p) hipFree(p); p = nullptr; }
+  for (auto& p : g.mirror_b) { if (p) hipFree(p); p = nullptr; }
+  if (g.ev_up) hipEventDestroy(g.ev_up);
+  if (g.ev_kdone) hipEventDestroy(g.ev_kdone);
   for (auto& b : g.mirror_bytes) b = 0;
   g.resident_valid = false; g.resident_dirty = false; g.mirror_host.clear();
   g.sorted_land = -1; g.sorted_glacier = -1;

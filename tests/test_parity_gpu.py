@@ -547,6 +547,45 @@ def test_resident_host_path_lazy_download(engine, port, tables):
     _check(plain, other, engine, steps=nsteps + 1, fields=_outs(plain))
 
 
+def test_resident_host_path_static_inputs_and_deferred_status(engine, tables):
+    """"static_inputs" + "deferred_status" on top of resident_state + lazy_download: 12 steps give the bits of the ordinary host path;
+    a call reports the PREVIOUS step (tallies, fatal column), the last step's fatal comes out of fetch; a static array changed
+    behind the engine's back is (by contract) not seen until the state is rebuilt."""
+    from noahmp_amd.driver import NoahMPFatal
+    s = synth.mixed_small(tables[1], ni=128, nj=8, seed=67)
+    synth.first_step_fixups(s)
+    plain, res = s.copy(), s.copy()
+    nsteps = 12
+    tallies = []
+    for it in range(1, nsteps + 1):
+        synth.diurnal_forcing(plain, (it - 1) % 24, t_offset=s.t_offset)
+        st = engine.noahmplsm(plain, it, 2000, 180.0)
+        tallies.append((st.n_land, st.n_glacier, st.n_skipped))
+    try:
+        for k, v in (("resident_state", 1), ("lazy_download", 1), ("static_inputs", 1), ("deferred_status", 1)):
+            engine.set_option(k, v)
+        for it in range(1, nsteps + 1):
+            synth.diurnal_forcing(res, (it - 1) % 24, t_offset=s.t_offset)      # in place: same arrays every call
+            st = engine.noahmplsm(res, it, 2000, 180.0)
+            assert st.code == 0
+            assert (st.n_land, st.n_glacier, st.n_skipped) == ((0, 0, 0) if it == 1 else tallies[it - 2])      # the previous step's
+            res["coszin"][...] = -5.0                                           # the caller may overwrite its forcing right away
+        engine.fetch()
+        _check(plain, res, engine, steps=nsteps, fields=_outs(plain))
+        # a fatal column (soil type out of range) in the LAST step: the call itself returns 0, fetch reports it
+        bad = res.copy()
+        synth.diurnal_forcing(bad, 3, t_offset=s.t_offset)
+        engine.set_option("static_inputs", 0)                                   # ISLTYP is a static array: let the change through
+        bad["isltyp"][2, 5] = 99
+        st = engine.noahmplsm(bad, nsteps + 1, 2000, 180.0, check=False)
+        assert st.code == 0
+        rc = engine.lib.noahmp_hip_fetch(None)
+        assert rc == 1, rc                                                      # NOAHMP_ERR_SOILTYP_RANGE
+    finally:
+        for k in ("deferred_status", "static_inputs", "lazy_download", "resident_state"):
+            engine.set_option(k, 0)
+
+
 def test_resident_host_path_alternating_tiles_of_different_size(engine, tables):
     """Two tiles (nests) of different extents advanced alternately with "resident_state" + "lazy_download": a call with other
     arrays first brings the previous tile's host arrays up to date from the still intact mirrors, and only then re-sizes the

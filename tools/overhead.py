@@ -28,12 +28,12 @@ def host_path(label, **opts):
     synth.first_step_fixups(s); synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
     prev = {k: eng.set_option(k, v) for k, v in opts.items()}
     for it in range(3): eng.noahmplsm(s, it + 1, 2000, 180.0)
-    t = time.perf_counter(); n = 6
+    t = time.perf_counter(); n = 12
     for it in range(n): st = eng.noahmplsm(s, it + 4, 2000, 180.0)
     w = (time.perf_counter() - t) / n
     if opts.get("lazy_download"):
         t1 = time.perf_counter(); eng.fetch(); print("    fetch of INOUT+OUT arrays: %.1f ms" % ((time.perf_counter() - t1) * 1e3))
-    for k in ("lazy_download", "resident_state"):
+    for k in ("deferred_status", "static_inputs", "lazy_download", "resident_state"):
         if k in prev: eng.set_option(k, prev.pop(k))
     for k, v in prev.items(): eng.set_option(k, v)
     print("host-memory path 1024x1024 %-44s %.1f ms/step (kernel %.2f ms) -> %.3e col-steps/s PCIe-inclusive" % (label, w * 1e3, st.kernel_ms, s.ncol / w))
@@ -47,6 +47,8 @@ host_path("resident state, downloads every call, pageable:", resident_state=1)
 host_path("resident state, downloads every call, pinned:", resident_state=1, pin_host_arrays=1)
 host_path("resident state, lazy download, pageable:", resident_state=1, lazy_download=1)
 host_path("resident state, lazy download, pinned:", resident_state=1, lazy_download=1, pin_host_arrays=1)
+host_path("... + static inputs:", resident_state=1, lazy_download=1, pin_host_arrays=1, static_inputs=1)
+host_path("... + static inputs + deferred status:", resident_state=1, lazy_download=1, pin_host_arrays=1, static_inputs=1, deferred_status=1)
 sys.exit(0)
 # (old single measurement): H2D of all arrays + kernel + D2H, 1M columns
 s = synth.config2(tb, ni=1024, nj=1024)
