@@ -118,18 +118,27 @@ def self_launch(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
+GW_SHARED = ("smois", "sh2o", "smcwtdxy", "zwtxy", "deeprechxy", "rechxy")   # what the column step and WTABLE_mmf_noahmp both update
+GW_ONLY_OUT = ("qrf", "qspring", "qslat", "qrfs", "qsprings")
+
+
 class Run:
-    """One rank's share of a workload: setup() builds the device-resident state, step(it) enqueues one timestep,
-    collect() waits and returns the tallies."""
+    """One rank's share of a workload: the constructor builds the device-resident state, step(it) enqueues one timestep,
+    collect() waits and returns the tallies.
+
+    Sorted layout (default): the rank's tile lives in HBM sorted by (class, vegetation type, snow-layer count, TSK bin); forcing
+    arrives in tile order and is permuted per step.  With OPT_RUN = 5 (config 4) the groundwater planes additionally live in
+    a tile-order memory block that carries the 1-cell ring: around every WTABLE_mmf_noahmp call the six planes it shares with the
+    column step return to (i,j) order, the ZWTXY ring is exchanged, the stencil runs, and the planes go back to sorted order."""
 
     def __init__(self, args, workload, comm, eng, tb, dev):
         import torch
         from noahmp_amd import synth
         from noahmp_amd.partition import tile_geometry
-        from noahmp_amd.state import ModelConfig
+        from noahmp_amd.state import ColumnStore, DeviceColumnStore, ModelConfig, GW_ALIAS, GW_EXTRA
         self.torch, self.args, self.workload, self.comm, self.eng, self.dev = torch, args, workload, comm, eng, dev
         self.lateral = workload == "config4"
-        self.sorted = not self.lateral and not args.no_sort
+        self.sorted = not args.no_sort
         gx, gy = args.ni, args.nj
         if workload == "config2":
             cfg = ModelConfig(idveg=1)
@@ -144,10 +153,29 @@ class Run:
             s = synth.config2(tb, ni=gx, nj=gy, seed=2, cfg=cfg)
         else:       # this rank's memory block (tile + ring) cut from ONE global grid
             s = synth.config3_tile(tb, gx, gy, geom["ims"] - 1, geom["jms"] - 1, nx, ny, cfg=cfg, groundwater=self.lateral)
-        s.set_index(**{k: geom[k] for k in ("ids", "ide", "jds", "jde", "ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")})
+        idx_keys = ("ids", "ide", "jds", "jde", "ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")
+        s.set_index(**{k: geom[k] for k in idx_keys})
         synth.first_step_fixups(s)
+        self.i_off, self.j_off = geom["its"] - geom["ims"], geom["jts"] - geom["jms"]
+        nti, ntj = geom["ite"] - geom["its"] + 1, geom["jte"] - geom["jts"] + 1
+        self.tile_cells = nti * ntj
+        self.gw = None
+        if self.lateral and self.sorted:
+            # the groundwater planes stay in a tile-order block with the ring; the column state is the tile without it
+            gwb = DeviceColumnStore.__new__(DeviceColumnStore)
+            gwb.ni, gwb.nj, gwb.cfg, gwb.device, gwb.idx = s.ni, s.nj, cfg, torch.device(dev), dict(s.idx)
+            names = sorted(set(GW_ALIAS.values()) - {"dzs"} | set(GW_EXTRA))
+            gwb.a = {k: torch.from_numpy(s.a[k]).to(dev) for k in names}
+            gwb.a["dzs"] = s.a["dzs"].copy()
+            self.gw = gwb
+            inner = ColumnStore(nti, ntj, cfg)
+            for k in inner.a:
+                if k != "dzs":
+                    inner.a[k][...] = s.a[k][self.j_off:self.j_off + ntj, ..., self.i_off:self.i_off + nti]
+            inner.t_offset = s.t_offset[self.j_off:self.j_off + ntj, self.i_off:self.i_off + nti].copy()
+            inner.set_index(**dict({k: geom[k] for k in idx_keys}, ims=geom["its"], ime=geom["ite"], jms=geom["jts"], jme=geom["jte"]))
+            s = inner
         self.ni, self.nj = s.ni, s.nj
-        self.tile_cells = (geom["ite"] - geom["its"] + 1) * (geom["jte"] - geom["jts"] + 1)
         # 24 hourly forcing sets in tile order, resident in HBM (as a driver would have staged them)
         self.forcing = []
         for h in range(24):
@@ -157,33 +185,25 @@ class Run:
         self.stepwtd = max(int(cfg.wtddt * 60.0 / cfg.dt + 0.5), 1)                 # hdrv:1227 NINT
         self.ts = torch.cuda.Stream(device=dev)                                     # every kernel and exchange of the run
         self.sp = self.ts.cuda_stream
-        self.kernel_ms = 0.0
-        self.class_ms = [0.0, 0.0, 0.0]
-        self.n_adv = 0
-        self.n_land = 0
-        self.resorts = 0
-        self.stale_seen = []
-        self.halo_events = []
-        self.gw_calls = 0
+        self.reset_counters()
+        halo_store = self.gw if self.gw is not None else d
+        if self.lateral:
+            self.wargs = halo_store.wtable_args()
+            with torch.cuda.stream(self.ts):                                         # static planes of the stencil: once
+                comm.exchange_halo([halo_store.a["fdepth"], halo_store.a["topo"]], geom)
+                comm.exchange_halo([halo_store.a["isltyp"]], geom)
+            self.ts.synchronize()
         if self.sorted:
-            # Layout in HBM: state sorted on the device; forcing arrives in tile order and is permuted
-            # into the sorted working set every step
-            self.perm = eng.sort_store(d, tsk_bin=args.tsk_bin)
+            self.perm = eng.sort_store(d, tsk_bin=args.tsk_bin, allow_lateral=True)
             self._bind_sorted()
         else:
             self.sargs = []
             for h in range(24):                                                      # a step just points the block at the hour's set
                 d.a.update(self.forcing[h])
                 self.sargs.append(d.step_args(1, 2000, 180.0))
-            if self.lateral:
-                self.wargs = d.wtable_args()
-                with torch.cuda.stream(self.ts):                                     # static planes of the stencil: once
-                    comm.exchange_halo([d.a["fdepth"], d.a["topo"]], geom)
-                    comm.exchange_halo([d.a["isltyp"]], geom)
-                self.ts.synchronize()
 
     def _bind_sorted(self):
-        torch, d, eng = self.torch, self.d, self.eng
+        d, eng = self.d, self.eng
         self.work = {k: d.a[k] for k in FKEYS}
         self.scat = eng.scatter([self.work[k] for k in FKEYS], [self.forcing[0][k] for k in FKEYS], self.perm, self.ni, self.nj)
         self.sarg = d.step_args(1, 2000, 180.0)
@@ -195,22 +215,33 @@ class Run:
             self.scat(self.sp)
             self.sarg.itimestep = it
             self.eng.noahmplsm_async(self.sarg, self.sp)
-            if self.args.resort_every and it % self.args.resort_every == 0:
-                self.maybe_resort()
-            return
-        sa = self.sargs[h]
-        sa.itimestep = it
-        self.eng.noahmplsm_async(sa, self.sp)
+        else:
+            sa = self.sargs[h]
+            sa.itimestep = it
+            self.eng.noahmplsm_async(sa, self.sp)
         if self.lateral and it % self.stepwtd == 0:
-            torch = self.torch
-            with torch.cuda.stream(self.ts):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self.comm.exchange_halo([self.d.a["zwtxy"]], self.geom)              # ZWTXY ring before every call (gw:231-252)
-                e1.record()
-            self.halo_events.append((e0, e1))
-            self.eng.wtable_mmf_async(self.wargs, self.sp)
-            self.gw_calls += 1
+            self.groundwater()
+        if self.sorted and self.args.resort_every and it % self.args.resort_every == 0:
+            self.maybe_resort()
+
+    def groundwater(self):
+        """WTABLE_mmf_noahmp (gw:14) after the ZWTXY ring exchange (gw:231-252), enqueued on the run's stream."""
+        torch = self.torch
+        halo_store = self.gw if self.gw is not None else self.d
+        if self.gw is not None:                                                      # sorted -> (i,j) order, into the ring-carrying block
+            self.scat.exchange([self.d.a[k] for k in GW_SHARED], [self.gw.a[k] for k in GW_SHARED], True, self.gw.ni,
+                               self.i_off, self.j_off, self.sp)
+        with torch.cuda.stream(self.ts):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.comm.exchange_halo([halo_store.a["zwtxy"]], self.geom)              # ZWTXY ring before every call
+            e1.record()
+        self.halo_events.append((e0, e1))
+        self.eng.wtable_mmf_async(self.wargs, self.sp)
+        if self.gw is not None:                                                      # back to sorted order
+            self.scat.exchange([self.d.a[k] for k in GW_SHARED], [self.gw.a[k] for k in GW_SHARED], False, self.gw.ni,
+                               self.i_off, self.j_off, self.sp)
+        self.gw_calls += 1
 
     def collect(self):
         st, bad = self.eng.sync()                       # waits for the pending steps; tallies and kernel times summed over them
@@ -226,10 +257,11 @@ class Run:
         """Every `resort_every` steps: how many columns left the bucket they were sorted into (snow layers appeared or
         vanished)?  Above the threshold the state is sorted again on the device -- all of it inside the timed region."""
         self.collect()
+        self.ts.synchronize()
         stale = self.eng.sort_staleness(self.d)
         self.stale_seen.append(stale)
         if stale > self.args.resort_frac * self.d.ncol:
-            self.perm = self.eng.sort_store(self.d, tsk_bin=self.args.tsk_bin)
+            self.perm = self.eng.sort_store(self.d, tsk_bin=self.args.tsk_bin, allow_lateral=True)
             self._bind_sorted()
             self.resorts += 1
 
@@ -249,12 +281,16 @@ class Run:
             inv[p] = np.arange(p.size)
         out = {"geom": np.array([g["its"], g["ite"], g["jts"], g["jte"]])}
         for k, v in h.a.items():
-            if k == "dzs" or (k in FIELD_INFO and FIELD_INFO[k][2] == "in"):
+            if k not in FIELD_INFO or FIELD_INFO[k][2] == "in" or k == "dzs":
                 continue
             if inv is not None:                      # sorted position -> tile order
                 v = (v.transpose(1, 0, 2).reshape(v.shape[1], -1)[:, inv].reshape(v.shape[1], v.shape[0], v.shape[2]).transpose(1, 0, 2)
                      if v.ndim == 3 else v.reshape(-1)[inv].reshape(v.shape))
-            out[k] = v[j0:j1, ..., i0:i1]
+            out[k] = v if self.gw is not None else v[j0:j1, ..., i0:i1]      # the sorted config-4 state is the tile without the ring
+        if self.lateral:
+            src = self.gw.a if self.gw is not None else self.d.a
+            for k in GW_ONLY_OUT:
+                out[k] = src[k].cpu().numpy()[j0:j1, i0:i1]
         np.savez(path, **out)
 
     def reset_counters(self):
@@ -268,7 +304,8 @@ WORKLOAD_TEXT = {
     "config3": "BASELINE configs[2]: CONUS-1-km-like grid %(ni)dx%(nj)d = %(cols)d columns, 4 soil / up to 3 snow layers (30 %% snow-covered, "
                "ISNOW 0..-3), 2 %% urban, 1 %% land ice, reference namelist options (DVEG=%(dveg)d, opt_run=1)",
     "config4": "BASELINE configs[3]: the config-3 grid %(ni)dx%(nj)d = %(cols)d columns with OPT_RUN=5 cut into %(world)d tile(s) by "
-               "mpp_land_partition_calc, WTABLE_mmf_noahmp every %(stepwtd)d step(s) after the ZWTXY ring exchange, tile order",
+               "mpp_land_partition_calc, WTABLE_mmf_noahmp every %(stepwtd)d step(s) after the ZWTXY ring exchange (its planes return to "
+               "(i,j) order around the call)",
 }
 
 

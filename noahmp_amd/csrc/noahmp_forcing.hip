@@ -81,6 +81,10 @@ struct ScatterArgs {
   const unsigned short* order;
   const int* dpos;
   int n, ni, nj;
+  // the tile-order side may be the interior of a larger memory block (a tile that carries the LATERALFLOW ring): cell (ti, tj)
+  // of the tile sits at row tj + j_off, column ti + i_off of rows ni_mem long
+  int ni_mem, i_off, j_off;
+  int reverse;                     // 0: tile order -> sorted (src = tile side), 1: sorted -> tile order (dst = tile side)
 };
 __global__ void __launch_bounds__(256) noahmp_scatter_kernel(const ScatterArgs k) {
   constexpr int R = kChunk / 256;
@@ -97,7 +101,8 @@ __global__ void __launch_bounds__(256) noahmp_scatter_kernel(const ScatterArgs k
     pj[r] = dp >= 0 ? dp / k.ni : -1;
     pi[r] = dp >= 0 ? dp - pj[r] * k.ni : 0;
     sj[r] = in ? (int)(q / k.ni) : -1;
-    si[r] = in ? (int)(q - (long)sj[r] * k.ni) : 0;
+    si[r] = in ? (int)(q - (long)sj[r] * k.ni) + k.i_off : 0;
+    if (in) sj[r] += k.j_off;
   }
   int phase = 0;
   for (int f = 0; f < k.n; f++) {
@@ -105,13 +110,23 @@ __global__ void __launch_bounds__(256) noahmp_scatter_kernel(const ScatterArgs k
     const uint32_t* s = (const uint32_t*)k.src[f];
     uint32_t* d = (uint32_t*)k.dst[f];
     for (int l = 0; l < nk; l++, phase ^= 1) {
+      if (!k.reverse) {          // coalesced reads of consecutive tile cells, writes in ascending sorted position
 #pragma unroll
-      for (int r = 0; r < R; r++)
-        if (sj[r] >= 0) buf[phase][r * 256 + threadIdx.x] = s[((size_t)sj[r] * nk + l) * k.ni + si[r]];
-      __syncthreads();
+        for (int r = 0; r < R; r++)
+          if (sj[r] >= 0) buf[phase][r * 256 + threadIdx.x] = s[((size_t)sj[r] * nk + l) * k.ni_mem + si[r]];
+        __syncthreads();
 #pragma unroll
-      for (int r = 0; r < R; r++)
-        if (pj[r] >= 0) d[((size_t)pj[r] * nk + l) * k.ni + pi[r]] = buf[phase][ord[r]];
+        for (int r = 0; r < R; r++)
+          if (pj[r] >= 0) d[((size_t)pj[r] * nk + l) * k.ni + pi[r]] = buf[phase][ord[r]];
+      } else {                   // reads in ascending sorted position, coalesced writes of consecutive tile cells
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (pj[r] >= 0) buf[phase][ord[r]] = s[((size_t)pj[r] * nk + l) * k.ni + pi[r]];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          if (sj[r] >= 0) d[((size_t)sj[r] * nk + l) * k.ni_mem + si[r]] = buf[phase][r * 256 + threadIdx.x];
+      }
     }
   }
 }
@@ -128,8 +143,31 @@ int noahmp_hip_scatter_fields(int n, void* const* dst, const void* const* src, c
   ScatterArgs k;
   memset(&k, 0, sizeof(k));
   for (int f = 0; f < n; f++) { k.dst[f] = dst[f]; k.src[f] = src[f]; k.nlev[f] = nlev[f]; }
-  k.order = order; k.dpos = dpos; k.n = n; k.ni = ni; k.nj = nj;
+  k.order = order; k.dpos = dpos; k.n = n; k.ni = ni; k.nj = nj; k.ni_mem = ni;
   const long ncol = (long)ni * nj;
+  if (ncol > 0 && n > 0)
+    hipLaunchKernelGGL(noahmp_scatter_kernel, dim3((unsigned)((ncol + kChunk - 1) / kChunk)), dim3(256), 0, s, k);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The same plan between a SORTED store of a tile (nti x ntj columns, sorted positions) and planes in TILE order that may be the
+// interior of a larger memory block (rows ni_mem long, tile origin at (i_off, j_off)): direction 0 tile -> sorted, 1 sorted -> tile.
+// An OPT_RUN = 5 run keeps its columns sorted for the column kernel and returns the planes WTABLE_mmf_noahmp shares with it
+// (SMOIS, SH2O, SMCWTD, ZWT, DEEPRECH, RECH) to (i,j) order around every groundwater call (the stencil of gw:259-292 needs it).
+int noahmp_hip_sorted_exchange(int n, void* const* sorted, void* const* tile, const int* nlev, const uint16_t* order,
+                               const int32_t* dpos, int nti, int ntj, int ni_mem, int i_off, int j_off, int direction, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (n < 0 || n > kMaxGather) { g.last_error = "noahmp_hip_sorted_exchange: at most 32 fields per call"; return -107; }
+  if (ni_mem < nti + i_off || i_off < 0 || j_off < 0) { g.last_error = "noahmp_hip_sorted_exchange: the tile does not fit the memory block"; return -105; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  ScatterArgs k;
+  memset(&k, 0, sizeof(k));
+  for (int f = 0; f < n; f++) { k.dst[f] = direction ? tile[f] : sorted[f]; k.src[f] = direction ? sorted[f] : tile[f]; k.nlev[f] = nlev[f]; }
+  k.order = order; k.dpos = dpos; k.n = n; k.ni = nti; k.nj = ntj; k.ni_mem = ni_mem; k.i_off = i_off; k.j_off = j_off;
+  k.reverse = direction ? 1 : 0;
+  const long ncol = (long)nti * ntj;
   if (ncol > 0 && n > 0)
     hipLaunchKernelGGL(noahmp_scatter_kernel, dim3((unsigned)((ncol + kChunk - 1) / kChunk)), dim3(256), 0, s, k);
   HIPCHK(hipGetLastError());

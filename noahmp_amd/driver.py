@@ -267,6 +267,19 @@ class Engine:
             if rc:
                 raise RuntimeError("noahmp_hip_scatter_fields: rc=%d" % rc)
 
+        def exchange(self, sorted_planes, tile_planes, to_tile, ni_mem=None, i_off=0, j_off=0, stream=None):
+            """Move planes between the sorted store and TILE-order planes (possibly the interior of a memory block that carries
+            the LATERALFLOW ring: rows ni_mem long, tile origin at (i_off, j_off)) with this permutation's plan
+            (noahmp_hip_sorted_exchange).  to_tile: sorted -> tile order, else tile order -> sorted."""
+            n = len(sorted_planes)
+            sp = (C.c_void_p * n)(*[t.data_ptr() for t in sorted_planes])
+            tp = (C.c_void_p * n)(*[t.data_ptr() for t in tile_planes])
+            nl = (C.c_int * n)(*[(t.shape[1] if t.dim() == 3 else 1) for t in sorted_planes])
+            rc = self.lib.noahmp_hip_sorted_exchange(n, sp, tp, nl, self.order.data_ptr(), self.dpos.data_ptr(), self.ni, self.nj,
+                                                     ni_mem or self.ni, i_off, j_off, 1 if to_tile else 0, stream)
+            if rc:
+                raise RuntimeError("noahmp_hip_sorted_exchange: rc=%d" % rc)
+
     def scatter(self, dst, src, perm, ni, nj):
         return Engine.Scatter(self.lib, dst, src, perm, ni, nj)
 

@@ -337,3 +337,17 @@ def test_cabi_halo_exchange_on_host_planes(world):
         assert pr.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(n > 0 for _, _, n in res)
+
+
+@pytest.mark.gpu
+def test_bench_config4_sorted_equals_tile_order(tmp_path):
+    """Config 4 on the sorted layout (groundwater planes returned to (i,j) order around every WTABLE_mmf_noahmp call,
+    noahmp_hip_sorted_exchange) gives the bits of the tile-order run: column step, groundwater step and accumulators."""
+    a, da = _run_bench(["--gpus", "1", "--workload", "config4"], str(tmp_path), "sorted")
+    b, db = _run_bench(["--gpus", "1", "--workload", "config4", "--no-sort"], str(tmp_path), "tile")
+    assert "sort" in a and "sort" not in b
+    x, y = np.load(da + ".rank0.npz"), np.load(db + ".rank0.npz")
+    assert set(x.files) == set(y.files) and "qslat" in x.files
+    for k in x.files:
+        assert np.array_equal(x[k], y[k], equal_nan=True), k
+    assert (x["qslat"] != 0).any() and (x["isnowxy"] < 0).any()
