@@ -194,7 +194,9 @@ class Run:
                 comm.exchange_halo([halo_store.a["isltyp"]], geom)
             self.ts.synchronize()
         if self.sorted:
-            self.perm = eng.sort_store(d, tsk_bin=args.tsk_bin, allow_lateral=True)
+            self.sort_kw = dict(tsk_bin=args.tsk_bin, allow_lateral=True, snow_first=args.snow_first, veg=not args.no_veg_key,
+                                snow=not args.no_snow_key)
+            self.perm = eng.sort_store(d, **self.sort_kw)
             self._bind_sorted()
         else:
             self.sargs = []
@@ -261,7 +263,7 @@ class Run:
         stale = self.eng.sort_staleness(self.d)
         self.stale_seen.append(stale)
         if stale > self.args.resort_frac * self.d.ncol:
-            self.perm = self.eng.sort_store(self.d, tsk_bin=self.args.tsk_bin, allow_lateral=True)
+            self.perm = self.eng.sort_store(self.d, **self.sort_kw)
             self._bind_sorted()
             self.resorts += 1
 
@@ -322,6 +324,9 @@ def main():
     ap.add_argument("--resort-every", type=int, default=24, help="steps between staleness checks of the sorted layout (0 = never)")
     ap.add_argument("--resort-frac", type=float, default=0.01, help="re-sort when this share of the columns left their bucket")
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
+    ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-snow-key", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--halo", choices=("torch", "rccl", "tcp"), default=os.environ.get("NMP_HALO", "torch"),
                     help="who moves the groundwater ring: torch.distributed send/recv (RCCL under the nccl backend), or the engine's "
                          "C-ABI exchange noahmp_hip_exchange_halo with its RCCL or socket transport")
