@@ -195,7 +195,7 @@ class Run:
             self.ts.synchronize()
         if self.sorted:
             self.sort_kw = dict(tsk_bin=args.tsk_bin, allow_lateral=True, snow_first=args.snow_first, veg=not args.no_veg_key,
-                                snow=not args.no_snow_key)
+                                snow=not args.no_snow_key, tair=args.tair_key)
             self.perm = eng.sort_store(d, **self.sort_kw)
             self._bind_sorted()
         else:
@@ -322,9 +322,12 @@ def main():
     ap.add_argument("--dveg", type=int, default=3)
     ap.add_argument("--tsk-bin", type=float, default=1.0, help="skin-temperature bin of the sort key [K], 0 = off")
     ap.add_argument("--resort-every", type=int, default=24, help="steps between staleness checks of the sorted layout (0 = never)")
-    ap.add_argument("--resort-frac", type=float, default=0.01, help="re-sort when this share of the columns left their bucket")
+    ap.add_argument("--resort-frac", type=float, default=0.10,
+                    help="re-sort when this share of the columns left their bucket (measured: 11 %% stale columns cost the land kernel 0.8 %%, "
+                         "a re-sort 1.7 ms -- profiles/r02_experiments.md)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
+    ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-snow-key", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--halo", choices=("torch", "rccl", "tcp"), default=os.environ.get("NMP_HALO", "torch"),

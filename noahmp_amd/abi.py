@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnoahmp_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
-SORT_VEG, SORT_SNOW, SORT_SNOW_FIRST = 1, 2, 4
+SORT_VEG, SORT_SNOW, SORT_SNOW_FIRST, SORT_TAIR = 1, 2, 4, 8
 HALO_TCP, HALO_RCCL = 0, 1
 
 

@@ -696,7 +696,7 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
 int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   if (st) memset(st, 0, sizeof(*st));
   if (step_out) *step_out = -1;
-  if (!g.async_pending) return 0;
+  if (!g.async_pending) { g.sync_steps = 0; for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f; return 0; }
   hipStream_t s = g.async_stream;
   for (hipStream_t q : g.async_streams) if (q != s) HIPCHK(hipStreamSynchronize(q));   // steps may sit on several streams
   g.async_streams.clear();

@@ -16,7 +16,8 @@ using nmp_host::g;
 namespace {
 
 struct KeyArgs {
-  const float* xland; const float* xice; const float* tsk;
+  const float* xland; const float* xice; const float* tsk;   // tsk: the temperature plane of the key (TSK, or level 1 of T3D)
+  int t_nk, t_k, ni;                                          // its levels per row, the level taken, the row length
   const int* ivgtyp; const int* isnow;
   float xice_thres, inv_bin;
   int isice, flags;
@@ -34,7 +35,7 @@ __device__ __forceinline__ unsigned column_key(const KeyArgs& k, long p) {
   if (cls == 0u && (k.flags & NOAHMP_SORT_VEG)) veg = (unsigned)min(max(ivg, 0), 63);
   if (k.flags & NOAHMP_SORT_SNOW) sn = (unsigned)min(max(-k.isnow[p], 0), 3);
   if (k.inv_bin > 0.f) {
-    float t = k.tsk[p];
+    float t = k.t_nk == 1 ? k.tsk[p] : k.tsk[((size_t)(p / k.ni) * k.t_nk + k.t_k) * k.ni + p % k.ni];
     if (!(t == t)) t = 250.f;
     tb = (unsigned)min(max((int)((t - 230.0f) * k.inv_bin), 0), 255);
   }
@@ -104,6 +105,8 @@ int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_
     return -105;
   }
   k.xland = a->xland; k.xice = a->xice; k.tsk = a->tsk; k.ivgtyp = a->ivgtyp; k.isnow = a->isnowxy;
+  k.t_nk = 1; k.t_k = 0; k.ni = a->ime - a->ims + 1;
+  if (flags & NOAHMP_SORT_TAIR) { k.tsk = a->t3d; k.t_nk = a->kme - a->kms + 1; k.t_k = 1 - a->kms; }   // the forcing air temperature (level 1)
   k.xice_thres = a->xice_thres; k.isice = a->isice; k.flags = flags;
   k.inv_bin = tsk_bin_mk > 0 ? 1000.0f / (float)tsk_bin_mk : 0.f;
   k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);

@@ -1,0 +1,23 @@
+#!/bin/bash
+O=gpurun_out/r2_keys2; mkdir -p $O
+run() {
+  tag=$1; shift
+  timeout 600 python bench.py --no-cpu-baseline "$@" > $O/$tag.log 2>&1
+  python - "$O/$tag.log" "$tag" <<'PY'
+import json, sys
+for ln in open(sys.argv[1]):
+    if ln.startswith("{"):
+        j = json.loads(ln)
+        print("%-22s value %.4g  ms/step %.3f  land kernel %.3f ms  sort %s" % (sys.argv[2], j["value"], j["ms_per_step"], j["roofline"]["kernel_ms_avg"], j.get("sort")))
+        break
+else:
+    print(sys.argv[2], "FAILED"); print(open(sys.argv[1]).read()[-800:])
+PY
+}
+run tsk_resort6 --resort-every 6 --resort-frac 0
+run tair_resort0 --tair-key --resort-every 0
+run tair_resort6 --tair-key --resort-every 6 --resort-frac 0
+run tair_resort24 --tair-key --resort-every 24 --resort-frac 0
+run tair05_resort0 --tair-key --tsk-bin 0.5 --resort-every 0
+run tair_nosnow --tair-key --no-snow-key --resort-every 0
+run frac10 --resort-frac 0.10
