@@ -100,6 +100,7 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s);
 void jit_finalize();
 void jit_stats(int* out);
 std::string cache_dir_public();
+unsigned long long source_hash_public();
 void sort_finalize();     // noahmp_sort.hip
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \

@@ -248,6 +248,7 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
 }
 
 std::string cache_dir_public() { return cache_dir(); }
+unsigned long long source_hash_public() { return source_hash(); }
 
 bool jit_compile_probe(const int* o, std::string& log) {
   const int keep = g.jit_compile_only;
@@ -278,6 +279,9 @@ extern "C" int noahmp_hip_jit_compile_check(const int32_t* options12, char* log,
   if (log && cap) { strncpy(log, msg.c_str(), cap - 1); log[cap - 1] = 0; }
   return ok ? 0 : 1;
 }
+
+// the hash that keys the cache files (kernel sources + build macros + compiler flags + hiprtc version); 0 = sources not found
+extern "C" unsigned long long noahmp_hip_jit_source_hash(void) { return nmp_host::source_hash_public(); }
 
 // {compiled by this process, loaded from the on-disk cache, fell back to the generic kernel}; returns the cache directory ("" = none)
 extern "C" const char* noahmp_hip_jit_cache_info(int32_t* counts3) {

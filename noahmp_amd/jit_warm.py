@@ -61,7 +61,25 @@ def warm(cfgs=None, jobs=None, verbose=False):
             print("jit_warm: option set %s FAILED\n%s" % (o, out[-600:]))
         elif verbose:
             print("jit_warm:", o, out.strip().splitlines()[-1] if out.strip() else "")
+    _drop_stale()
     return len(sets), failed
+
+
+def _drop_stale():
+    """Remove code objects of earlier source versions from the cache directory (their hash no longer matches)."""
+    from . import abi
+    lib = abi.load_library()
+    d = lib.noahmp_hip_jit_cache_info(None)
+    h = "%016x" % lib.noahmp_hip_jit_source_hash()
+    if not d or h == "0" * 16:
+        return
+    d = d.decode()
+    for f in os.listdir(d):
+        if f.startswith("nmp_gfx950_") and f.endswith(".hsaco") and not f.endswith("_" + h + ".hsaco"):
+            try:
+                os.unlink(os.path.join(d, f))
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":
