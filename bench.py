@@ -334,6 +334,8 @@ def main():
                     help="who moves the groundwater ring: torch.distributed send/recv (RCCL under the nccl backend), or the engine's "
                          "C-ABI exchange noahmp_hip_exchange_halo with its RCCL or socket transport")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="N = 1, default workload: skip the short config-4 run that gives the N = 1 point of the --gpus N curve")
     ap.add_argument("--dump", default=None, help="write every rank's tile (tile order, without the ring) to DUMP.rank<r>.npz after the run")
     ap.add_argument("--cpu-baseline-only", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -398,6 +400,43 @@ def main():
 
     if args.dump:
         run.dump(args.dump + ".rank%d.npz" % rank)
+
+    # The default N > 1 workload is config 4 (the same grid with the groundwater exchange).  So that a scaling curve over
+    # N = 1, 2, 4, 8 has its N = 1 point on the SAME workload, the default N = 1 run measures it too, after the headline (a second,
+    # separately timed region of the same length; reported beside the headline, never as `value`).
+    scaling_ref = None
+    if world == 1 and workload == "config3" and args.workload is None and not args.no_scaling_reference:
+        summary = dict(class_ms=list(run.class_ms), n_land=run.n_land, n_adv=run.n_adv, resorts=run.resorts, stale=list(run.stale_seen),
+                       sorted=run.sorted, lateral=run.lateral, tile_cells=run.tile_cells, stepwtd=run.stepwtd, kernel_ms=run.kernel_ms)
+        del run
+        torch.cuda.empty_cache()
+        r4 = Run(args, "config4", comm, eng, tb, dev)
+        it4 = 0
+        for _ in range(args.warmup):
+            it4 += 1
+            r4.step(it4)
+        r4.collect()
+        r4.reset_counters()
+        barrier()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            it4 += 1
+            r4.step(it4)
+        r4.collect()
+        barrier()
+        dt4 = time.perf_counter() - t4
+        scaling_ref = {"workload": "BASELINE configs[3] on one GPU (`--workload config4`): the N = 1 point of the --gpus N strong-scaling curve",
+                       "value": r4.n_adv / dt4, "unit": "column-steps/s", "ms_per_step": dt4 / args.steps * 1e3, "steps": args.steps,
+                       "groundwater_calls": r4.gw_calls, "column_kernels_ms_per_step": r4.kernel_ms / args.steps}
+        del r4
+        torch.cuda.empty_cache()
+
+        class _R:            # what the report below needs of the headline run
+            pass
+        run = _R()
+        run.class_ms, run.n_land, run.n_adv, run.resorts, run.stale_seen = summary["class_ms"], summary["n_land"], summary["n_adv"], summary["resorts"], summary["stale"]
+        run.sorted, run.lateral, run.tile_cells, run.stepwtd, run.kernel_ms = summary["sorted"], summary["lateral"], summary["tile_cells"], summary["stepwtd"], summary["kernel_ms"]
+        run.gw_calls = 0
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -468,6 +507,8 @@ def main():
             out["groundwater"] = {"calls": run.gw_calls, "stepwtd": run.stepwtd,
                                   "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
+        if scaling_ref is not None:
+            out["scaling_reference"] = scaling_ref
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

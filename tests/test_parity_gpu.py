@@ -20,9 +20,15 @@ EXACT = None
 
 
 def _exact(engine):
+    """True for the shipped build (reference-libm algorithms on the device: bit-identity is asserted).  A library built with
+    -DNMP_EXACT_LIBM=0 (ocml) only meets the statistical contract; the suite refuses to downgrade silently: such a build must
+    be announced with NMP_TEST_OCML_BUILD=1."""
     global EXACT
     if EXACT is None:
         EXACT = engine.exact_libm
+        if not EXACT and os.environ.get("NMP_TEST_OCML_BUILD") != "1":
+            raise AssertionError("libnoahmp_hip.so was built without the reference-libm restatements (exact_libm = 0): the bit-identity "
+                                 "tests would silently turn into statistical ones.  Set NMP_TEST_OCML_BUILD=1 to test such a build.")
     return EXACT
 
 
