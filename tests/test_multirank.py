@@ -351,3 +351,27 @@ def test_bench_config4_sorted_equals_tile_order(tmp_path):
     for k in x.files:
         assert np.array_equal(x[k], y[k], equal_nan=True), k
     assert (x["qslat"] != 0).any() and (x["isnowxy"] < 0).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["config4", "config3"])
+def test_bench_run_equals_the_oracle(workload, tmp_path, port, tables):
+    """The run bench.py times (small grid: column step on the sorted layout with the per-step forcing permutation; config 4: plus
+    WTABLE_mmf_noahmp every step on planes returned to (i,j) order) against the oracle advancing the same global grid in tile
+    order with the same forcing sequence -- every INOUT / OUT array bit for bit after 7 steps."""
+    from noahmp_amd.state import ModelConfig
+    gx, gy = 96, 130
+    res, dump = _run_bench(["--gpus", "1", "--workload", workload], str(tmp_path), "gpu")
+    lateral = workload == "config4"
+    g = synth.config3_tile(tables[1], gx, gy, cfg=ModelConfig(iopt_run=5 if lateral else 1), groundwater=lateral)
+    synth.first_step_fixups(g)
+    for it in range(1, 8):                                   # 2 warm-up + 5 timed steps, hours as bench.py's Run.step
+        synth.diurnal_forcing(g, (it + 5) % 24, t_offset=g.t_offset)
+        assert port.noahmplsm(g, it, 2000, 180.0).code == 0
+        if lateral:
+            port.wtable_mmf(g)
+    got = np.load(dump + ".rank0.npz")
+    names = [k for k in got.files if k != "geom"]
+    assert "tslb" in names and "isnowxy" in names and (not lateral or "qslat" in names)
+    for k in names:
+        assert np.array_equal(g.a[k], got[k], equal_nan=True), k
