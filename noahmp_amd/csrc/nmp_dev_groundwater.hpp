@@ -45,18 +45,22 @@ NMP_DEV float gw_klatfactor(int st) {
 }
 
 // gw:239-250 for one cell
-NMP_DEV void gw_cell_head(const GwArgs& g, size_t x) {
-  const float fdepth = g.a.fdepth[x], wtd = g.a.wtd[x];
+NMP_DEV void gw_cell_head_values(const GwArgs& g, float fdepth, float wtd, float topo, int st, float& kcell, float& head) {
   float kc = 0.f;
   if (fdepth > 0.f) {
-    const int st = g.a.isltyp[x];
     const float satdk = (st >= 1 && st <= 30 /* NSLTYPE, lsm:83 */) ? g.T->satdk[st - 1] : 0.f;
     const float klat = satdk * gw_klatfactor(st);
     if (wtd < -1.5f) kc = fdepth * klat * nmp_expf((wtd + 1.5f) / fdepth);
     else kc = klat * (wtd + 1.5f + fdepth);
   }
+  kcell = kc;
+  head = topo + wtd;
+}
+NMP_DEV void gw_cell_head(const GwArgs& g, size_t x) {
+  float kc, hd;
+  gw_cell_head_values(g, g.a.fdepth[x], g.a.wtd[x], g.a.topo[x], g.a.isltyp[x], kc, hd);
   g.kcell[x] = kc;
-  g.head[x] = g.a.topo[x] + wtd;
+  g.head[x] = hd;
 }
 
 // register-resident 1-based views of the NSOIL=4 layer arrays

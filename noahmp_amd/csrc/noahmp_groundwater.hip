@@ -22,13 +22,34 @@ namespace {
 
 constexpr int BX = 64, BY = 4;
 
-// KCELL / HEAD on the tile + ring rectangle (gw:237-252)
+// KCELL / HEAD on the tile + ring rectangle (gw:237-252).  24 algorithmic bytes and one EXP per cell: pure streaming, so every
+// thread takes HEAD_ILP cells (BX apart: each wave instruction still covers 256 contiguous bytes) and has their loads in flight together.
+constexpr int HEAD_ILP = 4;
 __global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
   libm::libm_stage_tables();
-  const int gi = k.hi0 + blockIdx.x * BX + threadIdx.x;
   const int gj = k.hj0 + blockIdx.y * BY + threadIdx.y;
-  if (gi > k.hi1 || gj > k.hj1) return;
-  gw_cell_head(k, (size_t)(gj - k.a.jms) * k.ni + (gi - k.a.ims));
+  if (gj > k.hj1) return;
+  const int gi0 = k.hi0 + blockIdx.x * (BX * HEAD_ILP) + threadIdx.x;
+  const size_t row = (size_t)(gj - k.a.jms) * k.ni;
+  float fdepth[HEAD_ILP], wtd[HEAD_ILP], topo[HEAD_ILP];
+  int st[HEAD_ILP];
+#pragma unroll
+  for (int u = 0; u < HEAD_ILP; u++) {
+    const int gi = gi0 + u * BX;
+    const bool in = gi <= k.hi1;
+    const size_t x = row + (in ? gi - k.a.ims : k.hi0 - k.a.ims);
+    fdepth[u] = k.a.fdepth[x]; wtd[u] = k.a.wtd[x]; topo[u] = k.a.topo[x]; st[u] = k.a.isltyp[x];
+  }
+#pragma unroll
+  for (int u = 0; u < HEAD_ILP; u++) {
+    const int gi = gi0 + u * BX;
+    if (gi > k.hi1) continue;
+    const size_t x = row + (gi - k.a.ims);
+    float kc, hd;
+    gw_cell_head_values(k, fdepth[u], wtd[u], topo[u], st[u], kc, hd);
+    k.kcell[x] = kc;
+    k.head[x] = hd;
+  }
 }
 
 // stencil + per-cell update over the tile (gw:105-195)
@@ -163,7 +184,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   const int hni = k.hi1 - k.hi0 + 1, hnj = k.hj1 - k.hj0 + 1;
   const int tni = a->ite - a->its + 1, tnj = a->jte - a->jts + 1;
   if (hni > 0 && hnj > 0)
-    hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX - 1) / BX, (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
+    hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX * HEAD_ILP - 1) / (BX * HEAD_ILP), (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
   if (init) {
     const int itf = imin(a->ite, a->ide - 1), jtf = imin(a->jte, a->jde - 1);
     const int ini_ = itf - a->its + 1, inj_ = jtf - a->jts + 1;
