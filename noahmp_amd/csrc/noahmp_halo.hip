@@ -64,6 +64,19 @@ struct Halo {
 
 int fail(const std::string& m, int rc = -109) { g.last_error = "noahmp_hip_halo: " + m; return rc; }
 
+int load_rccl() {
+  if (H.rccl.Send) return 0;
+  H.rccl.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!H.rccl.handle) H.rccl.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!H.rccl.handle) return fail("librccl.so not found (dlopen)");
+#define NMP_SYM(field, name) *(void**)&H.rccl.field = dlsym(H.rccl.handle, name); if (!H.rccl.field) return fail(std::string("librccl: no symbol ") + name);
+  NMP_SYM(GetUniqueId, "ncclGetUniqueId") NMP_SYM(CommInitRank, "ncclCommInitRank") NMP_SYM(CommDestroy, "ncclCommDestroy")
+  NMP_SYM(GroupStart, "ncclGroupStart") NMP_SYM(GroupEnd, "ncclGroupEnd") NMP_SYM(Send, "ncclSend") NMP_SYM(Recv, "ncclRecv")
+#undef NMP_SYM
+  *(void**)&H.rccl.GetErrorString = dlsym(H.rccl.handle, "ncclGetErrorString");
+  return 0;
+}
+
 // ---- sockets
 bool send_all(int fd, const void* p, size_t n) {
   const char* c = (const char*)p;
@@ -248,14 +261,7 @@ int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int mast
   std::vector<Peer> table(nranks);
   NcclUniqueId uid; memset(&uid, 0, sizeof uid);
   if (transport == NOAHMP_HALO_RCCL) {
-    H.rccl.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!H.rccl.handle) H.rccl.handle = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!H.rccl.handle) { close(lfd); return fail("librccl.so not found (dlopen)"); }
-#define NMP_SYM(field, name) *(void**)&H.rccl.field = dlsym(H.rccl.handle, name); if (!H.rccl.field) { close(lfd); return fail(std::string("librccl: no symbol ") + name); }
-    NMP_SYM(GetUniqueId, "ncclGetUniqueId") NMP_SYM(CommInitRank, "ncclCommInitRank") NMP_SYM(CommDestroy, "ncclCommDestroy")
-    NMP_SYM(GroupStart, "ncclGroupStart") NMP_SYM(GroupEnd, "ncclGroupEnd") NMP_SYM(Send, "ncclSend") NMP_SYM(Recv, "ncclRecv")
-#undef NMP_SYM
-    *(void**)&H.rccl.GetErrorString = dlsym(H.rccl.handle, "ncclGetErrorString");
+    if (load_rccl()) { close(lfd); return -109; }
     if (rank == 0 && H.rccl.GetUniqueId(&uid)) { close(lfd); return fail("ncclGetUniqueId"); }
   }
   if (rank == 0) {
@@ -348,6 +354,38 @@ int noahmp_hip_exchange_halo(int n, void* const* planes, const int32_t* index8, 
   rc = phase(n, planes, d_planes, device, s, 2, sd, rd, 3, su, ru);
   if (rc) return rc;
   if (device) HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Self-test of the RCCL plumbing on ONE GPU (the exchange itself needs one GPU per rank): load librccl, create a communicator of
+// size 1, send `words` 4-byte words to self through ncclSend / ncclRecv in one group on the engine's stream, compare.  0 = ok.
+int noahmp_hip_halo_selftest_rccl(int words) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (load_rccl()) return -109;
+  NcclUniqueId uid; memset(&uid, 0, sizeof uid);
+  int e = H.rccl.GetUniqueId(&uid);
+  if (e) return fail("ncclGetUniqueId");
+  NcclComm comm = nullptr;
+  e = H.rccl.CommInitRank(&comm, 1, uid, 0);
+  if (e) return fail(std::string("ncclCommInitRank: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e) : "error"));
+  std::vector<uint32_t> h(words), back(words, 0);
+  for (int i = 0; i < words; i++) h[i] = 0x9E3779B9u * (uint32_t)(i + 1);
+  uint32_t *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc((void**)&a, words * 4));
+  HIPCHK(hipMalloc((void**)&b, words * 4));
+  HIPCHK(hipMemcpy(a, h.data(), words * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(b, 0, words * 4));
+  e = H.rccl.GroupStart();
+  if (!e) e = H.rccl.Send(a, (size_t)words, kNcclInt32, 0, comm, g.own_stream);
+  if (!e) e = H.rccl.Recv(b, (size_t)words, kNcclInt32, 0, comm, g.own_stream);
+  const int e2 = H.rccl.GroupEnd();
+  if (e || e2) { H.rccl.CommDestroy(comm); return fail(std::string("RCCL self send/recv: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e ? e : e2) : "error")); }
+  HIPCHK(hipStreamSynchronize(g.own_stream));
+  HIPCHK(hipMemcpy(back.data(), b, words * 4, hipMemcpyDeviceToHost));
+  hipFree(a); hipFree(b);
+  H.rccl.CommDestroy(comm);
+  for (int i = 0; i < words; i++) if (back[i] != h[i]) return fail("RCCL self send/recv returned other data");
   return 0;
 }
 

@@ -375,3 +375,14 @@ def test_bench_run_equals_the_oracle(workload, tmp_path, port, tables):
     assert "tslb" in names and "isnowxy" in names and (not lateral or "qslat" in names)
     for k in names:
         assert np.array_equal(g.a[k], got[k], equal_nan=True), k
+
+
+@pytest.mark.gpu
+def test_rccl_plumbing_selftest_on_one_gpu():
+    """The RCCL transport of noahmp_hip_exchange_halo needs one GPU per rank; what one GPU can check is its plumbing: librccl
+    resolves (dlopen, beside torch's copy), ncclCommInitRank with a unique id, ncclSend / ncclRecv in one group on the engine's
+    stream (to self) return the data."""
+    from noahmp_amd import abi
+    lib = abi.load_library()
+    rc = lib.noahmp_hip_halo_selftest_rccl(25000)
+    assert rc == 0, lib.noahmp_hip_last_error().decode()
