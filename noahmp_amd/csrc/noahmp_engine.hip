@@ -585,7 +585,11 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   if (g.async_pending) { g.last_error = "noahmp_hip_step: asynchronous steps are pending, call noahmp_hip_sync() first"; return -106; }
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
   if (mem == NOAHMP_MEM_HOST && g.resident_state) return step_host_resident(a, s, st);
-  if (mem == NOAHMP_MEM_HOST && (g.deferred_pending || g.resident_dirty)) { rc = noahmp_hip_fetch(nullptr); if (rc < 0) return rc; }
+  if (mem == NOAHMP_MEM_HOST && (g.deferred_pending || g.resident_dirty)) {
+    rc = noahmp_hip_fetch(nullptr);                 // leaving the resident path: host arrays up to date first
+    if (rc < 0) return rc;
+    if (rc > 0) { if (st) st->code = rc; g.last_error = "a fatal column of the previous (deferred) step"; return rc; }   // never drop a pending fatal
+  }
   if (mem == NOAHMP_MEM_HOST) g.resident_valid = false;
   // the row-chunk pipeline only pays with pinned arrays (pageable asynchronous copies are staged and serialise)
   if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && g.host_chunks > 1 &&
