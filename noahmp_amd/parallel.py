@@ -26,6 +26,7 @@ class Comm:
         self.backend = None
         self.halo = halo
         self.halo_lib = None
+        self._halo_plans = {}
         if halo != "torch" and self.world > 1:
             from . import abi
             self.halo_lib = abi.load_library()
@@ -72,54 +73,52 @@ class Comm:
             return self._exchange_cabi(planes, geom)
         if not self.dist:
             return
+        key = (tuple(int(p.data_ptr()) for p in planes), tuple(sorted(geom.items())))
+        plan = self._halo_plans.get(key)
+        if plan is None:
+            plan = self._halo_plans[key] = self._build_plan(planes, geom)
+        for legs in plan:                                    # phase 1: left / right, phase 2: down / up
+            self._run_phase(legs)
+
+    def _build_plan(self, planes, geom):
+        """Views, persistent staging buffers and P2P descriptors of the two phases for these planes: the per-call work is then one
+        copy per edge, one batch_isend_irecv per phase and one copy per received edge (the exchange is latency-bound; at 8 ranks
+        a step of the config-4 run is under a millisecond, so the Python side must not rebuild anything per call)."""
+        dist = self.dist
         nb = self.my_neighbours()
         i0, i1 = geom["its"] - geom["ims"], geom["ite"] - geom["ims"]
         j0, j1 = geom["jts"] - geom["jms"], geom["jte"] - geom["jms"]
         rows = slice(j0, j1 + 1)
-        self._exchange(planes, [(nb["left"], (rows, i0), (rows, i0 - 1)),
-                                (nb["right"], (rows, i1), (rows, i1 + 1))])
         full = slice(None)
-        self._exchange(planes, [(nb["down"], (j0, full), (j0 - 1, full)),
-                                (nb["up"], (j1, full), (j1 + 1, full))])
+        phases = [[(nb["left"], (rows, i0), (rows, i0 - 1)), (nb["right"], (rows, i1), (rows, i1 + 1))],
+                  [(nb["down"], (j0, full), (j0 - 1, full)), (nb["up"], (j1, full), (j1 + 1, full))]]
+        plan = []
+        for legs in phases:
+            edges, ops = [], []
+            for peer, send_ix, recv_ix in legs:
+                if peer < 0:
+                    continue
+                for p in planes:
+                    sview, rview = p[send_ix], p[recv_ix]
+                    host = self.backend == "gloo" and p.is_cuda          # gloo has no device send/recv: stage through the host
+                    sbuf = sview.new_empty(sview.shape, device="cpu" if host else p.device)
+                    rbuf = sbuf.new_empty(sbuf.shape)
+                    ops.append(dist.P2POp(dist.isend, sbuf, peer))
+                    ops.append(dist.P2POp(dist.irecv, rbuf, peer))
+                    edges.append((sview, sbuf, rview, rbuf))
+            plan.append((edges, ops))
+        return plan
 
-    def _exchange_cabi(self, planes, geom):
-        """The same two-phase exchange done by the engine library (noahmp_hip_exchange_halo): device planes on torch's current
-        stream, host planes (numpy arrays / CPU tensors) over its socket transport."""
-        import ctypes as C
-        import numpy as np
-        from . import abi
-        n = len(planes)
-        ptrs = (C.c_void_p * n)(*[(p.ctypes.data if isinstance(p, np.ndarray) else p.data_ptr()) for p in planes])
-        idx = (C.c_int32 * 8)(*[geom[k] for k in ("ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")])
-        cuda = (not isinstance(planes[0], np.ndarray)) and planes[0].is_cuda
-        stream = None
-        if cuda:
-            import torch
-            stream = torch.cuda.current_stream().cuda_stream
-        rc = self.halo_lib.noahmp_hip_exchange_halo(n, ptrs, idx, abi.MEM_DEVICE if cuda else abi.MEM_HOST, stream)
-        if rc:
-            raise RuntimeError("noahmp_hip_exchange_halo: rc=%d %s" % (rc, self.halo_lib.noahmp_hip_last_error().decode()))
-
-    def _exchange(self, planes, legs):
-        dist = self.dist
-        ops, landing = [], []
-        for peer, send_ix, recv_ix in legs:
-            if peer < 0:
-                continue
-            for p in planes:
-                sbuf = p[send_ix].contiguous()
-                if self.backend == "gloo" and sbuf.is_cuda:      # gloo has no device send/recv: stage through the host
-                    sbuf = sbuf.cpu()
-                rbuf = sbuf.new_empty(sbuf.shape)
-                ops.append(dist.P2POp(dist.isend, sbuf, peer))
-                ops.append(dist.P2POp(dist.irecv, rbuf, peer))
-                landing.append((p, recv_ix, rbuf))
+    def _run_phase(self, phase):
+        edges, ops = phase
         if not ops:
             return
-        for w in dist.batch_isend_irecv(ops):
+        for sview, sbuf, rview, rbuf in edges:
+            sbuf.copy_(sview)
+        for w in self.dist.batch_isend_irecv(ops):
             w.wait()                                             # RCCL: orders the current stream after the transfer, no host wait
-        for p, recv_ix, rbuf in landing:
-            p[recv_ix] = rbuf.to(p.device, non_blocking=True) if rbuf.device != p.device else rbuf
+        for sview, sbuf, rview, rbuf in edges:
+            rview.copy_(rbuf, non_blocking=True)
 
     # ---- timing / metric plumbing
     def _dev(self):
