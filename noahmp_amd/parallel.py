@@ -120,6 +120,24 @@ class Comm:
         for sview, sbuf, rview, rbuf in edges:
             rview.copy_(rbuf, non_blocking=True)
 
+    def _exchange_cabi(self, planes, geom):
+        """The same two-phase exchange done by the engine library (noahmp_hip_exchange_halo): device planes on torch's current
+        stream, host planes (numpy arrays / CPU tensors) over its socket transport."""
+        import ctypes as C
+        import numpy as np
+        from . import abi
+        n = len(planes)
+        ptrs = (C.c_void_p * n)(*[(p.ctypes.data if isinstance(p, np.ndarray) else p.data_ptr()) for p in planes])
+        idx = (C.c_int32 * 8)(*[geom[k] for k in ("ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")])
+        cuda = (not isinstance(planes[0], np.ndarray)) and planes[0].is_cuda
+        stream = None
+        if cuda:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        rc = self.halo_lib.noahmp_hip_exchange_halo(n, ptrs, idx, abi.MEM_DEVICE if cuda else abi.MEM_HOST, stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_exchange_halo: rc=%d %s" % (rc, self.halo_lib.noahmp_hip_last_error().decode()))
+
     # ---- timing / metric plumbing
     def _dev(self):
         import torch
