@@ -48,7 +48,8 @@ def extract(store, flat, n=None):
     return out
 
 
-def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240), restart_path=None, cfgkw=None):
+def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240), restart_path=None, cfgkw=None,
+        resort_every=24, resort_frac=0.10):
     T, tb = load_tables("usgs")
     port = PortLib(autobuild=not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libnoahmp_oracle.so")))
     port.set_tables(T)
@@ -58,11 +59,17 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     dev = torch.device("cuda", 0)
     d = raw.to_device("cuda:0")
     eng.noahmp_init(d, fndsnowh=True)                                  # cold start on the device
-    perm = eng.sort_store(d)                                           # (class, vegetation type, TSK bin) order
-    pl = perm.long()
-    srt = lambda x: torch.from_numpy(x).to(dev).reshape(-1)[pl].reshape(nj, ni).contiguous()
-    lon_d = srt(lon)
-    recs = synth5.Records(d.a["xlatin"], lon_d, {k: srt(v) for k, v in static.items()})
+    perm = eng.sort_store(d)                                           # (class, vegetation type, snow layers, TSK bin) order
+    lon_t = torch.from_numpy(lon).to(dev).reshape(-1)
+    static_t = {k: torch.from_numpy(v).to(dev).reshape(-1) for k, v in static.items()}
+
+    def sorted_side(perm):
+        """what lives outside the store but in its column order: longitude and the static fields of the forcing records"""
+        pl = perm.long()
+        lon_d = lon_t[pl].reshape(nj, ni).contiguous()
+        return lon_d, synth5.Records(d.a["xlatin"], lon_d, {k: v[pl].reshape(nj, ni).contiguous() for k, v in static_t.items()})
+
+    lon_d, recs = sorted_side(perm)
     rain_d = torch.zeros((nj, ni), dtype=torch.float32, device=dev)
     n_land = int(((d.a["xland"] < 1.5) & (d.a["xice"] < raw.cfg.xice_thres)).sum().item())        # soil + glacier columns
 
@@ -71,6 +78,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     nsample = min(nsample, ni * nj)
     pos = np.sort(r.choice(ni * nj, size=nsample, replace=False))
     tile_cols = perm.cpu().numpy().astype(np.int64)[pos]
+    tile_cols_t = torch.from_numpy(tile_cols).to(dev)
     osamp = extract(raw, tile_cols)
     lon_s = lon.reshape(-1)[tile_cols][None].copy()
     pos_t = torch.from_numpy(pos).to(dev)
@@ -83,6 +91,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
 
     # ---- device run: record evaluation (torch) and the engine's kernels share one stream, so they are ordered
     snaps = {}
+    resorts, stale_seen = 0, []
     ts = torch.cuda.Stream(device=dev)
     sp = ts.cuda_stream
     torch.cuda.synchronize()
@@ -104,9 +113,21 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
                 kernel_ms += st.kernel_ms
                 if n + 1 in checkpoints:
                     t_hold = time.perf_counter()
-                    snaps[n + 1] = extract(d, pos)
+                    inv = torch.empty(ni * nj, dtype=torch.int64, device=dev)
+                    inv[perm.long()] = torch.arange(ni * nj, device=dev)
+                    snaps[n + 1] = extract(d, inv[tile_cols_t].cpu().numpy())         # the sample's current sorted positions
                     ts.synchronize()
                     t0 += time.perf_counter() - t_hold                   # snapshots are not part of the run
+                if resort_every and (n + 1) % resort_every == 0 and n + 1 < nsteps:   # inside the timed run: staleness, re-sort
+                    ts.synchronize()
+                    stale = eng.sort_staleness(d)
+                    stale_seen.append(stale)
+                    if stale > resort_frac * ni * nj:
+                        perm = eng.sort_store(d)
+                        lon_d, recs = sorted_side(perm)
+                        ri2, k2 = divmod(n + 1, synth5.RECORD_HOURS)       # records are in the store's column order: evaluate them again
+                        rec_a, rec_b = (recs.at(ri2), recs.at(ri2 + 1)) if k2 else (None, None)
+                        resorts += 1
         ts.synchronize()
     wall = time.perf_counter() - t0
     restart_s = None
@@ -141,6 +162,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     isn = sorted(set(np.unique(osamp.a["isnowxy"]).tolist()))
     res = dict(options=cfgkw or {}, grid=[ni, nj], steps=nsteps, land_columns=n_land, wall_s=round(wall, 3), ms_per_step=round(wall / nsteps * 1e3, 3),
                column_steps_per_s=n_land * nsteps / wall, column_kernel_ms_per_step=round(kernel_ms / nsteps, 3),
+               resorts=resorts, stale_columns_seen=stale_seen[-3:],
                sample=nsample, sample_bit_identical=bool(ok_all), checkpoints=[c for c, _, _ in report],
                isnow_states_in_sample=isn, oracle_sample_s=round(t_or, 1),
                glacier_in_sample=int((osamp.a["ivgtyp"] == raw.cfg.isice).sum()),
@@ -157,5 +179,6 @@ if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:] if "=" not in x]
     res = run(*(a[:2] if len(a) >= 2 else (3600, 1800)), nsteps=a[2] if len(a) > 2 else 720,
               nsample=a[3] if len(a) > 3 else 4096, restart_path=os.environ.get("NMP_RESTART_PATH"),
-              cfgkw=kw or None)
+              cfgkw=kw or None, resort_frac=float(os.environ.get("NMP_RESORT_FRAC", "0.10")),
+              resort_every=int(os.environ.get("NMP_RESORT_EVERY", "24")))
     sys.exit(0 if res["sample_bit_identical"] else 1)
