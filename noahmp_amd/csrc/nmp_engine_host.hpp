@@ -27,6 +27,9 @@ struct Engine {
   int* h_counts = nullptr;               // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t own_stream = nullptr;
+  hipStream_t aux_stream = nullptr;      // land-ice / skipped class kernels beside the land kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int overlap_class_kernels = 1;
   // host-mode mirrors of the noahmp_step_args arrays (one per field of nmp_fields.inc)
   std::vector<void*> mirror;
   std::vector<size_t> mirror_bytes;

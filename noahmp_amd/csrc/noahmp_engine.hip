@@ -180,6 +180,7 @@ int noahmp_hip_set_option(const char* key, int value) {
       g.lazy_download = value;
     }
   }
+  else if (!strcmp(key, "overlap_class_kernels")) { prev = g.overlap_class_kernels; if (value == 0 || value == 1) g.overlap_class_kernels = value; }
   else if (!strcmp(key, "static_inputs")) { prev = g.static_inputs; if (value == 0 || value == 1) g.static_inputs = value; }
   else if (!strcmp(key, "deferred_status")) {
     prev = g.deferred_status;
@@ -276,11 +277,29 @@ static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false,
   // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
   if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
       g.block == 256 && g.use_lds) {
+    // The land-ice and skipped ranges are tiny next to the land range and latency-bound (a column-step takes a wave ~50 us whatever the
+    // launch size): they run on a second stream beside the land kernel -- disjoint columns -- and join before anything else follows.
+    const long n_rest = ncol - g.sorted_land;
+    const bool fork = g.overlap_class_kernels && g.sorted_land > 0 && n_rest > 0;
+    if (fork) {
+      if (!g.aux_stream) {
+        hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);
+        hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming);
+        hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming);
+      }
+      hipEventRecord(g.ev_fork, s);
+      hipStreamWaitEvent(g.aux_stream, g.ev_fork, 0);
+    }
+    hipStream_t s2 = fork ? g.aux_stream : s;
     launch_range<1>(k, 0, g.sorted_land, s);
     if (mid) hipEventRecord(mid[0], s);
-    launch_range<2>(k, g.sorted_land, g.sorted_glacier, s);
-    if (mid) hipEventRecord(mid[1], s);
-    launch_range<3>(k, g.sorted_land + g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s);
+    launch_range<2>(k, g.sorted_land, g.sorted_glacier, s2);
+    launch_range<3>(k, g.sorted_land + g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s2);
+    if (mid) hipEventRecord(mid[1], s2);        // with the fork: start of the step .. end of the land-ice + skipped kernels
+    if (fork) {
+      hipEventRecord(g.ev_join, s2);
+      hipStreamWaitEvent(s, g.ev_join, 0);
+    }
     return;
   }
   struct MidAtEnd { hipEvent_t* m; hipStream_t s; ~MidAtEnd() { if (m) { hipEventRecord(m[0], s); hipEventRecord(m[1], s); } } } at_end{mid, s};
@@ -717,10 +736,13 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
       float one = 0.f;
       hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 3]);
       ms += one;
-      for (int c = 0; c < 3; c++) {
-        one = 0.f;
-        hipEventElapsedTime(&one, g.async_events[4 * i + c], g.async_events[4 * i + c + 1]);
-        g.sync_class_ms[c] += one;
+      // land: start .. end of the land kernel.  land ice (+ skipped): they run beside the land kernel when the class kernels overlap
+      // (their end is then measured from the start of the step), behind it otherwise
+      one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 1]); g.sync_class_ms[0] += one;
+      one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + (g.overlap_class_kernels && g.aux_stream ? 0 : 1)], g.async_events[4 * i + 2]);
+      g.sync_class_ms[1] += one > 0.f ? one : 0.f;
+      if (!(g.overlap_class_kernels && g.aux_stream)) {
+        one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + 2], g.async_events[4 * i + 3]); g.sync_class_ms[2] += one;
       }
     }
     g.sync_steps = nsteps;
@@ -848,6 +870,7 @@ void noahmp_hip_finalize(void) {
   if (g.h_counts) hipHostFree(g.h_counts);
   if (g.ev0) hipEventDestroy(g.ev0);
   if (g.ev1) hipEventDestroy(g.ev1);
+  if (g.aux_stream) { hipStreamDestroy(g.aux_stream); hipEventDestroy(g.ev_fork); hipEventDestroy(g.ev_join); }
   if (g.own_stream) hipStreamDestroy(g.own_stream);
   g = nmp_host::Engine();
 }
