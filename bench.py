@@ -178,6 +178,7 @@ class Run:
         nti, ntj = geom["ite"] - geom["its"] + 1, geom["jte"] - geom["jts"] + 1
         self.tile_cells = nti * ntj
         self.gw = None
+        self.tsk_bin = None
         if self.lateral and self.sorted:
             # the groundwater planes stay in a tile-order block with the ring; the column state is the tile without it
             gwb = DeviceColumnStore.__new__(DeviceColumnStore)
@@ -212,7 +213,8 @@ class Run:
                 comm.exchange_halo([halo_store.a["isltyp"]], geom)
             self.ts.synchronize()
         if self.sorted:
-            self.sort_kw = dict(tsk_bin=args.tsk_bin, allow_lateral=True, snow_first=args.snow_first, veg=not args.no_veg_key,
+            self.tsk_bin = args.tsk_bin if args.tsk_bin is not None else (4.0 if self.lateral else 1.0)
+            self.sort_kw = dict(tsk_bin=self.tsk_bin, allow_lateral=True, snow_first=args.snow_first, veg=not args.no_veg_key,
                                 snow=not args.no_snow_key, tair=args.tair_key)
             self.perm = eng.sort_store(d, **self.sort_kw)
             self._bind_sorted()
@@ -338,7 +340,9 @@ def main():
     ap.add_argument("--ni", type=int, default=None)
     ap.add_argument("--nj", type=int, default=None)
     ap.add_argument("--dveg", type=int, default=3)
-    ap.add_argument("--tsk-bin", type=float, default=1.0, help="skin-temperature bin of the sort key [K], 0 = off")
+    ap.add_argument("--tsk-bin", type=float, default=None,
+                    help="skin-temperature bin of the sort key [K], 0 = off; default 1 K, 4 K for config 4 (coarser bins = longer runs in "
+                         "the permutations around WTABLE_mmf_noahmp: 5.40 -> 5.19 ms/step, column kernel +0.4 %%)")
     ap.add_argument("--resort-every", type=int, default=24, help="steps between staleness checks of the sorted layout (0 = never)")
     ap.add_argument("--resort-frac", type=float, default=0.10,
                     help="re-sort when this share of the columns left their bucket (measured: 11 %% stale columns cost the land kernel 0.8 %%, "
@@ -424,7 +428,7 @@ def main():
     # separately timed region of the same length; reported beside the headline, never as `value`).
     scaling_ref = None
     if world == 1 and workload == "config3" and args.workload is None and not args.no_scaling_reference:
-        summary = dict(class_ms=list(run.class_ms), n_land=run.n_land, n_adv=run.n_adv, resorts=run.resorts, stale=list(run.stale_seen),
+        summary = dict(tsk_bin=run.tsk_bin, class_ms=list(run.class_ms), n_land=run.n_land, n_adv=run.n_adv, resorts=run.resorts, stale=list(run.stale_seen),
                        sorted=run.sorted, lateral=run.lateral, tile_cells=run.tile_cells, stepwtd=run.stepwtd, kernel_ms=run.kernel_ms)
         del run
         torch.cuda.empty_cache()
@@ -455,6 +459,7 @@ def main():
         run.class_ms, run.n_land, run.n_adv, run.resorts, run.stale_seen = summary["class_ms"], summary["n_land"], summary["n_adv"], summary["resorts"], summary["stale"]
         run.sorted, run.lateral, run.tile_cells, run.stepwtd, run.kernel_ms = summary["sorted"], summary["lateral"], summary["tile_cells"], summary["stepwtd"], summary["kernel_ms"]
         run.gw_calls = 0
+        run.tsk_bin = summary["tsk_bin"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -494,7 +499,7 @@ def main():
         if run.sorted:
             desc += ("; state resident in HBM, sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature "
                      "bin), staleness check every %d steps (re-sort above %g %% stale), hourly diurnal forcing permuted per step; "
-                     "all of it inside the timed region" % (args.tsk_bin, args.resort_every, args.resort_frac * 100))
+                     "all of it inside the timed region" % (run.tsk_bin, args.resort_every, args.resort_frac * 100))
         else:
             desc += "; state resident in HBM, hourly diurnal forcing"
         out = {
