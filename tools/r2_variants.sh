@@ -3,7 +3,7 @@
 O=gpurun_out/r2_variants; mkdir -p $O
 for v in "" $(ls noahmp_amd/csrc/variants/lib_*.so 2>/dev/null); do
   tag=$(basename "${v:-default}" .so)
-  NMP_LIB=$v timeout 600 python bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 6 > $O/$tag.log 2>&1
+  NMP_LIB=$v timeout 600 python bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 6 --resort-every 0 > $O/$tag.log 2>&1
   python - "$O/$tag.log" "$tag" <<'PY'
 import json, sys
 for ln in open(sys.argv[1]):
