@@ -491,7 +491,12 @@ def main():
                                 "insts_per_column_step_wave": dv.get("valu_insts_per_column_step"),
                                 "lane_utilisation": dv.get("lane_utilisation"), "cycles_per_inst": 2, "simds": SIMDS,
                                 "clock_ghz": CLOCK_GHZ, "frac": frac,
-                                "note": "fraction of the chip's wave64 VALU issue slots the kernel's instruction count fills"}
+                                "insts_per_cycle_per_simd": dv["valu_wave_insts_per_launch"] / (SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3),
+                                "microbenchmark_insts_per_cycle_per_simd": {"independent_v_fma_f32_2_waves": 0.40, "dependent_chain_2_waves": 0.22,
+                                                                            "dependent_chain_8_waves": 0.24, "source": "tools/micro/valu_issue.hip"},
+                                "note": "fraction of the chip's wave64 VALU issue slots (one per 2 cycles and SIMD) the kernel's instruction count "
+                                        "fills; its streams are dependent chains (IEEE division: 43 SIMD cycles each; libm polynomials), which this "
+                                        "SIMD issues at 0.18-0.24 per cycle at any occupancy (profiles/r02_experiments.md 4, 4b)"}
             except Exception:
                 traffic, valu = None, None
         desc = WORKLOAD_TEXT[workload] % dict(cols=args.ni * args.nj, ni=args.ni, nj=args.nj, dveg=args.dveg, world=world,
