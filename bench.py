@@ -179,7 +179,15 @@ class Run:
         self.tile_cells = nti * ntj
         self.gw = None
         self.tsk_bin = None
+        self.pending_back = False
+        self.block_forcing = None
         if self.lateral and self.sorted:
+            # forcing arrives shaped like the rank's memory block (tile + ring), as the groundwater planes are: its permutation into
+            # the sorted working set then shares a launch with the return of the groundwater planes to sorted order
+            self.block_forcing = []
+            for h in range(24):
+                synth.diurnal_forcing(s, h, t_offset=s.t_offset)
+                self.block_forcing.append({k: torch.from_numpy(s.a[k].copy()).to(dev) for k in FKEYS})
             # the groundwater planes stay in a tile-order block with the ring; the column state is the tile without it
             gwb = DeviceColumnStore.__new__(DeviceColumnStore)
             gwb.ni, gwb.nj, gwb.cfg, gwb.device, gwb.idx = s.ni, s.nj, cfg, torch.device(dev), dict(s.idx)
@@ -199,7 +207,7 @@ class Run:
         self.forcing = []
         for h in range(24):
             synth.diurnal_forcing(s, h, t_offset=s.t_offset)
-            self.forcing.append({k: torch.from_numpy(s.a[k].copy()).to(dev) for k in FKEYS})
+            self.forcing.append(self.block_forcing[h] if self.block_forcing else {k: torch.from_numpy(s.a[k].copy()).to(dev) for k in FKEYS})
         self.d = d = s.to_device(dev)
         self.stepwtd = max(int(cfg.wtddt * 60.0 / cfg.dt + 0.5), 1)                 # hdrv:1227 NINT
         self.ts = torch.cuda.Stream(device=dev)                                     # every kernel and exchange of the run
@@ -227,12 +235,25 @@ class Run:
     def _bind_sorted(self):
         d, eng = self.d, self.eng
         self.work = {k: d.a[k] for k in FKEYS}
-        self.scat = eng.scatter([self.work[k] for k in FKEYS], [self.forcing[0][k] for k in FKEYS], self.perm, self.ni, self.nj)
+        src0 = [self.work[k] for k in FKEYS] if self.block_forcing else [self.forcing[0][k] for k in FKEYS]   # (plan only; sources are set per step)
+        self.scat = eng.scatter([self.work[k] for k in FKEYS], src0, self.perm, self.ni, self.nj)
         self.sarg = d.step_args(1, 2000, 180.0)
 
     def step(self, it):
         h = (it + 5) % 24
-        if self.sorted:
+        if self.sorted and self.gw is not None:
+            # config 4: forcing (tile order, ring-carrying block) -> sorted working set; the groundwater planes of the previous
+            # step's WTABLE call return to sorted order in the same launch
+            srt = [self.work[k] for k in FKEYS]
+            til = [self.forcing[h][k] for k in FKEYS]
+            if self.pending_back:
+                srt += [self.d.a[k] for k in GW_SHARED]
+                til += [self.gw.a[k] for k in GW_SHARED]
+                self.pending_back = False
+            self.scat.exchange(srt, til, False, self.gw.ni, self.i_off, self.j_off, self.sp)
+            self.sarg.itimestep = it
+            self.eng.noahmplsm_async(self.sarg, self.sp)
+        elif self.sorted:
             self.scat.set_sources([self.forcing[h][k] for k in FKEYS])
             self.scat(self.sp)
             self.sarg.itimestep = it
@@ -260,12 +281,18 @@ class Run:
             e1.record()
         self.halo_events.append((e0, e1))
         self.eng.wtable_mmf_async(self.wargs, self.sp)
-        if self.gw is not None:                                                      # back to sorted order
-            self.scat.exchange([self.d.a[k] for k in GW_SHARED], [self.gw.a[k] for k in GW_SHARED], False, self.gw.ni,
-                               self.i_off, self.j_off, self.sp)
+        self.pending_back = self.gw is not None        # back to sorted order: with the next step's forcing permutation, or at flush()
         self.gw_calls += 1
 
+    def flush(self):
+        """The groundwater planes of the last WTABLE call back into the sorted store (when no further step does it)."""
+        if self.pending_back:
+            self.scat.exchange([self.d.a[k] for k in GW_SHARED], [self.gw.a[k] for k in GW_SHARED], False, self.gw.ni,
+                               self.i_off, self.j_off, self.sp)
+            self.pending_back = False
+
     def collect(self):
+        self.flush()
         st, bad = self.eng.sync()                       # waits for the pending steps; tallies and kernel times summed over them
         self.kernel_ms += st.kernel_ms
         cm, _ = self.eng.sync_timing()
