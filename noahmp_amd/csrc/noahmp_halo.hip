@@ -59,7 +59,6 @@ struct Halo {
   // staging
   uint32_t* d_send = nullptr; uint32_t* d_recv = nullptr; size_t d_words = 0;
   uint32_t* h_send = nullptr; uint32_t* h_recv = nullptr; size_t h_words = 0; bool h_pinned = false;
-  void** d_planes = nullptr; int d_planes_cap = 0;
 } H;
 
 int fail(const std::string& m, int rc = -109) { g.last_error = "noahmp_hip_halo: " + m; return rc; }
@@ -132,7 +131,8 @@ struct Peer { uint32_t ip; int port; };
 
 // ---- edge packing.  An edge = `count` words of a plane starting at `first`, `stride` apart; n planes share a message.
 struct EdgeDesc { long first, stride; int count; long buf_off; };     // buf_off: word offset of plane 0's copy in the staging buffer
-struct PackArgs { void* const* planes; int n; EdgeDesc e[2]; int nedge; };
+constexpr int kMaxPlanes = 64;
+struct PackArgs { void* planes[kMaxPlanes]; int n; EdgeDesc e[2]; int nedge; };     // plane addresses travel as kernel arguments
 
 __global__ void __launch_bounds__(256) halo_pack_kernel(const PackArgs k, uint32_t* buf, int unpack) {
   const int per = k.e[0].count;                     // both edges of a phase have the same length
@@ -147,10 +147,10 @@ __global__ void __launch_bounds__(256) halo_pack_kernel(const PackArgs k, uint32
   else *slot = plane[e.first + (long)q * e.stride];
 }
 
-void host_pack(const PackArgs& k, uint32_t* buf, int unpack, void* const* planes) {
+void host_pack(const PackArgs& k, uint32_t* buf, int unpack) {
   for (int ed = 0; ed < k.nedge; ed++)
     for (int p = 0; p < k.n; p++) {
-      uint32_t* plane = (uint32_t*)planes[p];
+      uint32_t* plane = (uint32_t*)k.planes[p];
       uint32_t* slot = buf + k.e[ed].buf_off + (long)p * k.e[ed].count;
       for (int q = 0; q < k.e[ed].count; q++) {
         if (unpack) plane[k.e[ed].first + (long)q * k.e[ed].stride] = slot[q];
@@ -184,7 +184,7 @@ int ensure_staging(size_t words, bool device) {
 }
 
 // one phase: exchange edge `a` with neighbour slot na and edge `b` with slot nb_ (either may be absent)
-int phase(int n, void* const* planes, void* const* d_planes, bool device, hipStream_t s, int slot_a, const EdgeDesc& send_a,
+int phase(int n, void* const* planes, bool device, hipStream_t s, int slot_a, const EdgeDesc& send_a,
           const EdgeDesc& recv_a, int slot_b, const EdgeDesc& send_b, const EdgeDesc& recv_b) {
   const int per = send_a.count;
   if (per <= 0) return 0;
@@ -194,7 +194,8 @@ int phase(int n, void* const* planes, void* const* d_planes, bool device, hipStr
   const int slots[2] = {slot_a, slot_b};
   PackArgs pk; memset(&pk, 0, sizeof pk);
   PackArgs up; memset(&up, 0, sizeof up);
-  pk.planes = up.planes = device ? d_planes : planes; pk.n = up.n = n;
+  for (int p = 0; p < n; p++) pk.planes[p] = up.planes[p] = planes[p];
+  pk.n = up.n = n;
   const EdgeDesc snd[2] = {send_a, send_b}, rcv[2] = {recv_a, recv_b};
   long off[2] = {0, (long)n * per};
   for (int i = 0; i < 2; i++) {
@@ -205,7 +206,7 @@ int phase(int n, void* const* planes, void* const* d_planes, bool device, hipStr
   if (!pk.nedge) return 0;
   const unsigned nb = (unsigned)(((long)pk.nedge * n * per + 255) / 256);
   if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, s, pk, H.d_send, 0);
-  else host_pack(pk, H.h_send, 0, planes);
+  else host_pack(pk, H.h_send, 0);
   if (H.transport == NOAHMP_HALO_RCCL) {
     if (!device) return fail("the RCCL transport exchanges device-resident planes");
     int e = H.rccl.GroupStart();
@@ -235,7 +236,7 @@ int phase(int n, void* const* planes, void* const* d_planes, bool device, hipStr
     if (device) HIPCHK(hipMemcpyAsync(H.d_recv, H.h_recv, words * 4, hipMemcpyHostToDevice, s));
   }
   if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, s, up, H.d_recv, 1);
-  else host_pack(up, H.h_recv, 1, planes);
+  else host_pack(up, H.h_recv, 1);
   return 0;
 }
 
@@ -324,7 +325,7 @@ int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int mast
 int noahmp_hip_exchange_halo(int n, void* const* planes, const int32_t* index8, int mem, void* stream) {
   if (!H.up) return fail("noahmp_hip_halo_init has not been called");
   if (n <= 0 || H.nranks == 1) return 0;
-  if (n > 64) return fail("at most 64 planes per call");
+  if (n > kMaxPlanes) return fail("at most 64 planes per call");
   const int ims = index8[0], ime = index8[1], jms = index8[2], jme = index8[3], its = index8[4], ite = index8[5], jts = index8[6], jte = index8[7];
   const long ni = ime - ims + 1;
   const int i0 = its - ims, i1 = ite - ims, j0 = jts - jms, j1 = jte - jms;
@@ -333,25 +334,21 @@ int noahmp_hip_exchange_halo(int n, void* const* planes, const int32_t* index8, 
     return fail("the memory block (ims:ime, jms:jme) does not hold the 1-cell ring towards every neighbour", -103);
   const bool device = mem == NOAHMP_MEM_DEVICE;
   hipStream_t s = nullptr;
-  void** d_planes = nullptr;
   if (device) {
     int rc = nmp_host::ensure_init();
     if (rc) return rc;
     s = stream ? (hipStream_t)stream : g.own_stream;
-    if (H.d_planes_cap < n) { if (H.d_planes) hipFree(H.d_planes); HIPCHK(hipMalloc((void**)&H.d_planes, 64 * sizeof(void*))); H.d_planes_cap = 64; }
-    HIPCHK(hipMemcpyAsync(H.d_planes, planes, n * sizeof(void*), hipMemcpyHostToDevice, s));
-    d_planes = H.d_planes;
   }
   const int nrow = j1 - j0 + 1;
   // phase 1 (mpp_land_comlr_real): columns its / ite of the tile rows -> the neighbour's ring column
   EdgeDesc sl{(long)j0 * ni + i0, ni, nrow, 0}, rl{(long)j0 * ni + i0 - 1, ni, nrow, 0};
   EdgeDesc sr{(long)j0 * ni + i1, ni, nrow, 0}, rr{(long)j0 * ni + i1 + 1, ni, nrow, 0};
-  int rc = phase(n, planes, d_planes, device, s, 0, sl, rl, 1, sr, rr);
+  int rc = phase(n, planes, device, s, 0, sl, rl, 1, sr, rr);
   if (rc) return rc;
   // phase 2 (mpp_land_comub_real, flag 99): whole memory rows jts / jte, including the columns just received
   EdgeDesc sd{(long)j0 * ni, 1, (int)ni, 0}, rd{(long)(j0 - 1) * ni, 1, (int)ni, 0};
   EdgeDesc su{(long)j1 * ni, 1, (int)ni, 0}, ru{(long)(j1 + 1) * ni, 1, (int)ni, 0};
-  rc = phase(n, planes, d_planes, device, s, 2, sd, rd, 3, su, ru);
+  rc = phase(n, planes, device, s, 2, sd, rd, 3, su, ru);
   if (rc) return rc;
   if (device) HIPCHK(hipGetLastError());
   return 0;
@@ -394,7 +391,6 @@ int noahmp_hip_halo_finalize(void) {
   if (H.comm && H.rccl.CommDestroy) H.rccl.CommDestroy(H.comm);
   H.comm = nullptr;
   if (H.d_send) { hipFree(H.d_send); hipFree(H.d_recv); }
-  if (H.d_planes) hipFree(H.d_planes);
   if (H.h_send) { if (H.h_pinned) { hipHostFree(H.h_send); hipHostFree(H.h_recv); } else { free(H.h_send); free(H.h_recv); } }
   H = Halo();
   return 0;
