@@ -54,3 +54,14 @@ def test_gpu_config5_chain_sample_bit_identical():
     assert res["checkpoints"] == [1, 7, 24, 30]
     assert res["glacier_in_sample"] > 0 and res["water_in_sample"] > 0
     assert set(res["isnow_states_in_sample"]) >= {0, -3}
+
+
+@pytest.mark.gpu
+def test_gpu_config5_chain_with_resorts_bit_identical():
+    """The same chain with the column order re-established every 6 steps whatever the staleness (re-sort of the state, of the
+    longitude / static record fields that live in the store's column order, re-evaluation of the cached forcing records): the
+    sample, followed through every permutation, stays bit-identical to the oracle."""
+    from tools.config5_run import run
+    res = run(360, 180, nsteps=30, nsample=2048, verbose=False, checkpoints=(1, 7, 24), resort_every=6, resort_frac=-1.0)
+    assert res["sample_bit_identical"], res
+    assert res["resorts"] == 4 and res["checkpoints"] == [1, 7, 24, 30]

@@ -108,7 +108,8 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
             iday, ihour = synth5.step_time(n)
             jul = eng.forcing_prep(d, lon_d, rain_d, iday, ihour, first_step=(n == 0), stream=sp, wait=False)
             eng.noahmplsm_async(d.step_args(n + 1, 2000, jul), stream=sp)
-            if n + 1 in checkpoints or (n + 1) % 24 == 0:
+            resort_due = bool(resort_every) and (n + 1) % resort_every == 0 and n + 1 < nsteps
+            if n + 1 in checkpoints or (n + 1) % 24 == 0 or resort_due:
                 st, _ = eng.sync()
                 kernel_ms += st.kernel_ms
                 if n + 1 in checkpoints:
@@ -118,7 +119,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
                     snaps[n + 1] = extract(d, inv[tile_cols_t].cpu().numpy())         # the sample's current sorted positions
                     ts.synchronize()
                     t0 += time.perf_counter() - t_hold                   # snapshots are not part of the run
-                if resort_every and (n + 1) % resort_every == 0 and n + 1 < nsteps:   # inside the timed run: staleness, re-sort
+                if resort_due:                                         # inside the timed run: staleness, re-sort
                     ts.synchronize()
                     stale = eng.sort_staleness(d)
                     stale_seen.append(stale)
