@@ -545,6 +545,7 @@ def main():
                                                                           "tcp": "noahmp_hip_exchange_halo, socket transport"}[args.halo])
                                           if run.lateral else ", no collective"))},
             "timed_region_s": dt, "setup_s": t_setup,
+            "achieved_hbm_gbs": achieved,          # the second half of BASELINE.json's metric: algorithmic GB/s of the dominant kernel (= roofline.achieved)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "noahmp_column_kernel (%s)" % ("land range of the sorted layout" if run.sorted else "mixed tile"),
