@@ -214,7 +214,9 @@ class Run:
         self.sp = self.ts.cuda_stream
         self.reset_counters()
         halo_store = self.gw if self.gw is not None else d
+        self.halo_mover = None
         if self.lateral:
+            self.halo_mover = comm.probe_halo()                                      # agree on a working mover before the first exchange
             self.wargs = halo_store.wtable_args()
             with torch.cuda.stream(self.ts):                                         # static planes of the stencil: once
                 comm.exchange_halo([halo_store.a["fdepth"], halo_store.a["topo"]], geom)
@@ -560,7 +562,7 @@ def main():
         if run.sorted:
             out["sort"] = {"resorts_in_timed_region": run.resorts, "stale_columns_seen": run.stale_seen}
         if run.lateral:
-            out["groundwater"] = {"calls": run.gw_calls, "stepwtd": run.stepwtd,
+            out["groundwater"] = {"calls": run.gw_calls, "stepwtd": run.stepwtd, "halo_mover": getattr(run, "halo_mover", None),
                                   "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
         if scaling_ref is not None:

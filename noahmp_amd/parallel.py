@@ -44,9 +44,13 @@ class Comm:
             if backend == "nccl":
                 torch.cuda.set_device(self.device_index)
                 kw["device_id"] = torch.device("cuda", self.device_index)
-            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            import datetime
+            # a collective that never completes ends the job after 5 minutes instead of hanging a GPU box
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=5), **kw)
             self.dist = dist
             self.backend = backend
+        self.p2p_group = None          # set by probe_halo() when device send/recv does not work: host-staged edges over a gloo group
+        self.p2p_host = False
 
     # ---- tile assignment (mpp_land_partition_calc, mpp:227-288)
     def my_tile(self, global_nx, global_ny):
@@ -80,6 +84,39 @@ class Comm:
         for legs in plan:                                    # phase 1: left / right, phase 2: down / up
             self._run_phase(legs)
 
+    def probe_halo(self):
+        """One tiny send/recv round between ring neighbours with the mover exchange_halo will use, checked and AGREED on by all
+        ranks (one all_reduce) -- called once at set-up by bench.py.  If device send/recv raises or returns wrong data on any rank
+        (or NMP_HALO_FORCE_HOST=1), every rank switches to edges staged through the host over a gloo group: slower, but the run
+        completes and says so (`halo_mover`).  Returns the mover's name."""
+        if not self.dist or self.halo_lib is not None:
+            return "noahmp_hip_exchange_halo" if self.halo_lib is not None else "none"
+        import torch
+        dist = self.dist
+        dev = self._dev()
+        bad = 1.0 if os.environ.get("NMP_HALO_FORCE_HOST") == "1" else 0.0
+        if not bad and self.backend == "nccl":
+            try:
+                send = torch.full((256,), float(self.rank), device=dev)
+                recv = torch.full((256,), -1.0, device=dev)
+                nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt), dist.P2POp(dist.irecv, recv, prv)]):
+                    w.wait()
+                torch.cuda.synchronize()
+                if not bool((recv == float(prv)).all()):
+                    bad = 1.0
+            except Exception as e:                                   # noqa: BLE001  (any failure of the device mover)
+                print("noahmp_amd.parallel: device send/recv failed on rank %d (%s)" % (self.rank, e), flush=True)
+                bad = 1.0
+        flag = torch.tensor([bad], dtype=torch.float32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag.item()) > 0.0:
+            self.p2p_group = dist.new_group(backend="gloo")          # collective: every rank creates it
+            self.p2p_host = True
+            self._halo_plans = {}
+            return "torch.distributed over gloo, edges staged through the host (device send/recv unavailable)"
+        return "torch.distributed send/recv (%s)" % ("RCCL" if self.backend == "nccl" else self.backend)
+
     def _build_plan(self, planes, geom):
         """Views, persistent staging buffers and P2P descriptors of the two phases for these planes: the per-call work is then one
         copy per edge, one batch_isend_irecv per phase and one copy per received edge (the exchange is latency-bound; at 8 ranks
@@ -100,11 +137,11 @@ class Comm:
                     continue
                 for p in planes:
                     sview, rview = p[send_ix], p[recv_ix]
-                    host = self.backend == "gloo" and p.is_cuda          # gloo has no device send/recv: stage through the host
+                    host = (self.backend == "gloo" or self.p2p_host) and p.is_cuda   # gloo has no device send/recv: stage through the host
                     sbuf = sview.new_empty(sview.shape, device="cpu" if host else p.device)
                     rbuf = sbuf.new_empty(sbuf.shape)
-                    ops.append(dist.P2POp(dist.isend, sbuf, peer))
-                    ops.append(dist.P2POp(dist.irecv, rbuf, peer))
+                    ops.append(dist.P2POp(dist.isend, sbuf, peer, group=self.p2p_group))
+                    ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=self.p2p_group))
                     edges.append((sview, sbuf, rview, rbuf))
             plan.append((edges, ops))
         return plan

@@ -263,20 +263,26 @@ def _run_bench(extra, tmp, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["config4", "config3", "config4-cabi"])
-def test_bench_two_ranks_equal_one_rank(workload, tmp_path):
+@pytest.mark.parametrize("workload", ["config4", "config3", "config4-cabi", "config4-hostfallback"])
+def test_bench_two_ranks_equal_one_rank(workload, tmp_path, monkeypatch):
     """`bench.py --gpus 2` starts its two ranks itself (here both on the one GPU, ring exchange staged through the host) and
     prints n_gpus: 2; the union of the ranks' tiles equals the single-rank run of the same global grid bit for bit -- the
     config-4 groundwater step included (parity target: the single domain)."""
     extra = []
     if workload == "config4-cabi":              # the ring moved by the engine's own C-ABI exchange (socket transport, device planes)
         workload, extra = "config4", ["--halo", "tcp"]
+    if workload == "config4-hostfallback":      # the mover probe_halo() falls back to when device send/recv does not work
+        workload = "config4"
+        monkeypatch.setenv("NMP_HALO_FORCE_HOST", "1")
     one, d1 = _run_bench(["--gpus", "1", "--workload", workload], str(tmp_path), "one")
     two, d2 = _run_bench(["--gpus", "2", "--workload", workload] + extra, str(tmp_path), "two")
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     if workload == "config4":
         assert two["groundwater"]["calls"] == 5 and "ring exchange" in two["config"]["parallelism"]
         assert ("noahmp_hip_exchange_halo" in two["config"]["parallelism"]) == bool(extra)
+        assert two["groundwater"]["halo_mover"]
+        if os.environ.get("NMP_HALO_FORCE_HOST") == "1":
+            assert "staged through the host" in two["groundwater"]["halo_mover"]
     whole = np.load(d1 + ".rank0.npz")
     seen = 0
     for r in range(2):
