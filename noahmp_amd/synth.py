@@ -36,7 +36,7 @@ def diurnal_forcing(store, hour, t_offset=None, t_base=283.0, rain_hours=(10, 11
     a["v_phy"][...] = F(1.0)
     a["p8w3d"][...] = F(95000.0)
     a["dz8w"][...] = F(2.0 * cfg.zlvl)                       # hdrv:344
-    a["rainbl"][...] = F(rain_mm if (hour % 24) in rain_hours else 0.0)   # mm per step (hdrv:343)
+    a["rainbl"][...] = F(rain_mm if (int(math.floor(hour)) % 24) in rain_hours else 0.0)   # mm per step (hdrv:343)
     return cosz
 
 
@@ -248,6 +248,41 @@ def veg_snow_matrix(tables, cfg=None, seed=21):
     depth = np.array([0.0, 0.04, 0.15, 0.60], dtype=F)[np.arange(nj) % 4][:, None] * np.ones(shp, F)
     snowy = depth > 0
     tair = np.where(snowy, F(268.0), F(285.0)) + r.uniform(-2.0, 2.0, size=shp).astype(F)
+    tair[a["ivgtyp"] == cfg.isice] = np.minimum(tair[a["ivgtyp"] == cfg.isice], F(266.0))
+    s.t_offset = (tair - F(283.0)).astype(F)
+    a["tmn"][...] = (tair + F(2.0)).astype(F)
+    a["tsk"][...] = tair
+    a["snowh"][...] = depth
+    a["snow"][...] = depth * F(200.0)
+    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+        a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
+        a["smois"][:, k, :] = F(sm) + r.uniform(-0.04, 0.04, size=shp).astype(F)
+    diurnal_forcing(s, 0, t_offset=s.t_offset)
+    noahmp_init(s, tables)
+    return s
+
+
+def scalar_tile(tables, cfg=None, seed=23):
+    """Tile of the uniform-scalar sweep (tests/golden/make_golden_scalars.py): every USGS category (27 columns) x 4 rows of
+    snow depth {0, 0.04, 0.15, 0.60 m}; both hemispheres for every category (the sign of XLATIN selects PHENOLOGY's half-year
+    shift, lsm:1054-1071) in a checkerboard; soil type by column."""
+    cfg = cfg or ModelConfig()
+    r = _rng(seed)
+    ni, nj = 27, 4
+    s = _base_store(ni, nj, cfg)
+    a = s.a
+    shp = (nj, ni)
+    a["ivgtyp"][...] = np.arange(1, 28, dtype=np.int32)[None, :]
+    a["isltyp"][...] = (1 + (np.arange(ni) * 5) % 12)[None, :]
+    a["isltyp"][a["ivgtyp"] == cfg.isice] = 16
+    a["isltyp"][a["ivgtyp"] == cfg.iswater] = 14
+    a["xland"][a["ivgtyp"] == cfg.iswater] = 2.0
+    south = ((np.arange(nj)[:, None] + np.arange(ni)[None, :]) % 2) == 1
+    a["xlatin"][...] = np.where(south, F(-35.0), F(40.0))
+    a["vegfra"][...] = r.uniform(30.0, 85.0, size=shp).astype(F)
+    a["vegmax"][...] = np.maximum(a["vegfra"], F(90.0))
+    depth = np.array([0.0, 0.04, 0.15, 0.60], dtype=F)[:, None] * np.ones(shp, F)
+    tair = np.where(depth > 0, F(269.0), F(285.0)) + r.uniform(-2.0, 2.0, size=shp).astype(F)
     tair[a["ivgtyp"] == cfg.isice] = np.minimum(tair[a["ivgtyp"] == cfg.isice], F(266.0))
     s.t_offset = (tair - F(283.0)).astype(F)
     a["tmn"][...] = (tair + F(2.0)).astype(F)

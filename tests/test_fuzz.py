@@ -7,6 +7,9 @@ from tools import fuzz_parity
 
 OPTS = [dict(), dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_sfc=2, iopt_frz=2), dict(iopt_run=5, idveg=3),
         dict(iopt_rad=1, iopt_alb=1, iopt_snf=3, iopt_tbot=1, idveg=5, iopt_crs=2, iopt_btr=2, iopt_inf=2)]
+# scalars=1: DT / DZS / YR / JULIAN / DZ8W drawn per seed (fuzz_parity.draw_scalars) instead of the namelist defaults
+SCALARS = [dict(scalars=1), dict(scalars=1, idveg=4, iopt_run=3, iopt_inf=1, iopt_frz=2), dict(scalars=1, iopt_run=5)]
+SEEDS = (1, 14, 27, 32)           # dt 600 / 900 / 1800 / 3600, three DZS sets, YR 2004 / 2100 / 2001, julian 60 ... 296
 
 
 @pytest.mark.parametrize("kw", OPTS, ids=[repr(k) for k in OPTS])
@@ -24,7 +27,28 @@ def test_oracle_vs_compiled_reference_random(reflib, port, kw, tmp_path):
     assert rc == 0
 
 
+@pytest.mark.parametrize("kw", SCALARS, ids=[repr(k) for k in SCALARS])
+def test_device_source_on_host_vs_oracle_random_scalars(port, kw):
+    for seed in SEEDS:
+        assert fuzz_parity.one_seed("emul", seed, 1024, kw) == 0
+
+
+def test_oracle_vs_compiled_reference_random_scalars(reflib, port):
+    import subprocess
+    import sys
+    for seed in SEEDS:
+        rc = subprocess.call([sys.executable, fuzz_parity.__file__, "ref", "1", "1024", "scalars=1", "--seed:%d" % seed])
+        assert rc == 0, seed
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", OPTS, ids=[repr(k) for k in OPTS])
 def test_gpu_vs_oracle_random(engine, port, kw):
     assert fuzz_parity.one_seed("gpu", 303, 4096, kw) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", SCALARS, ids=[repr(k) for k in SCALARS])
+def test_gpu_vs_oracle_random_scalars(engine, port, kw):
+    for seed in SEEDS:
+        assert fuzz_parity.one_seed("gpu", seed, 4096, kw) == 0

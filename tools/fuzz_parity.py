@@ -26,6 +26,7 @@ from tools.compare import exact_check  # noqa: E402
 
 F = np.float32
 NSTEPS = 3
+YR, JUL = 2000, 180.0
 SFC2_UNDEF = ("t2mvxy", "t2mbxy", "q2mvxy", "q2mbxy", "chv2xy", "chb2xy")
 
 
@@ -86,7 +87,7 @@ def clean(port, s, it0):
         t = s.copy()
         bad = None
         for it in range(it0, it0 + NSTEPS):
-            st = port.noahmplsm(t, it, 2000, 180.0)
+            st = port.noahmplsm(t, it, YR, JUL)
             if st.code:
                 bad = st.i - 1
                 codes[st.code] = codes.get(st.code, 0) + 1
@@ -109,7 +110,25 @@ def clean(port, s, it0):
     raise RuntimeError("too many fatal columns: %s" % codes)
 
 
+def draw_scalars(seed):
+    """scalars=1: the uniform scalars of the boundary (drv:51-83) drawn per seed -- DT, DZS, YR, JULIAN, DZ8W (= 2 ZLVL)."""
+    r = np.random.Generator(np.random.Philox(seed + 7919))
+    dt = float(r.choice([600.0, 900.0, 1800.0, 3600.0]))
+    dzs = [(0.1, 0.3, 0.6, 1.0), (0.05, 0.25, 0.7, 1.5), (0.07, 0.21, 0.72, 1.0)][int(r.integers(0, 3))]
+    yr = int(r.choice([2000, 2001, 2004, 2100]))
+    jul = float(np.float32(r.uniform(1.0, 366.0 if yr in (2000, 2004) else 365.0)))
+    zlvl = float(r.choice([2.0, 10.0, 30.0]))
+    return dict(dt=dt, dzs=dzs, zlvl=zlvl), yr, jul
+
+
 def one_seed(mode, seed, ncol, kw):
+    global YR, JUL
+    kw = dict(kw)
+    YR, JUL = 2000, 180.0
+    if kw.pop("scalars", 0):
+        sc, YR, JUL = draw_scalars(seed)
+        kw.update(sc)
+        print("seed %d scalars: dt %g dzs %s zlvl %g yr %d julian %.3f" % (seed, sc["dt"], sc["dzs"], sc["zlvl"], YR, JUL))
     T, tb = load_tables("usgs")
     from oracle.portlib import PortLib
     port = PortLib(autobuild=False)
@@ -148,22 +167,22 @@ def one_seed(mode, seed, ncol, kw):
         from oracle.reflib import RefLib
         other = RefLib("O0")
         other.set_tables(T)
-        step = lambda x, it: other.noahmplsm(x, it, 2000, 180.0)
+        step = lambda x, it: other.noahmplsm(x, it, YR, JUL)
     elif mode == "emul":
         from host_emul.emullib import EmulLib
         other = EmulLib()
         other.set_tables(T)
-        step = lambda x, it: other.noahmplsm(x, it, 2000, 180.0)
+        step = lambda x, it: other.noahmplsm(x, it, YR, JUL)
     else:
         import torch  # noqa: F401
         from noahmp_amd.driver import Engine
         other = Engine(T, device=0)
-        step = lambda x, it: other.noahmplsm(x, it, 2000, 180.0, check=False)
+        step = lambda x, it: other.noahmplsm(x, it, YR, JUL, check=False)
     nbad = 0
     a = s.copy()
     for it in range(1, NSTEPS + 1):
         b = a.copy()
-        port.noahmplsm(a, it, 2000, 180.0)
+        port.noahmplsm(a, it, YR, JUL)
         step(b, it)
         ok, lines = exact_check(a, b, skip=skip)
         if not ok:
