@@ -171,6 +171,45 @@ struct Parm {  // REDPRM output (lsm:9282-9335): per-column, in registers instea
   float slope, csoil, zbot, czil, kdt, frzx;
 };
 
+// ---- Exact division through a float64 reciprocal (round 3) --------------------------------------------------------------
+// The reference divides in float32 (IEEE, round to nearest even); the compiler's sequence for that costs ~50 SIMD cycles
+// (2 v_div_scale, v_rcp, 6 FMA/MUL, v_div_fmas, v_div_fixup: tools/micro/div_known.hip).  For a divisor y whose float64
+// reciprocal r = (1/y)(1 + e), |e| <= 2^-50, is at hand,
+//        RN32(x / y) == (float)((double)x * r)            for EVERY float32 x                              (12.5 cycles)
+// because (i) the product carries a relative error below 2^-50 + 2^-53 < 2^-49, and (ii) a float32 quotient X/Y (24-bit
+// integers X, Y) that is not itself representable lies at least 1/(Y 2^24) > 2^-49 |X/Y| away from every float32 rounding
+// boundary M/2^24 (M odd): |X 2^24 - M Y| is a non-zero integer.  So the float64 value and the exact quotient round to the same
+// float32; zeros keep their sign, infinities and NaNs propagate as in the division, overflow rounds to infinity in the final
+// conversion, and gradual underflow is rounded once (the only inputs that can differ are exact ties BELOW the normal range,
+// |x| < |y| 2^-126).  tests/test_libm.py sweeps all 2^32 numerators for every constant divisor used below, and all 2^32
+// divisors for rc64().
+// Where r comes from: compile-time constants (NMP_RCC: folded by the compiler), scalars uniform over the grid (Urc, filled by
+// the host: DT, the soil-layer geometry), per-column parameters (Parm: once per column-step), and run-time divisors that serve
+// three or more divisions (rc64: v_rcp_f64 + one cubic Newton step, 2^-53; ~37 cycles).
+NMP_DEV float div_rc(float x, double r) { return (float)((double)x * r); }
+#define NMP_RCC(c) (1.0 / (double)(c))
+NMP_DEV double rc64(float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double yd = (double)y;
+  const double r0 = __builtin_amdgcn_rcp(yd);            // 2^-24.4 (measured over all float32 y, tools/micro/rc64.hip)
+  const double e = __builtin_fma(-yd, r0, 1.0);
+  const double t = __builtin_fma(e, e, e);               // r0 (1 + e + e^2): error e^3 = 2^-73, then one rounding
+  return __builtin_amdgcn_div_fixup(__builtin_fma(r0, t, r0), yd, 1.0);     // y = 0, Inf, NaN as 1/y
+#else
+  return 1.0 / (double)y;
+#endif
+}
+
+// float64 reciprocals of the divisors that are uniform over the grid (host: ctx_fill_uniform)
+struct Urc {
+  double dt;             // 1 / DT
+  double dt_hfus;        // 1 / (DT*HFUS), the float32 product the reference divides by (lsm:6836, 6843)
+  double dz[NL];         // 1 / DZ(k), k = 1..4: DZ(1) = -ZSOIL(1), DZ(k) = ZSOIL(k-1) - ZSOIL(k)     (slots L(1)..L(4))
+  double dz2[NL];        // 1 / (ZSOIL(k-1) - ZSOIL(k+1)), k = 1..3, ZSOIL(0) = 0 (SRT's TEMP1, lsm:8150-8163)
+  double dzmm[NL];       // 1 / (DZ(k)*1000.)
+  double one_m_ea4;      // 1 / (1 - EXP(-4.)) (SOILWATER's FCR, lsm:7770)
+};
+
 // launch-uniform context (kernel argument, lands in SGPRs)
 struct Ctx {
   const noahmp_tables* __restrict__ T;
@@ -178,7 +217,24 @@ struct Ctx {
   float dt;
   float zsoil[NL];   // zsoil[L(1..4)], drv:392-395
   int isurban;
+  Urc u;
 };
+
+// soil-layer thickness as SOILWATER sees it (DZSNSO(1..4) after SNOWWATER rebuilt the layer geometry, lsm:6978-6994): uniform
+NMP_DEV float dz_soil(const Ctx& c, int k) { return k == 1 ? -c.zsoil[L(1)] : (c.zsoil[L(k - 1)] - c.zsoil[L(k)]); }
+
+// host: everything of Ctx that follows from dt and zsoil
+NMP_DEV void ctx_fill_uniform(Ctx& c) {
+  c.u.dt = 1.0 / (double)c.dt;
+  c.u.dt_hfus = 1.0 / (double)(c.dt * HFUS);
+  for (int k = 1; k <= NSOIL; k++) {
+    const float dz = dz_soil(c, k);
+    c.u.dz[L(k)] = 1.0 / (double)dz;
+    c.u.dzmm[L(k)] = 1.0 / (double)(dz * 1000.f);
+    if (k < NSOIL) c.u.dz2[L(k)] = 1.0 / (double)(k == 1 ? -c.zsoil[L(2)] : (c.zsoil[L(k - 1)] - c.zsoil[L(k + 1)]));
+  }
+  c.u.one_m_ea4 = 1.0 / (double)(1.0f - nmp_expf(-4.0f));
+}
 
 // per-column scalar state of one NOAHMP_SFLX call (lsm:518-543); layer arrays are separate
 struct Col {

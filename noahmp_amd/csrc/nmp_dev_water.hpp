@@ -14,6 +14,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   const noahmp_tables* T = c.T;
   const int v = s.vegtyp - 1;
   const float dt = c.dt, sfctmp = s.sfctmp, fveg = s.fveg;
+  const double rdt = c.u.dt;
   float fp = 0.0f, qintr, qdripr, qthror, qints, qdrips, qthros, qevac, qdewc, qsubc, qfroc;
   float fpice = 0.f;
   if (c.O.snf == 1) {
@@ -27,7 +28,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
     fpice = (sfctmp >= TFRZ) ? 0.f : 1.0f;
   }
   s.fpice = fpice;
-  float bdfall = nmp_min(120.f, 67.92f + 51.25f * nmp_expf((sfctmp - TFRZ) / 2.59f));
+  float bdfall = nmp_min(120.f, 67.92f + 51.25f * nmp_expf(div_rc(sfctmp - TFRZ, NMP_RCC(2.59f))));
   float rain = (s.qprecc + s.qprecl) * (1.f - fpice);
   float snow = (s.qprecc + s.qprecl) * fpice;
   if (s.qprecc + s.qprecl > 0.f) fp = (s.qprecc + s.qprecl) / (10.f * s.qprecc + s.qprecl);
@@ -35,7 +36,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   float maxliq = T->ch2op[v] * vai;
   if (vai > 0.f) {
     qintr = fveg * rain * fp;
-    qintr = nmp_min(qintr, (maxliq - s.canliq) / dt * (1.f - nmp_expf(-rain * dt / maxliq)));
+    qintr = nmp_min(qintr, div_rc(maxliq - s.canliq, rdt) * (1.f - nmp_expf(-rain * dt / maxliq)));
     qintr = nmp_max(qintr, 0.f);
     qdripr = fveg * rain - qintr;
     qthror = (1.f - fveg) * rain;
@@ -43,45 +44,47 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
     qintr = 0.f; qdripr = 0.f; qthror = rain;
   }
   if (!s.frozen_canopy) {
-    s.etran = nmp_max(s.fctr / HVAP, 0.f);
-    qevac = nmp_max(s.fcev / HVAP, 0.f);
-    qdewc = fabsf(nmp_min(s.fcev / HVAP, 0.f));
+    const float fcev_hvap = div_rc(s.fcev, NMP_RCC(HVAP));
+    s.etran = nmp_max(div_rc(s.fctr, NMP_RCC(HVAP)), 0.f);
+    qevac = nmp_max(fcev_hvap, 0.f);
+    qdewc = fabsf(nmp_min(fcev_hvap, 0.f));
     qsubc = 0.f; qfroc = 0.f;
   } else {
-    s.etran = nmp_max(s.fctr / HSUB, 0.f);
+    const float fcev_hsub = div_rc(s.fcev, NMP_RCC(HSUB));
+    s.etran = nmp_max(div_rc(s.fctr, NMP_RCC(HSUB)), 0.f);
     qevac = 0.f; qdewc = 0.f;
-    qsubc = nmp_max(s.fcev / HSUB, 0.f);
-    qfroc = fabsf(nmp_min(s.fcev / HSUB, 0.f));
+    qsubc = nmp_max(fcev_hsub, 0.f);
+    qfroc = fabsf(nmp_min(fcev_hsub, 0.f));
   }
-  qevac = nmp_min(s.canliq / dt, qevac);
+  qevac = nmp_min(div_rc(s.canliq, rdt), qevac);
   s.canliq = nmp_max(0.f, s.canliq + (qintr + qdewc - qevac) * dt);
   if (s.canliq <= 1.E-06f) s.canliq = 0.0f;
   float maxsno = 6.6f * (0.27f + 46.f / bdfall) * vai;
   if (vai > 0.f) {
     qints = fveg * snow * fp;
-    qints = nmp_min(qints, (maxsno - s.canice) / dt * (1.f - nmp_expf(-snow * dt / maxsno)));
+    qints = nmp_min(qints, div_rc(maxsno - s.canice, rdt) * (1.f - nmp_expf(-snow * dt / maxsno)));
     qints = nmp_max(qints, 0.f);
-    float ft = nmp_max(0.0f, (s.tv - 270.15f) / 1.87E5f);
-    float fv = sqrtf(s.uu * s.uu + s.vv * s.vv) / 1.56E5f;
+    float ft = nmp_max(0.0f, div_rc(s.tv - 270.15f, NMP_RCC(1.87E5f)));
+    float fv = div_rc(sqrtf(s.uu * s.uu + s.vv * s.vv), NMP_RCC(1.56E5f));
     qdrips = nmp_max(0.f, s.canice) * (fv + ft);
     qthros = (1.0f - fveg) * snow + (fveg * snow - qints);
   } else {
     qints = 0.f; qdrips = 0.f; qthros = snow;
   }
-  qsubc = nmp_min(s.canice / dt, qsubc);
+  qsubc = nmp_min(div_rc(s.canice, rdt), qsubc);
   s.canice = nmp_max(0.f, s.canice + (qints - qdrips) * dt + (qfroc - qsubc) * dt);
   if (s.canice <= 1.E-6f) s.canice = 0.f;
   if (s.canice > 0.f) s.fwet = nmp_max(0.f, s.canice) / nmp_max(maxsno, 1.E-06f);
   else s.fwet = nmp_max(0.f, s.canliq) / nmp_max(maxliq, 1.E-06f);
   s.fwet = nmp_powf(nmp_min(s.fwet, 1.f), 0.667f);
   if (s.canice > 1.E-6f && s.tv > TFRZ) {
-    float qmeltc = nmp_min(s.canice / dt, (s.tv - TFRZ) * CICE * s.canice / DENICE / (dt * HFUS));
+    float qmeltc = nmp_min(div_rc(s.canice, rdt), div_rc(div_rc((s.tv - TFRZ) * CICE * s.canice, NMP_RCC(DENICE)), c.u.dt_hfus));
     s.canice = nmp_max(0.f, s.canice - qmeltc * dt);
     s.canliq = nmp_max(0.f, s.canliq + qmeltc * dt);
     s.tv = s.fwet * TFRZ + (1.f - s.fwet) * s.tv;
   }
   if (s.canliq > 1.E-6f && s.tv < TFRZ) {
-    float qfrzc = nmp_min(s.canliq / dt, (TFRZ - s.tv) * CWAT * s.canliq / DENH2O / (dt * HFUS));
+    float qfrzc = nmp_min(div_rc(s.canliq, rdt), div_rc(div_rc((TFRZ - s.tv) * CWAT * s.canliq, NMP_RCC(DENH2O)), c.u.dt_hfus));
     s.canliq = nmp_max(0.f, s.canliq - qfrzc * dt);
     s.canice = nmp_max(0.f, s.canice + qfrzc * dt);
     s.tv = s.fwet * TFRZ + (1.f - s.fwet) * s.tv;
@@ -280,7 +283,7 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
       float snice = y.snice[L(j)], snliq = y.snliq[L(j)], dz = y.dzsnso[L(j)];
       float wx = snice + snliq;
       float fice = snice / wx;
-      float void_ = 1.f - (snice / DENICE + snliq / DENH2O) / dz;
+      float void_ = 1.f - (div_rc(snice, NMP_RCC(DENICE)) + div_rc(snliq, NMP_RCC(DENH2O))) / dz;
       if (void_ > 0.001f && snice > 0.1f) {
         float bi = snice / dz;
         float td = nmp_max(0.f, TFRZ - y.stc[L(j)]);
@@ -288,11 +291,11 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
         float ddz1 = -C3 * dexpf, ddz3;
         if (bi > DM) ddz1 = ddz1 * nmp_expf(-46.0E-3f * (bi - DM));
         if (snliq > 0.01f * dz) ddz1 = ddz1 * C5;
-        float ddz2 = -(burden + 0.5f * wx) * nmp_expf(-0.08f * td - C2 * bi) / ETA0;
+        float ddz2 = div_rc(-(burden + 0.5f * wx) * nmp_expf(-0.08f * td - C2 * bi), NMP_RCC(ETA0));
         if (y.imelt[L(j)] == 1.f) {
           float fo = y.ficeold[L(j)];
           ddz3 = nmp_max(0.f, (fo - fice) / nmp_max(1.E-6f, fo));
-          ddz3 = -ddz3 / c.dt;
+          ddz3 = div_rc(-ddz3, c.u.dt);
         } else {
           ddz3 = 0.f;
         }
@@ -367,7 +370,7 @@ NMP_DEV void snowh2o(const Ctx& c, Col& s, const Lay<A>& y, float qsnfro, float 
       qin = qout;
     }
   }
-  s.qsnbot = qout / dt;
+  s.qsnbot = div_rc(qout, c.u.dt);
 }
 
 // Rebuild ZSNSO / DZSNSO after the snow-layer bookkeeping (lsm:6978-6994, gla:2219-2235);
@@ -431,7 +434,7 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
     snoflow = (s.sneqv - 2000.f);
     y.snice[L(0)] = y.snice[L(0)] - snoflow;
     y.dzsnso[L(0)] = y.dzsnso[L(0)] - snoflow / bdsnow;
-    snoflow = snoflow / dt;
+    snoflow = div_rc(snoflow, c.u.dt);
   }
   if (s.isnow < 0) {
     float sw = 0.f;
@@ -444,21 +447,21 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
 }
 
 // WDFCND1 lsm:8329-8362 / WDFCND2 lsm:8364-8400
-NMP_DEV void wdfcnd1(const Parm& P, float& wdf, float& wcnd, float smc, float fcr) {
-  float factr = nmp_max(0.01f, smc / P.smcmax);
+NMP_DEV void wdfcnd1(const Parm& P, double r_smcmax, float& wdf, float& wcnd, float smc, float fcr) {
+  float factr = nmp_max(0.01f, div_rc(smc, r_smcmax));
   wdf = P.dwsat * nmp_powf(factr, P.bexp + 2.0f);
   wdf = wdf * (1.0f - fcr);
   wcnd = P.dksat * nmp_powf(factr, 2.0f * P.bexp + 3.0f);
   wcnd = wcnd * (1.0f - fcr);
 }
-NMP_DEV void wdfcnd2(const Parm& P, float& wdf, float& wcnd, float smc, float sice) {
-  float factr = nmp_max(0.01f, smc / P.smcmax);
+NMP_DEV void wdfcnd2(const Parm& P, double r_smcmax, float& wdf, float& wcnd, float smc, float sice) {
+  float factr = nmp_max(0.01f, div_rc(smc, r_smcmax));
   float expon = P.bexp + 2.0f;
   wdf = P.dwsat * nmp_powf(factr, expon);
   if (sice > 0.0f) {
     float x = 500.f * sice;
     float vkwgt = 1.f / (1.f + nmp_powf(x, 3.f));
-    wdf = vkwgt * wdf + (1.f - vkwgt) * P.dwsat * nmp_powf(0.2f / P.smcmax, expon);
+    wdf = vkwgt * wdf + (1.f - vkwgt) * P.dwsat * nmp_powf(div_rc(0.2f, r_smcmax), expon);
   }
   wcnd = P.dksat * nmp_powf(factr, 2.0f * P.bexp + 3.0f);
 }
@@ -468,13 +471,15 @@ template <class A>
 NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float qinsur, float qseva,
                        const float* etrani, float& qdrain, float* wcnd, float& fcrmax) {
   const float dt = c.dt;
+  const double r_smcmax = rc64(P.smcmax);      // SMCMAX divides ~20 times below (FICE, WDFCND x 4 layers x NITER)
   float sh2o[NL], smc[NL], sice[NL], dz[NL], fcr[NL];
   float pddum = 0.0f, rsat = 0.0f, sicemax = 0.0f;
   s.runsrf = 0.0f;
   fcrmax = 0.0f;
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    sh2o[L(k)] = y.sh2o[L(k)]; smc[L(k)] = y.smc[L(k)]; sice[L(k)] = y.sice[L(k)]; dz[L(k)] = y.dzsnso[L(k)];
+    sh2o[L(k)] = y.sh2o[L(k)]; smc[L(k)] = y.smc[L(k)]; sice[L(k)] = y.sice[L(k)];
+    dz[L(k)] = dz_soil(c, k);       // = DZSNSO(k) as SNOWWATER's rebuild_layers left it: uniform, so are its reciprocals (Urc)
   }
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
@@ -485,8 +490,8 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
   const float ea4 = nmp_expf(-4.0f);
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    float fice = nmp_min(1.0f, sice[L(k)] / P.smcmax);
-    fcr[L(k)] = nmp_max(0.0f, nmp_expf(-4.0f * (1.f - fice)) - ea4) / (1.0f - ea4);
+    float fice = nmp_min(1.0f, div_rc(sice[L(k)], r_smcmax));
+    fcr[L(k)] = div_rc(nmp_max(0.0f, nmp_expf(-4.0f * (1.f - fice)) - ea4), c.u.one_m_ea4);
     if (sice[L(k)] > sicemax) sicemax = sice[L(k)];
     if (fcr[L(k)] > fcrmax) fcrmax = fcr[L(k)];
   }
@@ -561,7 +566,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       }
       infmax = infmax * fcr_;
       float wdf_, wcnd_;
-      wdfcnd2(P, wdf_, wcnd_, sh2o[L(1)], sicemax);
+      wdfcnd2(P, r_smcmax, wdf_, wcnd_, sh2o[L(1)], sicemax);
       infmax = nmp_max(infmax, wcnd_);
       infmax = nmp_min(infmax, px);
       s.runsrf = nmp_max(0.f, qinsur - infmax);
@@ -583,8 +588,8 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     float smxwtd = 0.f;
 #pragma unroll
     for (int k = 1; k <= NSOIL; k++) {
-      if (c.O.inf == 1) { wdfcnd1(P, wdf[L(k)], wcnd[L(k)], smc[L(k)], fcr[L(k)]); smx[L(k)] = smc[L(k)]; }
-      else { wdfcnd2(P, wdf[L(k)], wcnd[L(k)], sh2o[L(k)], sicemax); smx[L(k)] = sh2o[L(k)]; }
+      if (c.O.inf == 1) { wdfcnd1(P, r_smcmax, wdf[L(k)], wcnd[L(k)], smc[L(k)], fcr[L(k)]); smx[L(k)] = smc[L(k)]; }
+      else { wdfcnd2(P, r_smcmax, wdf[L(k)], wcnd[L(k)], sh2o[L(k)], sicemax); smx[L(k)] = sh2o[L(k)]; }
     }
     if (c.O.run == 5) smxwtd = (c.O.inf == 1) ? s.smcwtd : s.smcwtd * sh2o[L(NSOIL)] / smc[L(NSOIL)];
 #pragma unroll
@@ -592,15 +597,13 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       float denom, wflux;
       if (k == 1) {
         denom = -c.zsoil[L(k)];
-        float temp1 = -c.zsoil[L(k + 1)];
-        ddz[L(k)] = 2.0f / temp1;
-        dsmdz[L(k)] = 2.0f * (smx[L(k)] - smx[L(k + 1)]) / temp1;
+        ddz[L(k)] = div_rc(2.0f, c.u.dz2[L(k)]);                       // TEMP1 = -ZSOIL(2)
+        dsmdz[L(k)] = div_rc(2.0f * (smx[L(k)] - smx[L(k + 1)]), c.u.dz2[L(k)]);
         wflux = wdf[L(k)] * dsmdz[L(k)] + wcnd[L(k)] - pddum + etrani[L(k)] + qseva;
       } else if (k < NSOIL) {
         denom = (c.zsoil[L(k - 1)] - c.zsoil[L(k)]);
-        float temp1 = (c.zsoil[L(k - 1)] - c.zsoil[L(k + 1)]);
-        ddz[L(k)] = 2.0f / temp1;
-        dsmdz[L(k)] = 2.0f * (smx[L(k)] - smx[L(k + 1)]) / temp1;
+        ddz[L(k)] = div_rc(2.0f, c.u.dz2[L(k)]);                       // TEMP1 = ZSOIL(k-1) - ZSOIL(k+1)
+        dsmdz[L(k)] = div_rc(2.0f * (smx[L(k)] - smx[L(k + 1)]), c.u.dz2[L(k)]);
         wflux = wdf[L(k)] * dsmdz[L(k)] + wcnd[L(k)] - wdf[L(k - 1)] * dsmdz[L(k - 1)] - wcnd[L(k - 1)] +
                 etrani[L(k)];
       } else {
@@ -609,30 +612,30 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
         if (c.O.run == 3) qdrain = P.slope * wcnd[L(k)];
         if (c.O.run == 4) qdrain = (1.0f - fcrmax) * wcnd[L(k)];
         if (c.O.run == 5) {
-          float temp1 = 2.0f * denom, smxbot;
+          float smxbot;
           if (s.zwt < c.zsoil[L(NSOIL)] - denom)
             smxbot = smx[L(k)] - (smx[L(k)] - smxwtd) * denom * 2.f / (denom + c.zsoil[L(k)] - s.zwt);
           else
             smxbot = smxwtd;
-          dsmdz[L(k)] = 2.0f * (smx[L(k)] - smxbot) / temp1;
+          dsmdz[L(k)] = div_rc(2.0f * (smx[L(k)] - smxbot), 0.5 * c.u.dz[L(k)]);      // TEMP1 = 2 DENOM
           qdrain = wdf[L(k)] * dsmdz[L(k)] + wcnd[L(k)];
         }
         wflux = -(wdf[L(k - 1)] * dsmdz[L(k - 1)]) - wcnd[L(k - 1)] + etrani[L(k)] + qdrain;
       }
       if (k == 1) {
         ai[L(k)] = 0.0f;
-        bi[L(k)] = wdf[L(k)] * ddz[L(k)] / denom;
+        bi[L(k)] = div_rc(wdf[L(k)] * ddz[L(k)], c.u.dz[L(k)]);
         ci[L(k)] = -bi[L(k)];
       } else if (k < NSOIL) {
-        ai[L(k)] = -wdf[L(k - 1)] * ddz[L(k - 1)] / denom;
-        ci[L(k)] = -wdf[L(k)] * ddz[L(k)] / denom;
+        ai[L(k)] = div_rc(-wdf[L(k - 1)] * ddz[L(k - 1)], c.u.dz[L(k)]);
+        ci[L(k)] = div_rc(-wdf[L(k)] * ddz[L(k)], c.u.dz[L(k)]);
         bi[L(k)] = -(ai[L(k)] + ci[L(k)]);
       } else {
-        ai[L(k)] = -wdf[L(k - 1)] * ddz[L(k - 1)] / denom;
+        ai[L(k)] = div_rc(-wdf[L(k - 1)] * ddz[L(k - 1)], c.u.dz[L(k)]);
         ci[L(k)] = 0.0f;
         bi[L(k)] = -(ai[L(k)] + ci[L(k)]);
       }
-      rhstt[L(k)] = wflux / (-denom);
+      rhstt[L(k)] = div_rc(wflux, -c.u.dz[L(k)]);
     }
     // ---- SSTEP
     float wplus = 0.0f;
@@ -664,11 +667,11 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       if (s.zwt < c.zsoil[L(NSOIL)] - dz[L(NSOIL)]) {
         s.deeprech = s.deeprech + dtf * qdrain;
       } else {
-        s.smcwtd = s.smcwtd + dtf * qdrain / dz[L(NSOIL)];
+        s.smcwtd = s.smcwtd + div_rc(dtf * qdrain, c.u.dz[L(NSOIL)]);
         wplus = nmp_max((s.smcwtd - P.smcmax), 0.0f) * dz[L(NSOIL)];
         float wminus = nmp_max((1.E-4f - s.smcwtd), 0.0f) * dz[L(NSOIL)];
         s.smcwtd = nmp_max(nmp_min(s.smcwtd, P.smcmax), 1.E-4f);
-        sh2o[L(NSOIL)] = sh2o[L(NSOIL)] + wplus / dz[L(NSOIL)];
+        sh2o[L(NSOIL)] = sh2o[L(NSOIL)] + div_rc(wplus, c.u.dz[L(NSOIL)]);
         qdrain = qdrain - wplus / dtf;
         s.deeprech = s.deeprech - wminus;
       }
@@ -678,7 +681,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       float epore = nmp_max(1.E-4f, (P.smcmax - sice[L(k)]));
       wplus = nmp_max((sh2o[L(k)] - epore), 0.0f) * dz[L(k)];
       sh2o[L(k)] = nmp_min(epore, sh2o[L(k)]);
-      sh2o[L(k - 1)] = sh2o[L(k - 1)] + wplus / dz[L(k - 1)];
+      sh2o[L(k - 1)] = sh2o[L(k - 1)] + div_rc(wplus, c.u.dz[L(k - 1)]);
     }
     {
       float epore = nmp_max(1.E-4f, (P.smcmax - sice[L(1)]));
@@ -690,8 +693,8 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     rsat = rsat + wplus;
     qdrain_save = qdrain_save + qdrain;
   }
-  qdrain = qdrain_save / niter;
-  s.runsrf = s.runsrf * 1000.f + rsat * 1000.f / dt;
+  qdrain = (niter == 3) ? div_rc(qdrain_save, NMP_RCC(3.f)) : (niter == 6) ? div_rc(qdrain_save, NMP_RCC(6.f)) : qdrain_save;
+  s.runsrf = s.runsrf * 1000.f + div_rc(rsat * 1000.f, c.u.dt);
   qdrain = qdrain * 1000.f;
   if (c.O.run == 2) {
     float wtsub = 0.f;
@@ -700,7 +703,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
 #pragma unroll
     for (int k = 1; k <= NSOIL; k++) {
       float mh2o = s.runsub * dt * (wcnd[L(k)] * dz[L(k)]) / wtsub;
-      sh2o[L(k)] = sh2o[L(k)] - mh2o / (dz[L(k)] * 1000.f);
+      sh2o[L(k)] = sh2o[L(k)] - div_rc(mh2o, c.u.dzmm[L(k)]);
     }
   }
   if (c.O.run != 1) {
@@ -716,10 +719,10 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     }
     xs = (mliq[L(NSOIL)] < watmin) ? (watmin - mliq[L(NSOIL)]) : 0.f;
     mliq[L(NSOIL)] = mliq[L(NSOIL)] + xs;
-    s.runsub = s.runsub - xs / dt;
+    s.runsub = s.runsub - div_rc(xs, c.u.dt);
     if (c.O.run == 5) s.deeprech = s.deeprech - xs * 1.E-3f;
 #pragma unroll
-    for (int iz = 1; iz <= NSOIL; iz++) sh2o[L(iz)] = mliq[L(iz)] / (dz[L(iz)] * 1000.f);
+    for (int iz = 1; iz <= NSOIL; iz++) sh2o[L(iz)] = div_rc(mliq[L(iz)], c.u.dzmm[L(iz)]);
   }
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) { y.sh2o[L(k)] = sh2o[L(k)]; y.smc[L(k)] = smc[L(k)]; }
@@ -764,18 +767,18 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
   float wh_zwt = -s.zwt * 1.E3f;
   float wh = smpfz - zn_iwt * 1.E3f;
   float qin = -hk_iwt * (wh_zwt - wh) / ((s.zwt - zn_iwt) * 1.E3f);
-  qin = nmp_max(-10.0f / dt, nmp_min(10.f / dt, qin));
+  qin = nmp_max(div_rc(-10.0f, c.u.dt), nmp_min(div_rc(10.f, c.u.dt), qin));
   s.wt = s.wt + (qin - qdis) * dt;
   if (iwt == NSOIL) {
     s.wa = s.wa + (qin - qdis) * dt;
     s.wt = s.wa;
-    s.zwt = (-c.zsoil[L(NSOIL)] + 25.f) - s.wa / 1000.f / ROUS;
+    s.zwt = (-c.zsoil[L(NSOIL)] + 25.f) - div_rc(div_rc(s.wa, NMP_RCC(1000.f)), NMP_RCC(ROUS));
     mliq[L(NSOIL)] = mliq[L(NSOIL)] - qin * dt;
     mliq[L(NSOIL)] = mliq[L(NSOIL)] + nmp_max(0.f, (s.wa - 5000.f));
     s.wa = nmp_min(s.wa, 5000.f);
   } else {
     if (iwt == NSOIL - 1) {
-      s.zwt = -c.zsoil[L(NSOIL)] - (s.wt - ROUS * 1000 * 25.f) / (epore[L(NSOIL)]) / 1000.f;
+      s.zwt = -c.zsoil[L(NSOIL)] - div_rc((s.wt - ROUS * 1000 * 25.f) / (epore[L(NSOIL)]), NMP_RCC(1000.f));
     } else {
       float ws = 0.f;
 #pragma unroll
@@ -783,13 +786,14 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
         if (iz >= iwt + 2) ws = ws + epore[L(iz)] * dzmm[L(iz)];
       float ep = (iwt == 1) ? epore[L(2)] : epore[L(3)];
       float zs = (iwt == 1) ? c.zsoil[L(2)] : c.zsoil[L(3)];
-      s.zwt = -zs - (s.wt - ROUS * 1000.f * 25.f - ws) / (ep) / 1000.f;
+      s.zwt = -zs - div_rc((s.wt - ROUS * 1000.f * 25.f - ws) / (ep), NMP_RCC(1000.f));
     }
     float wtsub = 0.f;
 #pragma unroll
     for (int iz = 1; iz <= NSOIL; iz++) wtsub = wtsub + hk[L(iz)] * dzmm[L(iz)];
+    const double r_wtsub = rc64(wtsub);
 #pragma unroll
-    for (int iz = 1; iz <= NSOIL; iz++) mliq[L(iz)] = mliq[L(iz)] - qdis * dt * hk[L(iz)] * dzmm[L(iz)] / wtsub;
+    for (int iz = 1; iz <= NSOIL; iz++) mliq[L(iz)] = mliq[L(iz)] - div_rc(qdis * dt * hk[L(iz)] * dzmm[L(iz)], r_wtsub);
   }
   s.zwt = nmp_max(1.5f, s.zwt);
   float xs;
@@ -805,7 +809,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
   s.wa = s.wa - xs;
   s.wt = s.wt - xs;
 #pragma unroll
-  for (int iz = 1; iz <= NSOIL; iz++) y.sh2o[L(iz)] = mliq[L(iz)] / dzmm[L(iz)];
+  for (int iz = 1; iz <= NSOIL; iz++) y.sh2o[L(iz)] = div_rc(mliq[L(iz)], c.u.dzmm[L(iz)]);
 }
 
 // SHALLOWWATERTABLE lsm:8588-8718 (OPT_RUN = 5)
@@ -896,20 +900,20 @@ NMP_DEV void water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float q
   s.runsub = 0.f;
   canwater(c, s, qrain, snowhin);
   float qsnsub = 0.f;
-  if (s.sneqv > 0.f) qsnsub = nmp_min(qvap, s.sneqv / dt);
+  if (s.sneqv > 0.f) qsnsub = nmp_min(qvap, div_rc(s.sneqv, c.u.dt));
   float qseva = qvap - qsnsub;
   float qsnfro = 0.f;
   if (s.sneqv > 0.f) qsnfro = qdew;
   float qsdew = qdew - qsnfro;
   snowwater(c, s, y, snowhin, qsnfro, qsnsub, qrain, snoflow);
   if (s.frozen_ground) {
-    float si = y.sice[L(1)] + (qsdew - qseva) * dt / (y.dzsnso[L(1)] * 1000.f);
+    float si = y.sice[L(1)] + div_rc((qsdew - qseva) * dt, c.u.dzmm[L(1)]);     // DZSNSO(1) as rebuild_layers left it
     qsdew = 0.0f;
     qseva = 0.0f;
     if (si < 0.f) { y.sh2o[L(1)] = y.sh2o[L(1)] + si; si = 0.f; }
     y.sice[L(1)] = si;
   }
-  float qinsur = (s.ponding + s.ponding1 + s.ponding2) / dt * 0.001f;
+  float qinsur = div_rc(s.ponding + s.ponding1 + s.ponding2, c.u.dt) * 0.001f;
   if (s.isnow == 0) qinsur = qinsur + (s.qsnbot + qsdew + qrain) * 0.001f;
   else qinsur = qinsur + (s.qsnbot + qsdew) * 0.001f;
   qseva = qseva * 0.001f;

@@ -215,6 +215,7 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
   k.c.isurban = a->isurban;
   k.c.zsoil[L(1)] = -a->dzs[0];                                                    // drv:392-395
   for (int l = 2; l <= NOAHMP_NSOIL; l++) k.c.zsoil[L(l)] = -a->dzs[l - 1] + k.c.zsoil[L(l - 1)];
+  ctx_fill_uniform(k.c);
   k.err = g.d_err;
   k.counts = g.d_counts;
   k.a.dzs = nullptr;

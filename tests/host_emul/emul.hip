@@ -36,6 +36,7 @@ extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
   k.c.isurban = a->isurban;
   k.c.zsoil[L(1)] = -a->dzs[0];
   for (int l = 2; l <= NOAHMP_NSOIL; l++) k.c.zsoil[L(l)] = -a->dzs[l - 1] + k.c.zsoil[L(l - 1)];
+  ctx_fill_uniform(k.c);
   const long n = (long)k.nti * k.ntj;
   for (long t = 0; t < n; t++) {
     float base[LAY_SLOTS];
