@@ -207,6 +207,7 @@ struct Urc {
   double dz[NL];         // 1 / DZ(k), k = 1..4: DZ(1) = -ZSOIL(1), DZ(k) = ZSOIL(k-1) - ZSOIL(k)     (slots L(1)..L(4))
   double dz2[NL];        // 1 / (ZSOIL(k-1) - ZSOIL(k+1)), k = 1..3, ZSOIL(0) = 0 (SRT's TEMP1, lsm:8150-8163)
   double dzmm[NL];       // 1 / (DZ(k)*1000.)
+  double zs[NL];         // 1 / (-ZSOIL(k)): the root-zone depth ZROOT of a column whose roots reach layer k (lsm:1619, 8897)
   double one_m_ea4;      // 1 / (1 - EXP(-4.)) (SOILWATER's FCR, lsm:7770)
 };
 
@@ -231,6 +232,7 @@ NMP_DEV void ctx_fill_uniform(Ctx& c) {
     const float dz = dz_soil(c, k);
     c.u.dz[L(k)] = 1.0 / (double)dz;
     c.u.dzmm[L(k)] = 1.0 / (double)(dz * 1000.f);
+    c.u.zs[L(k)] = 1.0 / (double)(-c.zsoil[L(k)]);
     if (k < NSOIL) c.u.dz2[L(k)] = 1.0 / (double)(k == 1 ? -c.zsoil[L(2)] : (c.zsoil[L(k - 1)] - c.zsoil[L(k + 1)]));
   }
   c.u.one_m_ea4 = 1.0 / (double)(1.0f - nmp_expf(-4.0f));

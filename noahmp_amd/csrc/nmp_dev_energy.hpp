@@ -35,8 +35,8 @@ NMP_DEV float tdfcnd_thks_pow(const Parm& P) {
   float thks = nmp_powf(7.7f, P.quartz) * nmp_powf(2.0f, 1.f - P.quartz);
   return nmp_powf(thks, 1.f - P.smcmax);
 }
-NMP_DEV float tdfcnd(const Parm& P, float thks_pow, float smc, float sh2o) {
-  float satratio = smc / P.smcmax;
+NMP_DEV float tdfcnd(const Parm& P, double r_smcmax, float thks_pow, float smc, float sh2o) {
+  float satratio = div_rc(smc, r_smcmax);
   float xunfroz = sh2o / smc;
   float xu = xunfroz * P.smcmax;
   float thksat = thks_pow * nmp_powf(TKICE, P.smcmax - xu) * nmp_powf(0.57f, xu);
@@ -67,12 +67,13 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
   }
   const bool urban = (s.vegtyp == c.isurban);
   const float thks_pow = tdfcnd_thks_pow(P);
+  const double r_smcmax = rc64(P.smcmax);
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     float smc = y.smc[L(iz)], sh2o = y.sh2o[L(iz)];
     float sice = smc - sh2o;
     hcpct[L(iz)] = sh2o * CWAT + (1.0f - P.smcmax) * P.csoil + (P.smcmax - smc) * CPAIR + sice * CICE;
-    df[L(iz)] = urban ? 3.24f : tdfcnd(P, thks_pow, smc, sh2o);
+    df[L(iz)] = urban ? 3.24f : tdfcnd(P, r_smcmax, thks_pow, smc, sh2o);
   }
 #pragma unroll
   for (int iz = -2; iz <= NSOIL; iz++)
@@ -312,7 +313,8 @@ struct MoState {
 };
 
 // SFCDIF1 lsm:4061-4220
-NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, float rhoair, float h, float qair, float zlvl,
+// r_rhocp: float64 reciprocal of RHOAIR*CPAIR (the callers' loops divide by it once per iteration; div_rc, nmp_dev_common.hpp)
+NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, float qair, float zlvl,
                      float zpd, float z0m, float z0h, float ur, float mpe, MoState& m, float& cm,
                      float& ch) {
   float mozold = m.moz;
@@ -332,11 +334,12 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, float rhoair, float h, fl
     m.fv = 0.0f; m.moz = 0.0f; moz2 = 0.0f;
   } else {
     float tvir = (1.f + 0.61f * qair) * sfctmp;
-    float tmp1 = VKC * (GRAV / tvir) * h / (rhoair * CPAIR);
+    float tmp1 = div_rc(VKC * (GRAV / tvir) * h, r_rhocp);
     if (fabsf(tmp1) <= mpe) tmp1 = mpe;
     float mol = -1.f * powi3(m.fv) / tmp1;
-    m.moz = nmp_min((zlvl - zpd) / mol, 1.f);
-    moz2 = nmp_min((2.0f + z0h) / mol, 1.f);
+    const double r_mol = rc64(mol);
+    m.moz = nmp_min(div_rc(zlvl - zpd, r_mol), 1.f);
+    moz2 = nmp_min(div_rc(2.0f + z0h, r_mol), 1.f);
   }
   if (mozold * m.moz < 0.f) m.mozsgn = m.mozsgn + 1;
   if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
@@ -471,6 +474,7 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
   float vcmx = T->vcmx25[v] / (1.0f + st.vcmx_t) * fnf * btran * avcmx_pow;
   float rlb = rb / cf;
   float cihi = 1.5f * co2, cilow = 0.0f;
+  const double r_sfcprs = rc64(sfcprs);                 // divides once per bisection step
 #ifndef NMP_EXP_STOMATA_ITERS
 #define NMP_EXP_STOMATA_ITERS 20       // profiling variants only (tools): fewer bisection steps = wrong results, for timing
 #endif
@@ -479,7 +483,7 @@ NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, flo
     float ci = 0.5f * (cihi + cilow);
     float wj = nmp_max(ci - cp, 0.0f) * j / (ci + 2.0f * cp) * c3 + j * (1.f - c3);
     float wc = nmp_max(ci - cp, 0.0f) * vcmx / (ci + awc) * c3 + vcmx * (1.f - c3);
-    float we = 0.5f * vcmx * c3 + 4000.0f * vcmx * ci / sfcprs * (1.f - c3);
+    float we = 0.5f * vcmx * c3 + div_rc(4000.0f * vcmx * ci, r_sfcprs) * (1.f - c3);
     psn = nmp_min(nmp_min(wj, wc), we) * igs;
     float cs = nmp_max(co2 - 1.37f * rlb * sfcprs * psn, mpe);
     float a = mpv * psn * sfcprs * ea / (cs * ei) + bpv;
@@ -524,6 +528,7 @@ NMP_DEV void canres(const Parm& P, float par, float sfctmp, float rcsoil, float 
 struct VegIn {
   float ur, vai, gammav, gammag, laisun, laisha, cwp, zlvl, zpd, z0m, z0mg, emv, emg, rsurf, rhsur,
         parsun, parsha, df_top, dz_top, stc_top;
+  double r_rhocp, r_gammav, r_gammag;     // 1 / (RHOAIR*CPAIR), 1 / GAMMAV, 1 / GAMMAG (div_rc)
 };
 
 // ---- the canopy iteration (loop1 of VEGE_FLUX, lsm:3234-3459) as an explicit state machine ------------------
@@ -535,6 +540,7 @@ struct VegLoop {
   float sfctmp, rhoair, qair, zlvl, zpd, z0m, ur, z0mg, hcan, cwp, vaie, sqrt_dleaf_uc, fveg, tg, laisune,
         laishae, rssun, rssha, rsurf, eair, estg, gammav, air, cir, canliq, canice, latheav, sav, fwet, sfcprs,
         thair, czil;
+  double r_rhocp, r_hcan, r_gammav;     // 1 / (RHOAIR*CPAIR), 1 / HCAN, 1 / GAMMAV: divisors of every iteration (div_rc)
   // carried from iteration to iteration / read after the loop
   MoState mo;
   float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, qsfc,
@@ -554,7 +560,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   const float sfctmp = L.sfctmp, rhoair = L.rhoair, ur = L.ur, fveg = L.fveg, tg = L.tg;
   const float z0h = L.z0m, z0hg = L.z0mg, hcan = L.hcan;
   if (c.O.sfc == 1) {
-    sfcdif1(L.err, iter, sfctmp, rhoair, L.h, L.qair, L.zlvl, L.zpd, L.z0m, z0h, ur, MPE, L.mo, L.cm, L.ch);
+    sfcdif1(L.err, iter, sfctmp, L.r_rhocp, L.h, L.qair, L.zlvl, L.zpd, L.z0m, z0h, ur, MPE, L.mo, L.cm, L.ch);
   } else {
     sfcdif2(iter, L.z0m, L.tah, L.thair, ur, L.czil, L.zlvl, L.cm, L.ch, L.mo.moz, L.wstar, L.mo.fv);
     L.ch = L.ch / ur;
@@ -566,7 +572,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   {                                                   // RAGRB lsm:3960-4057
     float mozg = 0.f, fhgnew;
     if (!FIRST) {
-      float tmp1 = VKC * (GRAV / L.tah) * L.hg / (rhoair * CPAIR);
+      float tmp1 = div_rc(VKC * (GRAV / L.tah) * L.hg, L.r_rhocp);
       if (fabsf(tmp1) <= MPE) tmp1 = MPE;
       float molg = -1.f * powi3(L.mo.fv) / tmp1;
       mozg = nmp_min((L.zpd - L.z0mg) / molg, 1.f);
@@ -576,8 +582,8 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     if (FIRST) L.fhg = fhgnew;
     else L.fhg = 0.5f * (L.fhg + fhgnew);
     float cwpc = pow_half(L.cwp * L.vaie * hcan * L.fhg);
-    float tmp1 = nmp_expf(-cwpc * z0hg / hcan);
-    float tmp2 = nmp_expf(-cwpc * (z0h + L.zpd) / hcan);
+    float tmp1 = nmp_expf(div_rc(-cwpc * z0hg, L.r_hcan));
+    float tmp2 = nmp_expf(div_rc(-cwpc * (z0h + L.zpd), L.r_hcan));
     float tmprah2 = hcan * nmp_expf(cwpc) / cwpc * (tmp1 - tmp2);
     float kh = nmp_max(VKC * L.mo.fv * (hcan - L.zpd), MPE);
     L.rahg = tmprah2 / kh;
@@ -609,31 +615,35 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     }
   }
   NMP_TIC(19);   // vege loop1: stomata (first iteration only)
-  L.cah = 1.f / L.rahc;
-  L.cvh = 2.f * L.vaie / rb;
+  // RAHC, RB, RAHG and the two conductance sums each divide two or three times: one float64 reciprocal each (rc64)
+  const double r_rahc = rc64(L.rahc), r_rb = rc64(rb), r_rahg = rc64(L.rahg);
+  L.cah = div_rc(1.f, r_rahc);
+  L.cvh = div_rc(2.f * L.vaie, r_rb);
   const float cah = L.cah, cvh = L.cvh;
-  float cgh = 1.f / L.rahg;
+  float cgh = div_rc(1.f, r_rahg);
   float cond = cah + cvh + cgh;
-  float ata = (sfctmp * cah + tg * cgh) / cond;
-  float bta = cvh / cond;
+  const double r_cond = rc64(cond);
+  float ata = div_rc(sfctmp * cah + tg * cgh, r_cond);
+  float bta = div_rc(cvh, r_cond);
   float csh = (1.f - bta) * rhoair * CPAIR * cvh;
-  float caw = 1.f / rawc;
-  float cew = L.fwet * L.vaie / rb;
+  float caw = cah;                                    // 1 / RAWC, RAWC = RAHC (lsm:3325)
+  float cew = div_rc(L.fwet * L.vaie, r_rb);
   float ctw = (1.f - L.fwet) * (L.laisune / (rb + L.rssun) + L.laishae / (rb + L.rssha));
   float cgw = 1.f / (rawg + L.rsurf);
   cond = caw + cew + ctw + cgw;
-  float aea = (L.eair * caw + L.estg * cgw) / cond;
-  float bea = (cew + ctw) / cond;
-  float cev = (1.f - bea) * cew * rhoair * CPAIR / L.gammav;
-  float ctr = (1.f - bea) * ctw * rhoair * CPAIR / L.gammav;
+  const double r_cond2 = rc64(cond);
+  float aea = div_rc(L.eair * caw + L.estg * cgw, r_cond2);
+  float bea = div_rc(cew + ctw, r_cond2);
+  float cev = div_rc((1.f - bea) * cew * rhoair * CPAIR, L.r_gammav);
+  float ctr = div_rc((1.f - bea) * ctw * rhoair * CPAIR, L.r_gammav);
   L.tah = ata + bta * L.tv;
   L.eah = aea + bea * estv;
   L.irc = fveg * (L.air + L.cir * powi4(L.tv));
   L.shc = fveg * rhoair * CPAIR * cvh * (L.tv - L.tah);
-  L.evc = fveg * rhoair * CPAIR * cew * (estv - L.eah) / L.gammav;
-  L.tr = fveg * rhoair * CPAIR * ctw * (estv - L.eah) / L.gammav;
-  if (L.tv > TFRZ) L.evc = nmp_min(L.canliq * L.latheav / c.dt, L.evc);
-  else L.evc = nmp_min(L.canice * L.latheav / c.dt, L.evc);
+  L.evc = div_rc(fveg * rhoair * CPAIR * cew * (estv - L.eah), L.r_gammav);
+  L.tr = div_rc(fveg * rhoair * CPAIR * ctw * (estv - L.eah), L.r_gammav);
+  if (L.tv > TFRZ) L.evc = nmp_min(div_rc(L.canliq * L.latheav, c.u.dt), L.evc);
+  else L.evc = nmp_min(div_rc(L.canice * L.latheav, c.u.dt), L.evc);
   float b = L.sav - L.irc - L.shc - L.evc - L.tr;
   float a = fveg * (4.f * L.cir * powi3(L.tv) + csh + (cev + ctr) * destv);
   L.dtv = b / a;
@@ -642,8 +652,8 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   L.evc = L.evc + fveg * cev * destv * L.dtv;
   L.tr = L.tr + fveg * ctr * destv * L.dtv;
   L.tv = L.tv + L.dtv;
-  L.h = rhoair * CPAIR * (L.tah - sfctmp) / L.rahc;
-  L.hg = rhoair * CPAIR * (tg - L.tah) / L.rahg;
+  L.h = div_rc(rhoair * CPAIR * (L.tah - sfctmp), r_rahc);
+  L.hg = div_rc(rhoair * CPAIR * (tg - L.tah), r_rahg);
   L.qsfc = (0.622f * L.eah) / (L.sfcprs - 0.378f * L.eah);
   NMP_TIC(20);   // vege loop1: flux solve
   NMP_CNT(7);    // (host-emulation instrumentation) loop1 iterations
@@ -685,13 +695,16 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.fwet = s.fwet; L.sfcprs = s.sfcprs; L.thair = s.thair; L.czil = P.czil;
     L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
     L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
-    L.vaie = nmp_min(6.f, q.vai / fveg);
-    L.laisune = nmp_min(6.f, q.laisun / fveg);
-    L.laishae = nmp_min(6.f, q.laisha / fveg);
+    L.r_rhocp = q.r_rhocp; L.r_gammav = q.r_gammav;
+    const double r_fveg = rc64(fveg);
+    L.vaie = nmp_min(6.f, div_rc(q.vai, r_fveg));
+    L.laisune = nmp_min(6.f, div_rc(q.laisun, r_fveg));
+    L.laishae = nmp_min(6.f, div_rc(q.laisha, r_fveg));
     float t = tdc(L.tg), destg_unused;
     esat_sel(t, L.estg, destg_unused);
     L.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
     L.hcan = s.htop;
+    L.r_hcan = rc64(L.hcan);
     float uc = ur * nmp_logf(L.hcan / q.z0m) / nmp_logf(q.zlvl / q.z0m);
     if ((L.hcan - q.zpd) <= 0.f) raise(s, NOAHMP_ERR_HCAN_LE_ZPD);
     L.air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(L.tg);
@@ -755,8 +768,9 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     s.t2mv = tah;
     s.q2v = s.qsfc;
   } else {
-    s.t2mv = tah - (s.shg + s.shc / fveg) / (rhoair * CPAIR) * 1.f / cah2;
-    s.q2v = s.qsfc - ((s.evc + s.tr) / fveg + s.evg) / (s.latheav * rhoair) * 1.f / cah2;
+    const double r_fveg = rc64(fveg), r_cah2 = rc64(cah2);
+    s.t2mv = tah - div_rc(div_rc(s.shg + div_rc(s.shc, r_fveg), q.r_rhocp) * 1.f, r_cah2);
+    s.q2v = s.qsfc - div_rc(((div_rc(s.evc + s.tr, r_fveg) + s.evg) / (s.latheav * rhoair)) * 1.f, r_cah2);
   }
   s.chv = cah;
   s.chleaf = cvh;
@@ -778,7 +792,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
     if (c.O.sfc == 1) {
-      sfcdif1(s.err, iter, sfctmp, rhoair, h, s.qair, q.zlvl, zpdg, z0m, z0h, ur, MPE, mo, cm, ch);
+      sfcdif1(s.err, iter, sfctmp, q.r_rhocp, h, s.qair, q.zlvl, zpdg, z0m, z0h, ur, MPE, mo, cm, ch);
     } else {
       sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
       ch = ch / ur;
@@ -787,11 +801,12 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     }
     float rahb = nmp_max(1.f, 1.f / (ch * ur));
     float rawb = rahb;
-    ehb = 1.f / rahb;
+    const double r_rahb = rc64(rahb);
+    ehb = div_rc(1.f, r_rahb);
     t = tdc(tgb);
     esat_sel(t, estg, destg);
-    csh = rhoair * CPAIR / rahb;
-    cev = rhoair * CPAIR / gamma / (q.rsurf + rawb);
+    csh = div_rc(rhoair * CPAIR, r_rahb);
+    cev = div_rc(rhoair * CPAIR, q.r_gammag) / (q.rsurf + rawb);
     s.irb = cir * powi4(tgb) - q.emg * s.lwdn;
     s.shb = csh * (tgb - sfctmp);
     s.evb = cev * (estg * q.rhsur - s.eair);
@@ -824,7 +839,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     s.t2mb = tgb;
     s.q2b = s.qsfc;
   } else {
-    s.t2mb = tgb - s.shb / (rhoair * CPAIR) * 1.f / ehb2;
+    s.t2mb = tgb - div_rc(s.shb, q.r_rhocp) * 1.f / ehb2;
     s.q2b = s.qsfc - s.evb / (lathea * rhoair) * (1.f / ehb2 + q.rsurf);
   }
   if (s.vegtyp == c.isurban) s.q2b = s.qsfc;
@@ -852,14 +867,16 @@ NMP_DEV void tsnosoi(const Ctx& c, const Parm& P, const Col& s, const Lay<A>& y,
       if (k == ntop) {
         denom = -zs[L(k)] * hcpct[L(k)];
         float temp1 = -zs[L(kp)];
-        ddz[L(k)] = 2.0f / temp1;
-        dtsdz[L(k)] = 2.0f * (tt[L(k)] - tt[L(kp)]) / temp1;
+        const double r_temp1 = rc64(temp1);
+        ddz[L(k)] = div_rc(2.0f, r_temp1);
+        dtsdz[L(k)] = div_rc(2.0f * (tt[L(k)] - tt[L(kp)]), r_temp1);
         eflux = df[L(k)] * dtsdz[L(k)] - s.ssoil - 0.f;
       } else if (k < NSOIL) {
         denom = (zs[L(km)] - zs[L(k)]) * hcpct[L(k)];
         float temp1 = zs[L(km)] - zs[L(kp)];
-        ddz[L(k)] = 2.0f / temp1;
-        dtsdz[L(k)] = 2.0f * (tt[L(k)] - tt[L(kp)]) / temp1;
+        const double r_temp1 = rc64(temp1);
+        ddz[L(k)] = div_rc(2.0f, r_temp1);
+        dtsdz[L(k)] = div_rc(2.0f * (tt[L(k)] - tt[L(kp)]), r_temp1);
         eflux = (df[L(k)] * dtsdz[L(k)] - df[L(km)] * dtsdz[L(km)]) - 0.f;
       } else {
         denom = (zs[L(km)] - zs[L(k)]) * hcpct[L(k)];
@@ -870,21 +887,22 @@ NMP_DEV void tsnosoi(const Ctx& c, const Parm& P, const Col& s, const Lay<A>& y,
         }
         eflux = (-botflx - df[L(km)] * dtsdz[L(km)]) - 0.f;
       }
+      const double r_denom = rc64(denom);
       if (k == ntop) {
         ai[L(k)] = 0.0f;
-        ci[L(k)] = -df[L(k)] * ddz[L(k)] / denom;
+        ci[L(k)] = div_rc(-df[L(k)] * ddz[L(k)], r_denom);
         if (c.O.stc == 1) bi[L(k)] = -ci[L(k)];
         else bi[L(k)] = -ci[L(k)] + df[L(k)] / (0.5f * zs[L(k)] * zs[L(k)] * hcpct[L(k)]);
       } else if (k < NSOIL) {
-        ai[L(k)] = -df[L(km)] * ddz[L(km)] / denom;
-        ci[L(k)] = -df[L(k)] * ddz[L(k)] / denom;
+        ai[L(k)] = div_rc(-df[L(km)] * ddz[L(km)], r_denom);
+        ci[L(k)] = div_rc(-df[L(k)] * ddz[L(k)], r_denom);
         bi[L(k)] = -(ai[L(k)] + ci[L(k)]);
       } else {
-        ai[L(k)] = -df[L(km)] * ddz[L(km)] / denom;
+        ai[L(k)] = div_rc(-df[L(km)] * ddz[L(km)], r_denom);
         ci[L(k)] = 0.0f;
         bi[L(k)] = -(ai[L(k)] + ci[L(k)]);
       }
-      rhsts[L(k)] = eflux / (-denom);
+      rhsts[L(k)] = div_rc(eflux, -r_denom);
       // HSTEP scaling
       rhsts[L(k)] = rhsts[L(k)] * dt;
       ai[L(k)] = ai[L(k)] * dt;
@@ -1004,7 +1022,7 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
       }
       if (imelt[L(j)] == 1 && hm[L(j)] < 0.f) { hm[L(j)] = 0.f; imelt[L(j)] = 0; }
       if (imelt[L(j)] == 2 && hm[L(j)] > 0.f) { hm[L(j)] = 0.f; imelt[L(j)] = 0; }
-      xm[L(j)] = hm[L(j)] * dt / HFUS;
+      xm[L(j)] = div_rc(hm[L(j)] * dt, NMP_RCC(HFUS));
     }
   }
   (void)hm1; (void)xm1;
@@ -1013,10 +1031,10 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     s.sneqv = nmp_max(0.f, temp1 - xm[L(1)]);
     float propor = s.sneqv / temp1;
     s.snowh = nmp_max(0.f, propor * s.snowh);
-    float heatr = hm[L(1)] - HFUS * (temp1 - s.sneqv) / dt;
-    if (heatr > 0.f) { xm[L(1)] = heatr * dt / HFUS; hm[L(1)] = heatr; }
+    float heatr = hm[L(1)] - div_rc(HFUS * (temp1 - s.sneqv), c.u.dt);
+    if (heatr > 0.f) { xm[L(1)] = div_rc(heatr * dt, NMP_RCC(HFUS)); hm[L(1)] = heatr; }
     else { xm[L(1)] = 0.f; hm[L(1)] = 0.f; }
-    qmelt = nmp_max(0.f, (temp1 - s.sneqv)) / dt;
+    qmelt = div_rc(nmp_max(0.f, (temp1 - s.sneqv)), c.u.dt);
     ponding = temp1 - s.sneqv;
   }
 #pragma unroll
@@ -1026,7 +1044,7 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
         float heatr = 0.f;
         if (xm[L(j)] > 0.f) {
           mice[L(j)] = nmp_max(0.f, wice0[L(j)] - xm[L(j)]);
-          heatr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
+          heatr = hm[L(j)] - div_rc(HFUS * (wice0[L(j)] - mice[L(j)]), c.u.dt);
         } else if (xm[L(j)] < 0.f) {
           if (j <= 0) {
             mice[L(j)] = nmp_min(wmass0[L(j)], wice0[L(j)] - xm[L(j)]);
@@ -1038,7 +1056,7 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
               mice[L(j)] = nmp_max(mice[L(j)], 0.0f);
             }
           }
-          heatr = hm[L(j)] - HFUS * (wice0[L(j)] - mice[L(j)]) / dt;
+          heatr = hm[L(j)] - div_rc(HFUS * (wice0[L(j)] - mice[L(j)]), c.u.dt);
         }
         mliq[L(j)] = nmp_max(0.f, wmass0[L(j)] - mice[L(j)]);
         if (fabsf(heatr) > 0.f) {
@@ -1047,7 +1065,7 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
             if (mliq[L(j)] * mice[L(j)] > 0.f) stc[L(j)] = TFRZ;
           }
         }
-        if (j < 1) qmelt = qmelt + nmp_max(0.f, (wice0[L(j)] - mice[L(j)])) / dt;
+        if (j < 1) qmelt = qmelt + div_rc(nmp_max(0.f, (wice0[L(j)] - mice[L(j)])), c.u.dt);
       }
     }
   }
@@ -1061,9 +1079,9 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     if (j > isnow) { y.snliq[L(j)] = mliq[L(j)]; y.snice[L(j)] = mice[L(j)]; }
 #pragma unroll
   for (int j = 1; j <= NSOIL; j++) {
-    float dz = y.dzsnso[L(j)];
-    y.sh2o[L(j)] = mliq[L(j)] / (1000.f * dz);
-    y.smc[L(j)] = (mliq[L(j)] + mice[L(j)]) / (1000.f * dz);
+    const double r_dzmm = rc64(1000.f * y.dzsnso[L(j)]);
+    y.sh2o[L(j)] = div_rc(mliq[L(j)], r_dzmm);
+    y.smc[L(j)] = div_rc(mliq[L(j)] + mice[L(j)], r_dzmm);
   }
   s.qmelt = qmelt;
   s.ponding = ponding;
@@ -1099,7 +1117,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   s.fsno = 0.f;
   if (s.snowh > 0.f) {
     float bdsno = s.sneqv / s.snowh;
-    float fmelt = nmp_powf(bdsno / 100.f, M_MELT);
+    float fmelt = nmp_powf(div_rc(bdsno, NMP_RCC(100.f)), M_MELT);
     s.fsno = nmp_tanhf(s.snowh / (2.5f * Z0 * fmelt));
   }
   q.z0mg = Z0 * (1.0f - s.fsno) + s.fsno * Z0SNO;
@@ -1126,43 +1144,47 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   // BTRAN lsm:1617-1640
   s.btran = 0.f;
   const float zroot = -c.zsoil[L(P.nroot)];
+  const double r_zroot = c.u.zs[L(P.nroot)], r_smcmax = rc64(P.smcmax);
+  const double r_refwlt = (c.O.btr == 1) ? rc64(P.smcref - P.smcwlt) : 0.0;
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     if (iz <= P.nroot) {
       float gx, sh = y.sh2o[L(iz)];
       if (c.O.btr == 1) {
-        gx = (sh - P.smcwlt) / (P.smcref - P.smcwlt);
+        gx = div_rc(sh - P.smcwlt, r_refwlt);
       } else {
-        float psi = nmp_max(PSIWLT, -P.psisat * nmp_powf(nmp_max(0.01f, sh) / P.smcmax, -P.bexp));
+        float psi = nmp_max(PSIWLT, -P.psisat * nmp_powf(div_rc(nmp_max(0.01f, sh), r_smcmax), -P.bexp));
         if (c.O.btr == 2) gx = (1.f - psi / PSIWLT) / (1.f + P.psisat / PSIWLT);
         else gx = 1.f - nmp_expf(-5.8f * (nmp_logf(PSIWLT / psi)));
       }
       gx = nmp_min(1.f, nmp_max(0.f, gx));
-      float bt = nmp_max(MPE, y.dzsnso[L(iz)] / zroot * gx);
+      float bt = nmp_max(MPE, div_rc(y.dzsnso[L(iz)], r_zroot) * gx);
       y.btrani[L(iz)] = bt;
       s.btran = s.btran + bt;
     }
   }
   s.btran = nmp_max(MPE, s.btran);
+  const double r_btran = rc64(s.btran);
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++)
-    if (iz <= P.nroot) y.btrani[L(iz)] = y.btrani[L(iz)] / s.btran;
+    if (iz <= P.nroot) y.btrani[L(iz)] = div_rc(y.btrani[L(iz)], r_btran);
   // soil surface resistance lsm:1644-1669
   {
     float sh1 = y.sh2o[L(1)];
-    float l_rsurf = (-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - nmp_min(1.0f, sh1 / P.smcmax))) - 1.0f) /
-                    (2.71828f - 1.0f);
-    float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * nmp_powf(1.0f - P.smcwlt / P.smcmax, 2.0f + 3.0f / P.bexp);
+    float l_rsurf = div_rc((-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - nmp_min(1.0f, div_rc(sh1, r_smcmax)))) - 1.0f),
+                           NMP_RCC(2.71828f - 1.0f));
+    float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * nmp_powf(1.0f - div_rc(P.smcwlt, r_smcmax), 2.0f + 3.0f / P.bexp);
     q.rsurf = l_rsurf / d_rsurf;
     if (sh1 < 0.01f && s.snowh == 0.f) q.rsurf = 1.E6f;
-    float psi = -P.psisat * nmp_powf(nmp_max(0.01f, sh1) / P.smcmax, -P.bexp);
+    float psi = -P.psisat * nmp_powf(div_rc(nmp_max(0.01f, sh1), r_smcmax), -P.bexp);
     q.rhsur = s.fsno + (1.f - s.fsno) * nmp_expf(psi * GRAV / (RW * s.tg));
   }
   if (s.vegtyp == c.isurban && s.snowh == 0.f) q.rsurf = 1.E6f;
   if (s.tv > TFRZ) { s.latheav = HVAP; s.frozen_canopy = 0; } else { s.latheav = HSUB; s.frozen_canopy = 1; }
-  q.gammav = CPAIR * s.sfcprs / (0.622f * s.latheav);
+  q.gammav = div_rc(CPAIR * s.sfcprs, s.frozen_canopy ? NMP_RCC(0.622f * HSUB) : NMP_RCC(0.622f * HVAP));
   if (s.tg > TFRZ) { s.latheag = HVAP; s.frozen_ground = 0; } else { s.latheag = HSUB; s.frozen_ground = 1; }
-  q.gammag = CPAIR * s.sfcprs / (0.622f * s.latheag);
+  q.gammag = div_rc(CPAIR * s.sfcprs, s.frozen_ground ? NMP_RCC(0.622f * HSUB) : NMP_RCC(0.622f * HVAP));
+  q.r_rhocp = rc64(s.rhoair * CPAIR); q.r_gammav = rc64(q.gammav); q.r_gammag = rc64(q.gammag);
   q.df_top = at_top(df, s.isnow);
   q.dz_top = y.dzsnso[L(s.isnow + 1)];
   q.stc_top = y.stc[L(s.isnow + 1)];
