@@ -47,31 +47,100 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, ncol=32768, nsteps=24):
+def host_cpus():
+    """What this process may use of the host: CPUs in its affinity mask, the cgroup CPU quota (cpu.max), physical cores, SMT."""
+    info = {"logical_cpus": os.cpu_count() or 1}
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity_cpus"] = info["logical_cpus"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    info["cgroup_cpu_quota"] = quota
+    cores = set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    info["physical_cores"] = len(cores) or None
+    usable = info["affinity_cpus"]
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    info["usable_cpus"] = usable
+    return info
+
+
+def cpu_baseline(workload, ncol=16384, nsteps=12, budget_s=45.0):
     """Time the CPU path on this box's host cores: the compiled reference (oracle/_ref, -O2) when its .so travelled with the
-    repo, else the C restatement.  One process per core, each on its own `ncol`-column sample of the bench workload (same
-    generator, same class / snow mix), `nsteps` hourly steps (bounded: ~10-30 s of CPU)."""
+    repo, else the C restatement.  The reference has no threads, so the node-level figure is P independent processes,
+    each on its own `ncol`-column sample of the bench workload (same generator, same class / snow mix), `nsteps` hourly steps,
+    started together behind a barrier; rate = P x ncol x nsteps / (last end - first start).  P sweeps 1, 2, 4, ... up to the CPUs
+    this process may use (affinity mask and cgroup quota, not os.cpu_count()); the best aggregate is reported with the process
+    count that gave it, and the whole sweep beside it so that the scaling over P can be read (bounded: `budget_s` of wall clock)."""
     import multiprocessing as mp
     from oracle import reflib
     kind = "reference" if reflib.available("O2") else "port"
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    hw = host_cpus()
+    pmax = max(1, min(hw["usable_cpus"], 256))
+    counts = sorted({p for p in (1, 2, 4, 8, 16, 32, 48, 64, 96, 128, 192, 256) if p < pmax} | {pmax})
     ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(kind, workload, ncol, nsteps, r) for r in range(cores)])
-    wall = max(r[0] for r in res)
-    quiet = _cpu_worker((kind, workload, 4096, nsteps, 1000))
+    sweep = []
+    t_begin = time.perf_counter()
+    for P in counts:
+        if sweep and time.perf_counter() - t_begin > budget_s:
+            break
+        barrier = ctx.Barrier(P)
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(kind, workload, ncol, nsteps, r, barrier, q)) for r in range(P)]
+        for pr in procs:
+            pr.start()
+        res = [q.get(timeout=600) for _ in range(P)]
+        for pr in procs:
+            pr.join()
+        wall = max(r[1] for r in res) - min(r[0] for r in res)
+        per_proc = sorted(ncol * nsteps / r[2] for r in res)
+        sweep.append({"processes": P, "value": P * ncol * nsteps / wall, "per_process_median": per_proc[len(per_proc) // 2],
+                      "per_process_min": per_proc[0], "wall_s": wall})
+    best = max(sweep, key=lambda e: e["value"])
+    one = sweep[0]
     what = {"config2": "config-2", "config3": "config-3 (30 % snow, 2 % urban, 1 % land ice)",
             "config4": "config-4 (config-3 mix, OPT_RUN=5; column step only)"}[workload]
-    return {"value": cores * ncol * nsteps / wall, "unit": "column-steps/s", "cores": cores, "kind": kind,
-            "cpu_model": cpu_model(),
-            "single_core_while_all_cores_run": res[0][1], "single_core_alone": quiet[1],
-            "sample": "%d procs x %d columns x %d hourly steps of the %s workload (%s, float32), the noahmplsm call only"
-                      % (cores, ncol, nsteps, what,
+    # why P processes do not give P times one process: fewer usable CPUs than logical ones (quota / affinity), two hardware threads
+    # per core (the per-process rate halves once P exceeds the physical cores), lower clocks with all cores busy
+    return {"value": best["value"], "unit": "column-steps/s", "cores": best["processes"], "kind": kind,
+            "cpu_model": cpu_model(), "host": hw,
+            "single_process": one["value"], "per_process_at_best": best["per_process_median"],
+            "speedup_over_single_process": best["value"] / one["value"],
+            "sweep": sweep,
+            "sample": "%d processes (best of the sweep %s; CPUs usable by this process: %d of %d logical, %s physical cores, cgroup quota %s) "
+                      "x %d columns x %d hourly steps of the %s workload (%s, float32), the noahmplsm call loop"
+                      % (best["processes"], [e["processes"] for e in sweep], hw["usable_cpus"], hw["logical_cpus"], hw["physical_cores"],
+                         hw["cgroup_cpu_quota"], ncol, nsteps, what,
                          "reference Fortran flang -O2" if kind == "reference" else "C restatement gcc -O2")}
 
 
-def _cpu_worker(arg):
-    kind, workload, ncol, nsteps, r = arg
+def _cpu_worker(kind, workload, ncol, nsteps, r, barrier, q):
     from noahmp_amd import synth
     from noahmp_amd.state import ModelConfig
     from noahmp_amd.tables import load_tables
@@ -90,13 +159,21 @@ def _cpu_worker(arg):
         from oracle.portlib import PortLib
         lib = PortLib(autobuild=False)
     lib.set_tables(T)
-    dt = 0.0
+    forcing = []
+    for it in range(1, nsteps + 1):                                          # forcing prep is not timed
+        synth.diurnal_forcing(s, (2 * it + 4) % 24, t_offset=s.t_offset)    # every second hour: a whole day in 12 steps
+        forcing.append({k: s.a[k].copy() for k in FKEYS})
+    barrier.wait()
+    t0 = time.perf_counter()
+    calls = 0.0
     for it in range(1, nsteps + 1):
-        synth.diurnal_forcing(s, (it + 5) % 24, t_offset=s.t_offset)     # forcing prep is not timed
-        t0 = time.perf_counter()
-        lib.noahmplsm(s, it, 2000, 180.0)                                 # the noahmplsm call only
-        dt += time.perf_counter() - t0
-    return dt, ncol * nsteps / dt
+        for k in FKEYS:
+            s.a[k][...] = forcing[it - 1][k]
+        c0 = time.perf_counter()
+        lib.noahmplsm(s, it, 2000, 180.0)                                    # the noahmplsm call
+        calls += time.perf_counter() - c0
+    t1 = time.perf_counter()
+    q.put((t0, t1, calls))
 
 
 # ------------------------------------------------------------------------------------------------ N ranks without torchrun
