@@ -13,7 +13,10 @@ N > 1 workload (default) = BASELINE.json configs[3]: the SAME grid with OPT_RUN 
 mpp_land_partition_calc rule (mpp:227-288; 4 x 2 at N = 8), one process per GPU; every STEPWTD steps WTABLE_mmf_noahmp
 (gw:14) runs after the 1-cell ZWTXY ring has been exchanged between neighbouring ranks (RCCL send/recv over xGMI) -- the only
 data-path exchange.  Total work is fixed: STRONG scaling.  `--workload config4 --gpus 1` gives the N = 1 point of that curve,
-`--workload config3 --gpus N` the collective-free split of the N = 1 workload, `--workload config2` round 1's 1 M-column case.
+`--workload config3 --gpus N` the collective-free split of the N = 1 workload, `--workload config2` round 1's 1 M-column case,
+`--workload config5 [--gpus N]` BASELINE.json configs[4]: the global 0.1-degree grid cut into N tiles, cold start on the device, then
+forcing interpolation -> forcing preparation with CALC_DECLIN's zenith angle -> column step per hour (no collective; weak in
+nothing: the grid is fixed, STRONG scaling).  `--dt 900` runs config 4 with STEPWTD = 2 (hdrv:247-248).
 
 `python bench.py --gpus N` without a torchrun environment starts the N ranks itself (children are started before anything
 touches the GPU).  Prints ONE JSON line on rank 0 (metric contract of the driver) with `roofline` and `cpu_baseline`.
@@ -34,6 +37,11 @@ GW_BYTES_PER_CELL = 216              # gw_head_kernel 24 B + gw_c
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s spec
 SIMDS, CLOCK_GHZ = 1024, 2.4         # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz; a wave64 VALU op issues over 2 cycles
 FKEYS = ("coszin", "swdown", "glw", "t3d", "rainbl")     # what the diurnal forcing changes from hour to hour
+
+
+def forcing_hour(it, dt=3600.0):
+    """Local hour (0..23) of the synthetic diurnal forcing at 1-based step `it`: step 1 is 06:00."""
+    return int((it - 1) * dt / 3600.0 + 6.0) % 24
 
 
 # ------------------------------------------------------------------------------------------------ CPU leg
@@ -236,9 +244,9 @@ class Run:
         self.sorted = not args.no_sort
         gx, gy = args.ni, args.nj
         if workload == "config2":
-            cfg = ModelConfig(idveg=1)
+            cfg = ModelConfig(idveg=1, dt=args.dt)
         else:
-            cfg = ModelConfig(iopt_run=5 if self.lateral else 1, idveg=args.dveg)
+            cfg = ModelConfig(iopt_run=5 if self.lateral else 1, idveg=args.dveg, dt=args.dt)
         self.cfg = cfg
         geom = tile_geometry(gx, gy, comm.world, comm.rank, halo=1 if self.lateral else 0)
         self.geom = geom
@@ -319,7 +327,8 @@ class Run:
         self.sarg = d.step_args(1, 2000, 180.0)
 
     def step(self, it):
-        h = (it + 5) % 24
+        h = forcing_hour(it, self.cfg.dt)
+        self.step_hours.append(h)
         if self.sorted and self.gw is not None:
             # config 4: forcing (tile order, ring-carrying block) -> sorted working set; the groundwater planes of the previous
             # step's WTABLE call return to sorted order in the same launch
@@ -377,6 +386,9 @@ class Run:
         cm, _ = self.eng.sync_timing()
         for c in range(3):
             self.class_ms[c] += cm[c]
+        per_step = self.eng.sync_step_timing()            # land (or mixed) kernel of every step since the last sync, by forcing hour
+        for h, ms in zip(self.step_hours[len(self.step_hours) - len(per_step):], per_step):
+            self.hour_ms.setdefault(h, []).append(ms)
         self.n_adv += st.n_land + st.n_glacier
         self.n_land += st.n_land
         return st
@@ -424,6 +436,120 @@ class Run:
     def reset_counters(self):
         self.kernel_ms, self.class_ms, self.n_adv, self.n_land, self.resorts, self.stale_seen = 0.0, [0.0, 0.0, 0.0], 0, 0, 0, []
         self.halo_events, self.gw_calls = [], 0
+        self.step_hours = []
+        if not hasattr(self, "hour_ms"):
+            self.hour_ms = {}           # forcing hour -> land-kernel ms of every step at that hour (warm-up steps included)
+
+
+class Run5:
+    """One rank's share of BASELINE configs[4]: its tile of the global lat/lon grid (mpp_land_partition_calc,
+    mpp:227-288; no ring -- the columns are independent), cold start on the device (NOAHMP_INIT + SNOW_INIT, drv:847), then per
+    hourly step the chain the HRLDAS driver runs on the host (hdrv:331-415): temporal interpolation between 3-hourly forcing
+    records (netcdf_io:1369-1403), forcing preparation with CALC_DECLIN's zenith angle per cell (hdrv:336-354, 813-863) and the
+    column step -- all on device-resident arrays in the sorted layout, nothing returns to the host.  No collective."""
+
+    def __init__(self, args, comm, eng, tb, dev):
+        import torch
+        from noahmp_amd import synth5
+        from noahmp_amd.partition import tile_geometry
+        from noahmp_amd.state import ModelConfig
+        self.torch, self.args, self.comm, self.eng, self.dev, self.synth5 = torch, args, comm, eng, dev, synth5
+        self.workload, self.lateral, self.sorted = "config5", False, not args.no_sort
+        cfg = ModelConfig(idveg=1)
+        self.cfg = cfg
+        gx, gy = args.ni, args.nj
+        geom = tile_geometry(gx, gy, comm.world, comm.rank, halo=0)
+        self.geom = geom
+        nx, ny = geom["ite"] - geom["its"] + 1, geom["jte"] - geom["jts"] + 1
+        raw, lon, static = synth5.config5_tile(gx, gy, geom["its"] - 1, geom["jts"] - 1, nx, ny, cfg=cfg)
+        self.ni, self.nj, self.tile_cells = nx, ny, nx * ny
+        self.raw_host = (raw, lon, static) if args.dump else None
+        self.d = d = raw.to_device(dev)
+        self.ts = torch.cuda.Stream(device=dev)
+        self.sp = self.ts.cuda_stream
+        self.stepwtd, self.tsk_bin, self.halo_mover, self.gw = 0, None, None, None
+        t0 = time.perf_counter()
+        eng.noahmp_init(d, fndsnowh=True)                                   # cold start on the device (SURVEY 8f-3)
+        self.cold_start_s = time.perf_counter() - t0
+        self.lon_t = torch.from_numpy(lon).to(dev).reshape(-1)
+        self.static_t = {k: torch.from_numpy(v).to(dev).reshape(-1) for k, v in static.items()}
+        self.perm = None
+        if self.sorted:
+            self.tsk_bin = args.tsk_bin if args.tsk_bin is not None else 1.0
+            self.sort_kw = dict(tsk_bin=self.tsk_bin)
+            self.perm = eng.sort_store(d, **self.sort_kw)
+        self._bind()
+        self.rain = torch.zeros((ny, nx), dtype=torch.float32, device=dev)
+        self.rec_a = self.rec_b = None
+        self.reset_counters()
+
+    def _bind(self):
+        """what lives outside the store but in its column order: longitude and the static fields of the forcing records"""
+        if self.perm is not None:
+            pl = self.perm.long()
+            self.lon_d = self.lon_t[pl].reshape(self.nj, self.ni).contiguous()
+            st = {k: v[pl].reshape(self.nj, self.ni).contiguous() for k, v in self.static_t.items()}
+        else:
+            self.lon_d = self.lon_t.reshape(self.nj, self.ni)
+            st = {k: v.reshape(self.nj, self.ni) for k, v in self.static_t.items()}
+        self.recs = self.synth5.Records(self.d.a["xlatin"], self.lon_d, st)
+
+    def step(self, it):
+        n = it - 1
+        s5, eng, d = self.synth5, self.eng, self.d
+        ri, k = divmod(n, s5.RECORD_HOURS)
+        with self.torch.cuda.stream(self.ts):                               # record evaluation (torch) and the engine's kernels share one stream
+            if k == 0 or self.rec_b is None:
+                self.rec_a = self.recs.at(ri) if (self.rec_b is None or k) else self.rec_b
+                self.rec_b = self.recs.at(ri + 1)
+            eng.forcing_interpolate(d, self.rec_a, self.rec_b if k else None, 3600 * k, 3600 * s5.RECORD_HOURS, self.rain, stream=self.sp, wait=False)
+            iday, ihour = s5.step_time(n)
+            jul = eng.forcing_prep(d, self.lon_d, self.rain, iday, ihour, first_step=(n == 0), stream=self.sp, wait=False)
+            self.step_hours.append(ihour)
+            eng.noahmplsm_async(d.step_args(it, 2000, jul), stream=self.sp)
+        if self.sorted and self.args.resort_every and it % self.args.resort_every == 0:
+            self.maybe_resort(it)
+
+    def maybe_resort(self, it):
+        self.collect()
+        self.ts.synchronize()
+        stale = self.eng.sort_staleness(self.d)
+        self.stale_seen.append(stale)
+        if stale > self.args.resort_frac * self.d.ncol:
+            self.perm = self.eng.sort_store(self.d, **self.sort_kw)
+            self._bind()
+            ri, k = divmod(it, self.synth5.RECORD_HOURS)                     # records are in the store's column order: evaluate them again
+            with self.torch.cuda.stream(self.ts):
+                self.rec_a, self.rec_b = (self.recs.at(ri), self.recs.at(ri + 1)) if k else (None, None)
+            self.resorts += 1
+
+    collect = Run.collect
+    reset_counters = Run.reset_counters
+
+    def flush(self):
+        pass
+
+    def dump(self, path):
+        """The rank's INOUT / OUT arrays in tile order (tests compare decompositions and the oracle with them)."""
+        import numpy as np
+        from noahmp_amd.abi import FIELD_INFO
+        self.ts.synchronize()
+        h = self.d.to_host()
+        g = self.geom
+        inv = None
+        if self.perm is not None:
+            p = self.perm.cpu().numpy().astype(np.int64)
+            inv = np.empty_like(p)
+            inv[p] = np.arange(p.size)
+        out = {"geom": np.array([g["its"], g["ite"], g["jts"], g["jte"]])}
+        for k, v in h.a.items():
+            if k not in FIELD_INFO or FIELD_INFO[k][2] == "in" or k == "dzs":
+                continue
+            if inv is not None:
+                v = (v.transpose(1, 0, 2).reshape(v.shape[1], -1)[:, inv].reshape(v.shape[1], v.shape[0], v.shape[2]).transpose(1, 0, 2)
+                     if v.ndim == 3 else v.reshape(-1)[inv].reshape(v.shape))
+            out[k] = v
+        np.savez(path, **out)
 
 
 WORKLOAD_TEXT = {
@@ -434,6 +560,10 @@ WORKLOAD_TEXT = {
     "config4": "BASELINE configs[3]: the config-3 grid %(ni)dx%(nj)d = %(cols)d columns with OPT_RUN=5 cut into %(world)d tile(s) by "
                "mpp_land_partition_calc, WTABLE_mmf_noahmp every %(stepwtd)d step(s) after the ZWTXY ring exchange (its planes return to "
                "(i,j) order around the call)",
+    "config5": "BASELINE configs[4]: global %(ni)dx%(nj)d lat/lon grid = %(cols)d cells (3 %% open water, polar land ice, 1 %% urban, snow where "
+               "cold) cut into %(world)d tile(s) by mpp_land_partition_calc; cold start on the device (NOAHMP_INIT), then per hourly step "
+               "forcing interpolation between 3-hourly records, forcing preparation with CALC_DECLIN's zenith angle per cell and the "
+               "column step (DVEG=1, opt_run=1), all device-resident; a %(steps)d-step leg of the 30-day spin-up",
 }
 
 
@@ -442,7 +572,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--workload", choices=("config2", "config3", "config4"), default=None)
+    ap.add_argument("--workload", choices=("config2", "config3", "config4", "config5"), default=None)
+    ap.add_argument("--dt", type=float, default=3600.0, help="model time step [s]; 900 makes config 4 call WTABLE_mmf_noahmp every 2nd step "
+                    "(STEPWTD = nint(WTDDT*60/DT), hdrv:247-248); the synthetic forcing advances with it")
+    ap.add_argument("--no-config5-reference", action="store_true",
+                    help="N = 1, default workload: skip the short config-5 leg (BASELINE configs[4]) reported beside the headline")
     ap.add_argument("--ni", type=int, default=None)
     ap.add_argument("--nj", type=int, default=None)
     ap.add_argument("--dveg", type=int, default=3)
@@ -479,7 +613,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     workload = args.workload or ("config3" if world == 1 else "config4")
     if args.ni is None:
-        args.ni, args.nj = (1024, 1024) if workload == "config2" else (4608, 1536)
+        args.ni, args.nj = (1024, 1024) if workload == "config2" else ((3600, 1800) if workload == "config5" else (4608, 1536))
 
     from noahmp_amd.tables import load_tables
     T, tb = load_tables("usgs")
@@ -498,7 +632,7 @@ def main():
         eng.set_option("block", int(os.environ["NMP_BLOCK"]))
 
     t_setup = time.perf_counter()
-    run = Run(args, workload, comm, eng, tb, dev)
+    run = Run5(args, comm, eng, tb, dev) if workload == "config5" else Run(args, workload, comm, eng, tb, dev)
     t_setup = time.perf_counter() - t_setup
 
     it = 0
@@ -532,10 +666,11 @@ def main():
     # The default N > 1 workload is config 4 (the same grid with the groundwater exchange).  So that a scaling curve over
     # N = 1, 2, 4, 8 has its N = 1 point on the SAME workload, the default N = 1 run measures it too, after the headline (a second,
     # separately timed region of the same length; reported beside the headline, never as `value`).
-    scaling_ref = None
+    scaling_ref = config5_ref = None
     if world == 1 and workload == "config3" and args.workload is None and not args.no_scaling_reference:
         summary = dict(tsk_bin=run.tsk_bin, class_ms=list(run.class_ms), n_land=run.n_land, n_adv=run.n_adv, resorts=run.resorts, stale=list(run.stale_seen),
-                       sorted=run.sorted, lateral=run.lateral, tile_cells=run.tile_cells, stepwtd=run.stepwtd, kernel_ms=run.kernel_ms)
+                       sorted=run.sorted, lateral=run.lateral, tile_cells=run.tile_cells, stepwtd=run.stepwtd, kernel_ms=run.kernel_ms,
+                       hour_ms=dict(run.hour_ms))
         del run
         torch.cuda.empty_cache()
         r4 = Run(args, "config4", comm, eng, tb, dev)
@@ -558,6 +693,32 @@ def main():
                        "groundwater_calls": r4.gw_calls, "column_kernels_ms_per_step": r4.kernel_ms / args.steps}
         del r4
         torch.cuda.empty_cache()
+        if not args.no_config5_reference:
+            # BASELINE configs[4] on one GPU: a short leg of the 30-day spin-up (cold start outside the timed region, reported)
+            a5 = argparse.Namespace(**vars(args))
+            a5.ni, a5.nj, a5.dump = 3600, 1800, None
+            r5 = Run5(a5, comm, eng, tb, dev)
+            it5 = 0
+            for _ in range(args.warmup):
+                it5 += 1
+                r5.step(it5)
+            r5.collect()
+            r5.reset_counters()
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(args.steps):
+                it5 += 1
+                r5.step(it5)
+            r5.collect()
+            barrier()
+            dt5 = time.perf_counter() - t5
+            config5_ref = {"workload": WORKLOAD_TEXT["config5"] % dict(cols=3600 * 1800, ni=3600, nj=1800, world=1, steps=args.steps) +
+                           " (`--workload config5`)",
+                           "value": r5.n_adv / dt5, "unit": "column-steps/s", "ms_per_step": dt5 / args.steps * 1e3, "steps": args.steps,
+                           "columns_advanced_per_step": r5.n_adv // args.steps, "column_kernels_ms_per_step": r5.kernel_ms / args.steps,
+                           "cold_start_s": r5.cold_start_s}
+            del r5
+            torch.cuda.empty_cache()
 
         class _R:            # what the report below needs of the headline run
             pass
@@ -566,6 +727,7 @@ def main():
         run.sorted, run.lateral, run.tile_cells, run.stepwtd, run.kernel_ms = summary["sorted"], summary["lateral"], summary["tile_cells"], summary["stepwtd"], summary["kernel_ms"]
         run.gw_calls = 0
         run.tsk_bin = summary["tsk_bin"]
+        run.hour_ms = summary["hour_ms"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -582,37 +744,57 @@ def main():
         dom_ms = run.class_ms[0] / K
         dom_cols = (run.n_land if run.sorted else run.n_adv) / K       # columns one launch of that kernel advances
         achieved = ALG_BYTES_PER_COLSTEP * dom_cols / (dom_ms * 1e-3) / 1e9
-        traffic, valu = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tpath):
-            try:    # PMC counters come from separate rocprofv3 --pmc passes of this very command (tools/run_profile.sh)
+        traffic, valu, traffic_source = None, None, None
+        # PMC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this very command,
+        # tools/run_profile.sh -> tools/collect_profile.py): the newest committed summary is quoted, and only when workload and
+        # columns per launch are those of the profile
+        for tag in ("r03", "r02"):
+            tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
+            if not os.path.exists(tpath):
+                continue
+            try:
                 prof = json.load(open(tpath))
                 if prof.get("workload") == workload and prof.get("columns_per_launch") == int(dom_cols) and world == 1:
                     traffic = prof.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/%s_traffic.json (separate rocprofv3 --pmc passes of this command; not measured in this run)" % tag
+                    pm = prof.get("pmc_mean_per_launch") or {}
                     dv = prof.get("derived") or {}
-                    if dv.get("valu_wave_insts_per_launch"):
-                        # VALU-issue roofline: wave64 VALU instructions x 2 issue cycles / (SIMDs x clock x kernel time)
-                        frac = dv["valu_wave_insts_per_launch"] * 2.0 / (SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3)
-                        valu = {"bound": "valu_issue", "wave_insts_per_launch": dv["valu_wave_insts_per_launch"],
+                    if pm.get("SQ_ACTIVE_INST_VALU"):
+                        # VALU-busy roofline: SQ_ACTIVE_INST_VALU counts, per SIMD, the 4-cycle quads in which the VALU executes (a wave64
+                        # instruction occupies the 16-lane SIMD for 4 cycles; float64 / transcendental ones longer)
+                        busy = pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3)
+                        valu = {"bound": "valu_busy", "busy_quad_cycles_per_launch": pm["SQ_ACTIVE_INST_VALU"],
+                                "wave_insts_per_launch": pm.get("SQ_INSTS_VALU"),
                                 "insts_per_column_step_wave": dv.get("valu_insts_per_column_step"),
-                                "lane_utilisation": dv.get("lane_utilisation"), "cycles_per_inst": 2, "simds": SIMDS,
-                                "clock_ghz": CLOCK_GHZ, "frac": frac,
-                                "insts_per_cycle_per_simd": dv["valu_wave_insts_per_launch"] / (SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3),
-                                "microbenchmark_insts_per_cycle_per_simd": {"independent_v_fma_f32_2_waves": 0.40, "dependent_chain_2_waves": 0.22,
-                                                                            "dependent_chain_8_waves": 0.24, "source": "tools/micro/valu_issue.hip"},
-                                "note": "fraction of the chip's wave64 VALU issue slots (one per 2 cycles and SIMD) the kernel's instruction count "
-                                        "fills; its streams are dependent chains (IEEE division: 43 SIMD cycles each; libm polynomials), which this "
-                                        "SIMD issues at 0.18-0.24 per cycle at any occupancy (profiles/r02_experiments.md 4, 4b)"}
+                                "lane_utilisation": dv.get("lane_utilisation"), "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "frac": busy,
+                                "source": traffic_source,
+                                "note": "share of the kernel's duration in which the SIMDs' vector ALUs execute (SQ_ACTIVE_INST_VALU x 4 cycles / "
+                                        "(1024 SIMDs x 2.4 GHz x kernel time)); the rest is both resident waves of a SIMD waiting at once "
+                                        "(LDS look-ups of the libm tables, layer arrays, memory) -- profiles/r03_experiments.md"}
+                    break
             except Exception:
-                traffic, valu = None, None
+                traffic, valu, traffic_source = None, None, None
+        # the land kernel by forcing hour: day (COSZ > 0: hours 7..17 of the synthetic cycle) and night steps cost differently, and a
+        # timed window shorter than a day samples them unevenly -- the 24-hour mean uses every step of the run, warm-up included
+        hours = {h: sum(v) / len(v) for h, v in getattr(run, "hour_ms", {}).items() if v}
+        day = [hours[h] for h in hours if 6 < h < 18] if workload != "config5" else []
+        night = [hours[h] for h in hours if not 6 < h < 18] if workload != "config5" else []
+        ms_24h = sum(hours.values()) / 24.0 if len(hours) == 24 else None
         desc = WORKLOAD_TEXT[workload] % dict(cols=args.ni * args.nj, ni=args.ni, nj=args.nj, dveg=args.dveg, world=world,
-                                              stepwtd=run.stepwtd)
-        if run.sorted:
+                                              stepwtd=run.stepwtd, steps=K)
+        if workload == "config5":
+            desc += ("; sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature bin)" % run.tsk_bin
+                     if run.sorted else "; tile order")
+        elif run.sorted:
             desc += ("; state resident in HBM, sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature "
-                     "bin), staleness check every %d steps (re-sort above %g %% stale), hourly diurnal forcing permuted per step; "
-                     "all of it inside the timed region" % (run.tsk_bin, args.resort_every, args.resort_frac * 100))
+                     "bin); inside the timed region: the per-step permutation of the forcing (which arrives in tile order) and a staleness "
+                     "check every %d steps (a re-sort follows above %g %% stale columns: %d happened).  Forcing: the SURVEY 8d diurnal cycle, "
+                     "time step %g s, SPATIALLY UNIFORM in zenith angle / short wave / rain (the whole grid is in day or night together: no "
+                     "terminator, no precipitation fronts; per-column air-temperature offsets only) -- config 5's lat/lon-dependent zenith "
+                     "angle costs ~25 %% more per column (config5_reference)"
+                     % (run.tsk_bin, args.resort_every, args.resort_frac * 100, run.resorts, args.dt))
         else:
-            desc += "; state resident in HBM, hourly diurnal forcing"
+            desc += "; state resident in HBM, diurnal forcing (spatially uniform zenith angle / short wave / rain), time step %g s" % args.dt
         out = {
             "metric": "column-steps/sec", "value": value, "unit": "column-steps/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -629,9 +811,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "noahmp_column_kernel (%s)" % ("land range of the sorted layout" if run.sorted else "mixed tile"),
                          "kernel_ms_avg": dom_ms, "columns_per_launch": int(dom_cols),
+                         "kernel_ms_day": (sum(day) / len(day)) if day else None, "kernel_ms_night": (sum(night) / len(night)) if night else None,
+                         "kernel_ms_24h_mean": ms_24h, "hours_sampled": len(hours),
+                         "frac_24h_mean": (ALG_BYTES_PER_COLSTEP * dom_cols / (ms_24h * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_24h else None,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * int(dom_cols), "valu": valu,
-                         "note": "824 B/column-step x columns of the launch / HIP-event time of that kernel; the kernel is VALU-issue "
-                                 "and divergence bound, not HBM bound (SURVEY 8d) -- see `valu`"},
+                         "note": "824 B/column-step x columns of the launch / HIP-event time of that kernel (its own event pair per step on the "
+                                 "stream it runs on, mean over the timed steps); the kernel is bound by VALU work and by the latency of its "
+                                 "dependent chains at two waves per SIMD, not by HBM (SURVEY 8d) -- see `valu`"},
             "column_kernels_ms_per_step": {"land_or_mixed": run.class_ms[0] / K, "land_ice": run.class_ms[1] / K,
                                            "skipped": run.class_ms[2] / K, "all_max_over_ranks": kernel_ms_max / K},
             "kernel_only_column_steps_per_s": n_adv_all / (kernel_ms_max * 1e-3) if kernel_ms_max else None,
@@ -644,6 +831,10 @@ def main():
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
         if scaling_ref is not None:
             out["scaling_reference"] = scaling_ref
+        if config5_ref is not None:
+            out["config5_reference"] = config5_ref
+        if workload == "config5":
+            out["cold_start_s"] = run.cold_start_s
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -48,6 +48,10 @@ struct Engine {
   int async_nti = 1, async_its = 1, async_jts = 1;
   float sync_class_ms[3] = {0.f, 0.f, 0.f};   // noahmp_hip_sync_timing
   int sync_steps = 0;
+  std::vector<float> sync_step_ms;            // noahmp_hip_sync_step_timing: land (or mixed) kernel of each step of the last sync
+  std::vector<char> async_forked;             // per pending step: did launch_any run the land-ice / skipped kernels on the second stream?
+  bool last_launch_forked = false;
+  int deferred_code = 0;                      // fatal code of a deferred step that no call has returned yet
   // host-memory path: row-chunk pipeline H2D | kernel | D2H on three streams, optional pinning of the caller's arrays
   hipStream_t s_up = nullptr, s_dn = nullptr;
   std::vector<hipEvent_t> pipe_events;

@@ -140,6 +140,15 @@ int noahmp_hip_set_tables(const noahmp_tables* t) {
   return 0;
 }
 
+// set_option() has no channel for a status: a fatal column that a mode switch collected stays in g.deferred_code -- the next
+// noahmp_hip_step / noahmp_hip_fetch returns it -- and is named in last_error
+static void note_fetch(int rc) {
+  if (rc > 0) {
+    g.deferred_code = rc;
+    g.last_error = std::string("a fatal column of the previous (deferred) step is pending: ") + noahmp_hip_error_string(rc);
+  }
+}
+
 int noahmp_hip_set_option(const char* key, int value) {
   int prev = -1;
   if (!strcmp(key, "block")) { prev = g.block; if (value == 64 || value == 128 || value == 256) g.block = value; }
@@ -169,14 +178,14 @@ int noahmp_hip_set_option(const char* key, int value) {
   else if (!strcmp(key, "resident_state")) {
     prev = g.resident_state;
     if (value == 0 || value == 1) {
-      if (!value && g.resident_dirty) noahmp_hip_fetch(nullptr);     // leaving the mode: bring the host arrays up to date
+      if (!value && (g.resident_dirty || g.deferred_pending)) note_fetch(noahmp_hip_fetch(nullptr));     // leaving the mode: bring the host arrays up to date
       g.resident_state = value; g.resident_valid = false;
     }
   }
   else if (!strcmp(key, "lazy_download")) {
     prev = g.lazy_download;
     if (value == 0 || value == 1) {
-      if (!value && g.resident_dirty) noahmp_hip_fetch(nullptr);
+      if (!value && (g.resident_dirty || g.deferred_pending)) note_fetch(noahmp_hip_fetch(nullptr));
       g.lazy_download = value;
     }
   }
@@ -185,7 +194,7 @@ int noahmp_hip_set_option(const char* key, int value) {
   else if (!strcmp(key, "deferred_status")) {
     prev = g.deferred_status;
     if (value == 0 || value == 1) {
-      if (g.deferred_pending || g.resident_dirty) noahmp_hip_fetch(nullptr);
+      if (g.deferred_pending || g.resident_dirty) note_fetch(noahmp_hip_fetch(nullptr));
       g.deferred_status = value; g.resident_valid = false;
     }
   }
@@ -274,6 +283,7 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
 // mid: two events recorded after the land range and after the land-ice range (per-class kernel times of noahmp_hip_sync_timing)
 static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false, hipEvent_t* mid = nullptr) {
   const long ncol = (long)k.nti * k.ntj;
+  g.last_launch_forked = false;
   if (ncol <= 0) return;
   // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
   if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
@@ -282,6 +292,7 @@ static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false,
     // launch size): they run on a second stream beside the land kernel -- disjoint columns -- and join before anything else follows.
     const long n_rest = ncol - g.sorted_land;
     const bool fork = g.overlap_class_kernels && g.sorted_land > 0 && n_rest > 0;
+    g.last_launch_forked = fork;
     if (fork) {
       if (!g.aux_stream) {
         hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);
@@ -464,14 +475,20 @@ static void fill_status(const noahmp_step_args* a, int nti, noahmp_status* st, i
 }
 
 // "deferred_status": wait for the step the previous resident call left running and report it
+// The code is also kept in g.deferred_code until a call has RETURNED it to the caller (take_deferred_code): paths that collect a
+// pending step on the way to something else (set_option, a fetch with other arrays) must not drop a fatal column.
 static int resident_collect(noahmp_status* st, int* code_out) {
-  *code_out = 0;
+  *code_out = g.deferred_code;
   if (!g.deferred_pending) return 0;
   HIPCHK(hipEventSynchronize(g.ev_kdone));
   g.deferred_pending = false;
-  fill_status(&g.resident_args, g.resident_args.ite - g.resident_args.its + 1, st, code_out);
+  int code = 0;
+  fill_status(&g.resident_args, g.resident_args.ite - g.resident_args.its + 1, st, &code);
+  if (code && !g.deferred_code) g.deferred_code = code;
+  *code_out = g.deferred_code;
   return 0;
 }
+static int take_deferred_code(int code) { if (code == g.deferred_code) g.deferred_code = 0; return code; }
 
 static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_status* st) {
   KArgs k;
@@ -553,7 +570,7 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
     HIPCHK(hipEventRecord(g.ev_kdone, s));
     g.deferred_pending = true;
     HIPCHK(hipEventSynchronize(g.ev_up));
-    return prev_code;
+    return take_deferred_code(prev_code);
   }
   if (!g.lazy_download)
     for (int f = 0; f < kNumFields; f++) {
@@ -574,7 +591,10 @@ extern "C" {
 int noahmp_hip_fetch(const noahmp_step_args* a) {
   int rc = ensure_init();
   if (rc) return rc;
-  if (!g.resident_valid) { if (g.resident_dirty) { g.last_error = "noahmp_hip_fetch: no resident state"; return -108; } return 0; }
+  if (!g.resident_valid) {
+    if (g.resident_dirty) { g.last_error = "noahmp_hip_fetch: no resident state"; return -108; }
+    return take_deferred_code(g.deferred_code);          // a code a mode switch collected (note_fetch)
+  }
   int pending_code = 0;
   rc = resident_collect(nullptr, &pending_code);         // "deferred_status": the last step may still be running
   if (rc) return rc;
@@ -585,7 +605,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
         g.last_error = "noahmp_hip_fetch: these are not the arrays of the resident state";
         return -108;
       }
-  if (!g.resident_dirty) return pending_code;
+  if (!g.resident_dirty) return take_deferred_code(pending_code);
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];
     if (fd.io == 0) continue;
@@ -593,7 +613,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
   }
   HIPCHK(hipStreamSynchronize(g.own_stream));
   g.resident_dirty = false;
-  return pending_code;              // a fatal column of the step that was still running (0 = none)
+  return take_deferred_code(pending_code);              // a fatal column of the step that was still running (0 = none)
 }
 
 int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_status* st) {
@@ -605,7 +625,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   if (g.async_pending) { g.last_error = "noahmp_hip_step: asynchronous steps are pending, call noahmp_hip_sync() first"; return -106; }
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
   if (mem == NOAHMP_MEM_HOST && g.resident_state) return step_host_resident(a, s, st);
-  if (mem == NOAHMP_MEM_HOST && (g.deferred_pending || g.resident_dirty)) {
+  if (g.deferred_pending || g.resident_dirty || g.deferred_code) {        // also for DEVICE memory: d_err / h_err are shared with the running step
     rc = noahmp_hip_fetch(nullptr);                 // leaving the resident path: host arrays up to date first
     if (rc < 0) return rc;
     if (rc > 0) { if (st) st->code = rc; g.last_error = "a fatal column of the previous (deferred) step"; return rc; }   // never drop a pending fatal
@@ -706,6 +726,8 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   launch_any(k, s, true, &g.async_events[4 * g.async_pending + 1]);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(g.async_events[4 * g.async_pending + 3], s));
+  if ((int)g.async_forked.size() <= g.async_pending) g.async_forked.resize(g.async_pending + 1);
+  g.async_forked[g.async_pending] = g.last_launch_forked ? 1 : 0;
   g.async_pending++;
   g.async_stream = s;
   bool known = false;
@@ -720,7 +742,7 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
 int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   if (st) memset(st, 0, sizeof(*st));
   if (step_out) *step_out = -1;
-  if (!g.async_pending) { g.sync_steps = 0; for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f; return 0; }
+  if (!g.async_pending) { g.sync_steps = 0; g.sync_step_ms.clear(); for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f; return 0; }
   hipStream_t s = g.async_stream;
   for (hipStream_t q : g.async_streams) if (q != s) HIPCHK(hipStreamSynchronize(q));   // steps may sit on several streams
   g.async_streams.clear();
@@ -733,16 +755,19 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   if (st) {
     float ms = 0.f;
     for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f;
+    g.sync_step_ms.assign(nsteps, 0.f);
     for (int i = 0; i < nsteps; i++) {
       float one = 0.f;
       hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 3]);
       ms += one;
-      // land: start .. end of the land kernel.  land ice (+ skipped): they run beside the land kernel when the class kernels overlap
+      // land: start .. end of the land kernel.  land ice (+ skipped): they ran beside the land kernel when THIS step forked
       // (their end is then measured from the start of the step), behind it otherwise
+      const bool forked = i < (int)g.async_forked.size() && g.async_forked[i];
       one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 1]); g.sync_class_ms[0] += one;
-      one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + (g.overlap_class_kernels && g.aux_stream ? 0 : 1)], g.async_events[4 * i + 2]);
+      g.sync_step_ms[i] = one;
+      one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + (forked ? 0 : 1)], g.async_events[4 * i + 2]);
       g.sync_class_ms[1] += one > 0.f ? one : 0.f;
-      if (!(g.overlap_class_kernels && g.aux_stream)) {
+      if (!forked) {
         one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + 2], g.async_events[4 * i + 3]); g.sync_class_ms[2] += one;
       }
     }
@@ -800,6 +825,12 @@ int noahmp_hip_permute_step_arrays(const noahmp_step_args* src, const noahmp_ste
 int noahmp_hip_sync_timing(float* out, int n) {
   for (int c = 0; c < n && c < 3; c++) out[c] = g.sync_class_ms[c];
   return g.sync_steps;
+}
+
+// The same per step: out[i] = land (or mixed) kernel time of step i of the last noahmp_hip_sync [ms]; returns the number of steps.
+int noahmp_hip_sync_step_timing(float* out, int n) {
+  for (int i = 0; i < n && i < (int)g.sync_step_ms.size(); i++) out[i] = g.sync_step_ms[i];
+  return (int)g.sync_step_ms.size();
 }
 
 const char* noahmp_hip_error_string(int code) {

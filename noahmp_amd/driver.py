@@ -324,6 +324,13 @@ class Engine:
         n = self.lib.noahmp_hip_sync_timing(out, 3)
         return [float(x) for x in out], n
 
+    def sync_step_timing(self):
+        """Land (or mixed) kernel ms of every step of the last sync(), in step order."""
+        n = self.lib.noahmp_hip_sync_step_timing(None, 0)
+        out = (C.c_float * max(n, 1))()
+        self.lib.noahmp_hip_sync_step_timing(out, n)
+        return [float(out[i]) for i in range(n)]
+
     def jit_cache_info(self):
         """(cache directory, option sets compiled by this process, loaded from the disk cache, fallen back to the generic kernel)."""
         c = (C.c_int32 * 3)()

@@ -23,12 +23,47 @@ RECORD_HOURS = 3
 
 def config5_raw(ni=3600, nj=1800, seed=5, cfg=None, water_frac=0.03, urban_frac=0.01, polar_glacier=0.30):
     """The state handed to NOAHMP_INIT (nothing the cold start computes is set) + lon + the static forcing factors."""
+    return _config5_rows(ni, nj, 0, nj, seed, cfg, water_frac, urban_frac, polar_glacier)
+
+
+ROW_BLOCK = 60
+
+
+def config5_tile(gx, gy, x0=0, y0=0, nx=None, ny=None, seed=5, cfg=None, **kw):
+    """Cells [x0, x0+nx) x [y0, y0+ny) (0-based) of ONE global gx x gy config-5 grid: the grid is generated in blocks of ROW_BLOCK
+    full rows, block b from the Philox key (seed, b), so that a tile is the same cells whatever the decomposition
+    (mpp_land_partition_calc, mpp:227-288) -- what N ranks cut is what one rank holds.  -> (raw ColumnStore, lon, static)."""
+    nx = gx - x0 if nx is None else nx
+    ny = gy - y0 if ny is None else ny
+    assert 0 <= x0 and x0 + nx <= gx and 0 <= y0 and y0 + ny <= gy
+    cfg = cfg or ModelConfig(idveg=1)
+    out = _base_store(nx, ny, cfg)
+    lon = np.zeros((ny, nx), dtype=F)
+    static = None
+    for b in range(y0 // ROW_BLOCK, (y0 + ny - 1) // ROW_BLOCK + 1):
+        r0 = b * ROW_BLOCK
+        rows = min(ROW_BLOCK, gy - r0)
+        blk, blon, bst = _config5_rows(gx, gy, r0, rows, [seed, b], cfg, **kw)
+        lo, hi = max(y0, r0), min(y0 + ny, r0 + rows)
+        for k, v in blk.a.items():
+            if k != "dzs":
+                out.a[k][lo - y0:hi - y0] = v[lo - r0:hi - r0, ..., x0:x0 + nx]
+        lon[lo - y0:hi - y0] = blon[lo - r0:hi - r0, x0:x0 + nx]
+        if static is None:
+            static = {k: np.zeros((ny, nx), dtype=F) for k in bst}
+        for k, v in bst.items():
+            static[k][lo - y0:hi - y0] = v[lo - r0:hi - r0, x0:x0 + nx]
+    return out, lon, static
+
+
+def _config5_rows(ni, gy, r0, nj, seed, cfg, water_frac=0.03, urban_frac=0.01, polar_glacier=0.30):
+    """Rows r0 .. r0+nj-1 (all ni columns) of the global ni x gy grid."""
     cfg = cfg or ModelConfig(idveg=1)
     r = _rng(seed)
     s = _base_store(ni, nj, cfg)
     a = s.a
     shp = (nj, ni)
-    lat1 = (np.arange(nj, dtype=np.float64) + 0.5) * (180.0 / nj) - 90.0
+    lat1 = (np.arange(r0, r0 + nj, dtype=np.float64) + 0.5) * (180.0 / gy) - 90.0
     lon1 = (np.arange(ni, dtype=np.float64) + 0.5) * (360.0 / ni) - 180.0
     lat = np.broadcast_to(lat1[:, None], shp).astype(F)
     lon = np.broadcast_to(lon1[None, :], shp).astype(F).copy()

@@ -360,27 +360,79 @@ def test_bench_config4_sorted_equals_tile_order(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["config4", "config3"])
+@pytest.mark.parametrize("workload", ["config4", "config3", "config4-dt900"])
 def test_bench_run_equals_the_oracle(workload, tmp_path, port, tables):
     """The run bench.py times (small grid: column step on the sorted layout with the per-step forcing permutation; config 4: plus
-    WTABLE_mmf_noahmp every step on planes returned to (i,j) order) against the oracle advancing the same global grid in tile
-    order with the same forcing sequence -- every INOUT / OUT array bit for bit after 7 steps."""
+    WTABLE_mmf_noahmp every STEPWTD steps on planes returned to (i,j) order) against the oracle advancing the same global grid in
+    tile order with the same forcing sequence -- every INOUT / OUT array bit for bit after 7 steps.  config4-dt900: DT = 900 s, so
+    STEPWTD = nint(30 min / DT) = 2 (hdrv:247-248, 420) and the sub-hourly DT of the column step (NITER, FACT, accumulators)."""
     from noahmp_amd.state import ModelConfig
+    import bench
     gx, gy = 96, 130
-    res, dump = _run_bench(["--gpus", "1", "--workload", workload], str(tmp_path), "gpu")
+    dt = 900.0 if workload.endswith("dt900") else 3600.0
+    workload = workload.split("-")[0]
+    res, dump = _run_bench(["--gpus", "1", "--workload", workload, "--dt", str(dt)], str(tmp_path), "gpu")
     lateral = workload == "config4"
-    g = synth.config3_tile(tables[1], gx, gy, cfg=ModelConfig(iopt_run=5 if lateral else 1), groundwater=lateral)
+    stepwtd = max(int(30.0 * 60.0 / dt + 0.5), 1)
+    if lateral:
+        assert res["groundwater"]["stepwtd"] == stepwtd and res["groundwater"]["calls"] == len([i for i in range(3, 8) if i % stepwtd == 0])
+    g = synth.config3_tile(tables[1], gx, gy, cfg=ModelConfig(iopt_run=5 if lateral else 1, dt=dt), groundwater=lateral)
     synth.first_step_fixups(g)
     for it in range(1, 8):                                   # 2 warm-up + 5 timed steps, hours as bench.py's Run.step
-        synth.diurnal_forcing(g, (it + 5) % 24, t_offset=g.t_offset)
+        synth.diurnal_forcing(g, bench.forcing_hour(it, dt), t_offset=g.t_offset)
         assert port.noahmplsm(g, it, 2000, 180.0).code == 0
-        if lateral:
+        if lateral and it % stepwtd == 0:
             port.wtable_mmf(g)
     got = np.load(dump + ".rank0.npz")
     names = [k for k in got.files if k != "geom"]
     assert "tslb" in names and "isnowxy" in names and (not lateral or "qslat" in names)
     for k in names:
         assert np.array_equal(g.a[k], got[k], equal_nan=True), k
+
+
+@pytest.mark.gpu
+def test_bench_config5_ranks_and_oracle(tmp_path, port, tables):
+    """`bench.py --workload config5` (BASELINE configs[4]: tile of the global lat/lon grid, cold start on the device, forcing
+    interpolation -> CALC_DECLIN forcing preparation -> column step per hour, sorted layout): two ranks on the one GPU give the bits
+    of one rank, and the single-rank run equals the oracle advancing the same grid through the same chain from the same raw state
+    (forcing records evaluated by the same device code, tile order) -- every INOUT / OUT array after 2 + 5 steps."""
+    import torch
+    from noahmp_amd import synth5
+    gx, gy = 120, 66
+    common = ["--workload", "config5", "--ni", str(gx), "--nj", str(gy)]
+    one, d1 = _run_bench(["--gpus", "1"] + common, str(tmp_path), "one5")
+    two, d2 = _run_bench(["--gpus", "2"] + common, str(tmp_path), "two5")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "no collective" in two["config"]["parallelism"]
+    assert "configs[4]" in one["config"]["workload"] and one["cold_start_s"] > 0
+    whole = np.load(d1 + ".rank0.npz")
+    seen = 0
+    for r in range(2):
+        part = np.load(d2 + ".rank%d.npz" % r)
+        its, ite, jts, jte = part["geom"]
+        for k in part.files:
+            if k != "geom":
+                assert np.array_equal(whole[k][jts - 1:jte, ..., its - 1:ite], part[k], equal_nan=True), "%s rank %d" % (k, r)
+        seen += (ite - its + 1) * (jte - jts + 1)
+    assert seen == gx * gy
+    # the oracle through the same chain
+    raw, lon, static = synth5.config5_tile(gx, gy)
+    rc, _ = port.noahmp_init(raw, fndsnowh=True)
+    assert rc == 0
+    dev = torch.device("cuda", 0)
+    recs = synth5.Records(torch.from_numpy(raw.a["xlatin"]).to(dev), torch.from_numpy(lon).to(dev),
+                          {k: torch.from_numpy(v).to(dev) for k, v in static.items()})
+    host = lambda rec: {k: (v.cpu().numpy().copy() if v is not None else None) for k, v in rec.items()}
+    rain = np.zeros((gy, gx), np.float32)
+    for n in range(7):
+        ri, k = divmod(n, synth5.RECORD_HOURS)
+        port.forcing_interpolate(raw, host(recs.at(ri)), host(recs.at(ri + 1)) if k else None, 3600 * k, 3600 * synth5.RECORD_HOURS, rain)
+        iday, ihour = synth5.step_time(n)
+        jul = port.forcing_prep(raw, lon, rain, iday, ihour, first_step=(n == 0))
+        assert port.noahmplsm(raw, n + 1, 2000, jul).code == 0
+    names = [k for k in whole.files if k != "geom"]
+    assert "tslb" in names and (whole["isnowxy"] < 0).any() and (raw.a["ivgtyp"] == 24).any()
+    for k in names:
+        assert np.array_equal(raw.a[k], whole[k], equal_nan=True), k
 
 
 @pytest.mark.gpu
