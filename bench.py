@@ -827,6 +827,7 @@ def main():
             out["sort"] = {"resorts_in_timed_region": run.resorts, "stale_columns_seen": run.stale_seen}
         if run.lateral:
             out["groundwater"] = {"calls": run.gw_calls, "stepwtd": run.stepwtd, "halo_mover": getattr(run, "halo_mover", None),
+                                  "halo_probe_per_rank": comm.probe_results,
                                   "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
         if scaling_ref is not None:

@@ -19,7 +19,9 @@
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/socket.h>
 #include <time.h>
@@ -87,6 +89,35 @@ bool recv_all(int fd, void* p, size_t n) {
   while (n) { ssize_t k = ::recv(fd, c, n, 0); if (k <= 0) { if (k < 0 && errno == EINTR) continue; return false; } c += k; n -= k; }
   return true;
 }
+// Every wait of the rendezvous and of the socket transport has a deadline (default 120 s, NMP_HALO_TIMEOUT_S): a rank that dies or
+// never arrives ends the others with an error instead of parking them on a GPU box.
+double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+double halo_timeout_s() {
+  const char* e = getenv("NMP_HALO_TIMEOUT_S");
+  const double v = e ? atof(e) : 120.0;
+  return v > 0.0 ? v : 120.0;
+}
+void set_io_timeout(int fd, double sec) {
+  timeval tv; tv.tv_sec = (long)sec; tv.tv_usec = (long)((sec - (double)tv.tv_sec) * 1e6);
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+  setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof tv);
+}
+// accept() with a deadline (poll); the accepted socket gets the I/O timeout.  -1: nobody came in time
+int accept_deadline(int lfd, double deadline, sockaddr_in* from) {
+  pollfd p; p.fd = lfd; p.events = POLLIN; p.revents = 0;
+  for (;;) {
+    const double left = deadline - now_s();
+    if (left <= 0.0) return -1;
+    const int r = poll(&p, 1, (int)(left * 1000.0) + 1);
+    if (r < 0 && errno == EINTR) continue;
+    if (r <= 0) return -1;
+    sockaddr_in a; socklen_t l = sizeof a;
+    const int fd = accept(lfd, (sockaddr*)&a, &l);
+    if (fd >= 0) { if (from) *from = a; set_io_timeout(fd, halo_timeout_s()); return fd; }
+    if (errno == EINTR || errno == EAGAIN || errno == ECONNABORTED) continue;
+    return -1;
+  }
+}
 int listen_on(int port, int* port_out) {
   int fd = socket(AF_INET, SOCK_STREAM, 0);
   if (fd < 0) return -1;
@@ -101,15 +132,19 @@ int listen_on(int port, int* port_out) {
   return fd;
 }
 int connect_to(uint32_t ip_be, int port, double timeout_s) {
-  const double t0 = (double)time(nullptr);
+  const double t0 = now_s();
   for (;;) {
     int fd = socket(AF_INET, SOCK_STREAM, 0);
     if (fd < 0) return -1;
     sockaddr_in a; memset(&a, 0, sizeof a);
     a.sin_family = AF_INET; a.sin_addr.s_addr = ip_be; a.sin_port = htons((uint16_t)port);
-    if (connect(fd, (sockaddr*)&a, sizeof a) == 0) { int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one); return fd; }
+    if (connect(fd, (sockaddr*)&a, sizeof a) == 0) {
+      int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
+      set_io_timeout(fd, halo_timeout_s());
+      return fd;
+    }
     close(fd);
-    if ((double)time(nullptr) - t0 > timeout_s) return -1;
+    if (now_s() - t0 > timeout_s) return -1;
     usleep(50000);                         // the master may not be listening yet
   }
 }
@@ -244,6 +279,19 @@ int phase(int n, void* const* planes, bool device, hipStream_t s, int slot_a, co
 
 extern "C" {
 
+// Sockets that only live during noahmp_hip_halo_init: closed on every way out
+struct FdSet {
+  std::vector<int> fds;
+  int add(int fd) { if (fd >= 0) fds.push_back(fd); return fd; }
+  void close_one(int fd) { for (int& f : fds) if (f == fd) { close(f); f = -1; } }
+  ~FdSet() { for (int f : fds) if (f >= 0) close(f); }
+};
+// a failed init leaves nothing behind: neighbour sockets closed, state reset (H.up = false)
+static int init_failed(const std::string& m, int rc = -109) {
+  noahmp_hip_halo_finalize();
+  return fail(m, rc);
+}
+
 int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int master_port, int transport) {
   if (H.up) noahmp_hip_halo_finalize();
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail("bad rank / nranks");
@@ -255,69 +303,78 @@ int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int mast
   H.nb[2] = ipy > 0 ? rank - H.npx : -1; H.nb[3] = ipy < H.npy - 1 ? rank + H.npx : -1;
   H.up = true;
   if (nranks == 1) return 0;
-  // ---- rendezvous: every rank opens a listener; rank 0 collects (ip, port) of all and hands the table out
+  const double timeout = halo_timeout_s(), deadline = now_s() + timeout;
+  FdSet tmp;
+  // ---- rendezvous: every rank opens a listener; rank 0 collects (ip, port, status) of all and hands the table out.  A rank that cannot
+  // take part (no librccl for the RCCL transport) says so in its hello, and rank 0 tells everybody: all ranks fail together, none waits.
   int my_port = 0;
-  const int lfd = listen_on(0, &my_port);
-  if (lfd < 0) return fail("cannot open a listening socket");
+  const int lfd = tmp.add(listen_on(0, &my_port));
+  if (lfd < 0) return init_failed("cannot open a listening socket");
   std::vector<Peer> table(nranks);
   NcclUniqueId uid; memset(&uid, 0, sizeof uid);
+  int my_abort = 0;
+  std::string my_reason;
   if (transport == NOAHMP_HALO_RCCL) {
-    if (load_rccl()) { close(lfd); return -109; }
-    if (rank == 0 && H.rccl.GetUniqueId(&uid)) { close(lfd); return fail("ncclGetUniqueId"); }
+    if (load_rccl()) { my_abort = 1; my_reason = g.last_error; }
+    else if (rank == 0 && H.rccl.GetUniqueId(&uid)) { my_abort = 1; my_reason = "ncclGetUniqueId failed"; }
   }
+  int abort_all = my_abort;
   if (rank == 0) {
-    const int mfd = listen_on(master_port, nullptr);
-    if (mfd < 0) { close(lfd); return fail("rank 0 cannot listen on the master port " + std::to_string(master_port)); }
+    const int mfd = tmp.add(listen_on(master_port, nullptr));
+    if (mfd < 0) return init_failed("rank 0 cannot listen on the master port " + std::to_string(master_port));
     table[0] = Peer{htonl(INADDR_LOOPBACK), my_port};
     std::vector<int> fds(nranks, -1);
     for (int i = 1; i < nranks; i++) {
-      sockaddr_in a; socklen_t l = sizeof a;
-      const int fd = accept(mfd, (sockaddr*)&a, &l);
-      int hello[2];
-      if (fd < 0 || !recv_all(fd, hello, sizeof hello) || hello[0] < 1 || hello[0] >= nranks) { close(mfd); close(lfd); return fail("rendezvous: bad hello"); }
+      sockaddr_in a;
+      const int fd = tmp.add(accept_deadline(mfd, deadline, &a));
+      if (fd < 0) return init_failed("rendezvous: only " + std::to_string(i) + " of " + std::to_string(nranks) + " ranks arrived within " +
+                                     std::to_string((int)timeout) + " s");
+      int hello[3];
+      if (!recv_all(fd, hello, sizeof hello) || hello[0] < 1 || hello[0] >= nranks || fds[hello[0]] >= 0) return init_failed("rendezvous: bad hello");
       fds[hello[0]] = fd;
       table[hello[0]] = Peer{a.sin_addr.s_addr, hello[1]};
+      if (hello[2]) abort_all = 1;
     }
     // rank 0 as the others see it: the master address they connected to
     table[0].ip = resolve(master_addr && *master_addr ? master_addr : "127.0.0.1");
-    for (int i = 1; i < nranks; i++) {
-      const bool ok = send_all(fds[i], table.data(), sizeof(Peer) * nranks) && send_all(fds[i], &uid, sizeof uid);
-      close(fds[i]);
-      if (!ok) { close(mfd); close(lfd); return fail("rendezvous: table send"); }
-    }
-    close(mfd);
+    bool ok = true;
+    for (int i = 1; i < nranks; i++)
+      ok = send_all(fds[i], &abort_all, sizeof abort_all) && send_all(fds[i], table.data(), sizeof(Peer) * nranks) && send_all(fds[i], &uid, sizeof uid) && ok;
+    if (!ok) return init_failed("rendezvous: table send");
   } else {
-    const int fd = connect_to(resolve(master_addr && *master_addr ? master_addr : "127.0.0.1"), master_port, 120.0);
-    if (fd < 0) { close(lfd); return fail("cannot reach rank 0 at " + std::string(master_addr ? master_addr : "127.0.0.1") + ":" + std::to_string(master_port)); }
-    int hello[2] = {rank, my_port};
-    const bool ok = send_all(fd, hello, sizeof hello) && recv_all(fd, table.data(), sizeof(Peer) * nranks) && recv_all(fd, &uid, sizeof uid);
-    close(fd);
-    if (!ok) { close(lfd); return fail("rendezvous: table receive"); }
+    const int fd = tmp.add(connect_to(resolve(master_addr && *master_addr ? master_addr : "127.0.0.1"), master_port, timeout));
+    if (fd < 0) return init_failed("cannot reach rank 0 at " + std::string(master_addr ? master_addr : "127.0.0.1") + ":" + std::to_string(master_port));
+    int hello[3] = {rank, my_port, my_abort};
+    const bool ok = send_all(fd, hello, sizeof hello) && recv_all(fd, &abort_all, sizeof abort_all) &&
+                    recv_all(fd, table.data(), sizeof(Peer) * nranks) && recv_all(fd, &uid, sizeof uid);
+    if (!ok) return init_failed("rendezvous: no table from rank 0 (a rank is missing or rank 0 gave up)");
   }
+  if (abort_all) return init_failed(my_abort ? my_reason : "another rank cannot use the requested transport (see its error): all ranks stop");
   // ---- neighbour links (TCP transport; also a liveness check for RCCL): connect to lower-ranked neighbours, accept the higher ones
   int expect = 0;
   for (int d = 0; d < 4; d++) if (H.nb[d] > rank) expect++;
   for (int d = 0; d < 4; d++) {
     if (H.nb[d] < 0 || H.nb[d] > rank) continue;
-    const int fd = connect_to(table[H.nb[d]].ip, table[H.nb[d]].port, 120.0);
-    if (fd < 0 || !send_all(fd, &rank, sizeof rank)) { close(lfd); return fail("cannot connect to neighbour " + std::to_string(H.nb[d])); }
-    H.sock[d] = fd;
+    const int fd = connect_to(table[H.nb[d]].ip, table[H.nb[d]].port, timeout);
+    if (fd < 0) return init_failed("cannot connect to neighbour " + std::to_string(H.nb[d]));
+    H.sock[d] = fd;                          // from here on noahmp_hip_halo_finalize() owns it
+    if (!send_all(fd, &rank, sizeof rank)) return init_failed("cannot greet neighbour " + std::to_string(H.nb[d]));
   }
   for (int i = 0; i < expect; i++) {
-    const int fd = accept(lfd, nullptr, nullptr);
+    const int fd = accept_deadline(lfd, deadline + timeout, nullptr);
     int who = -1;
-    if (fd < 0 || !recv_all(fd, &who, sizeof who)) { close(lfd); return fail("neighbour accept"); }
+    if (fd < 0) return init_failed("a higher-ranked neighbour did not connect within the time limit");
+    if (!recv_all(fd, &who, sizeof who)) { close(fd); return init_failed("neighbour accept"); }
     int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
     bool placed = false;
     for (int d = 0; d < 4; d++) if (H.nb[d] == who && H.sock[d] < 0) { H.sock[d] = fd; placed = true; break; }
-    if (!placed) { close(fd); close(lfd); return fail("unexpected neighbour " + std::to_string(who)); }
+    if (!placed) { close(fd); return init_failed("unexpected neighbour " + std::to_string(who)); }
   }
-  close(lfd);
   if (transport == NOAHMP_HALO_RCCL) {
     int rc = nmp_host::ensure_init();
-    if (rc) return rc;
+    if (rc) { const std::string m = g.last_error; noahmp_hip_halo_finalize(); g.last_error = m; return rc; }
     const int e = H.rccl.CommInitRank(&H.comm, nranks, uid, rank);
-    if (e) return fail(std::string("ncclCommInitRank: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e) : "error"));
+    if (e) return init_failed(std::string("ncclCommInitRank: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e) : "error"));
   }
   return 0;
 }

@@ -30,6 +30,12 @@ class Comm:
         if halo != "torch" and self.world > 1:
             from . import abi
             self.halo_lib = abi.load_library()
+            # bind the engine to THIS rank's GPU before anything of it touches a device: halo_init (RCCL transport) creates the
+            # engine's stream and the communicator on the current device, which would be GPU 0 for every rank otherwise
+            if halo == "rccl" or self.halo_lib.noahmp_hip_device_count() > 0:
+                rc = self.halo_lib.noahmp_hip_set_device(self.device_index)
+                if rc:
+                    raise RuntimeError("noahmp_hip_set_device(%d): %s" % (self.device_index, self.halo_lib.noahmp_hip_last_error().decode()))
             port = halo_port or int(os.environ.get("NMP_HALO_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
             rc = self.halo_lib.noahmp_hip_halo_init(self.rank, self.world, os.environ.get("MASTER_ADDR", "127.0.0.1").encode(), port,
                                                     abi.HALO_RCCL if halo == "rccl" else abi.HALO_TCP)
@@ -49,6 +55,10 @@ class Comm:
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=5), **kw)
             self.dist = dist
             self.backend = backend
+            # control-plane group on the host, created while every rank is still healthy: probe_halo() agrees over it, so a rank
+            # whose device send/recv has just failed does not have to use the process group that failed
+            self.ctrl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=5)) if backend == "nccl" else None
+        self.probe_results = None
         self.p2p_group = None          # set by probe_halo() when device send/recv does not work: host-staged edges over a gloo group
         self.p2p_host = False
 
@@ -108,10 +118,14 @@ class Comm:
             except Exception as e:                                   # noqa: BLE001  (any failure of the device mover)
                 print("noahmp_amd.parallel: device send/recv failed on rank %d (%s)" % (self.rank, e), flush=True)
                 bad = 1.0
-        flag = torch.tensor([bad], dtype=torch.float32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        ctrl = getattr(self, "ctrl_group", None)
+        flag = torch.tensor([bad], dtype=torch.float32, device="cpu" if ctrl is not None else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctrl)     # nccl runs: over the gloo control group (host tensor)
+        per_rank = [None] * self.world
+        dist.all_gather_object(per_rank, "ok" if not bad else "device send/recv failed or forced off", group=ctrl)
+        self.probe_results = per_rank
         if float(flag.item()) > 0.0:
-            self.p2p_group = dist.new_group(backend="gloo")          # collective: every rank creates it
+            self.p2p_group = ctrl if ctrl is not None else dist.new_group(backend="gloo")    # (collective: every rank creates it)
             self.p2p_host = True
             self._halo_plans = {}
             return "torch.distributed over gloo, edges staged through the host (device send/recv unavailable)"

@@ -219,7 +219,7 @@ def _cfg4_worker(rank, world, port, gx, gy, nsteps, q):
     comm.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8, 9])          # 8 = the north-star 4 x 2 grid; 9 = 3 x 3: a rank with four neighbours
 def test_config4_ranks_cut_one_global_grid(world, port, tables):
     gx, gy, nsteps = 70, 130, 3                           # three row blocks of the generator, uneven tiles
     from noahmp_amd.state import ModelConfig
@@ -328,7 +328,7 @@ def _cabi_worker(rank, world, port, gx, gy, q):
     q.put((rank, ok, int(ring.sum())))
 
 
-@pytest.mark.parametrize("world", [2, 4, 6])
+@pytest.mark.parametrize("world", [2, 4, 6, 8, 9])       # 8 = 4 x 2 (north star), 9 = 3 x 3 (the centre rank has four neighbours)
 def test_cabi_halo_exchange_on_host_planes(world):
     gx, gy = 41, 29
     ctx = mp.get_context("spawn")
@@ -343,6 +343,37 @@ def test_cabi_halo_exchange_on_host_planes(world):
         assert pr.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(n > 0 for _, _, n in res)
+
+
+def _cabi_dead_rank_worker(rank, world, port, q):
+    import time
+    from noahmp_amd import abi
+    os.environ["NMP_HALO_TIMEOUT_S"] = "4"
+    lib = abi.load_library()
+    t0 = time.time()
+    rc = lib.noahmp_hip_halo_init(rank, world, b"127.0.0.1", port, abi.HALO_TCP)
+    q.put((rank, rc, time.time() - t0, lib.noahmp_hip_last_error().decode()))
+
+
+@pytest.mark.parametrize("dead", [2, 0])
+def test_cabi_halo_init_ends_when_a_rank_never_arrives(dead):
+    """A rank that dies before the rendezvous (here: is never started) ends every other rank's noahmp_hip_halo_init with an error
+    within the time limit (NMP_HALO_TIMEOUT_S) -- accept() and the table transfer have deadlines, nothing hangs, nothing leaks --
+    whether the missing rank is a neighbour (2) or the master itself (0)."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = _free_port()
+    procs = [ctx.Process(target=_cabi_dead_rank_worker, args=(r, world, p, q)) for r in range(world) if r != dead]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for pr in procs:
+        pr.join(30)
+        assert pr.exitcode == 0
+    assert all(rc != 0 for _, rc, _, _ in res), res
+    assert all(t < 40.0 for _, _, t, _ in res), res
+    assert all(msg for _, _, _, msg in res), res
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Host-side AddressSanitizer pass on the CPU (device ASan / host ASan beside the HSA runtime are not available on this pool): the
-# library's host code instrumented, the gloo-free halo tests (2/4/6 ranks over sockets) and the run-time compilation + disk cache test.
+# library's host code instrumented, the gloo-free halo tests (2 ... 9 ranks over sockets; a rank that never arrives), the run-time compilation + disk cache test.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); CS=$R/noahmp_amd/csrc; W=/tmp/nmp_asan; mkdir -p $W
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
