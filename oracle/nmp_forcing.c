@@ -1,8 +1,9 @@
 /* TEST INFRASTRUCTURE (oracle) -- CPU restatement of the driver-side forcing preparation:
  * driver/module_hrldas_noahmp_driver.F90:336-354 ("hdrv") and CALC_DECLIN (hdrv:813-863).
- * PARITY UNPINNED against a reference build: CALC_DECLIN lives in the driver file, which needs the NetCDF modules to
- * compile (unbuildable here).  It is a 15-line formula; this file restates it in float32 in source
- * order with the same libm, and tests/test_forcing.py additionally checks it against an independent float64 evaluation. */
+ * COSZEN / JULIAN: PINNED.  CALC_DECLIN is an external subroutine that needs only util/module_date_utilities.F; `make -C oracle declin`
+ * compiles it unmodified (oracle/_ref/libnoahmp_declin_ref.so) and tests/test_forcing.py holds this file to it bit for bit, live and
+ * through tests/golden/golden_declin.npz.  The copies and unit scalings of hdrv:336-354 sit inside the module part of the driver file
+ * (needs NetCDF: not buildable here) and are restated in float32 in source order; the temporal interpolation below likewise. */
 #include <math.h>
 #include <string.h>
 #include "noahmp_oracle.h"

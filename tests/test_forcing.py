@@ -1,7 +1,11 @@
 """Forcing preparation on the device: driver/module_hrldas_noahmp_driver.F90:336-354 + CALC_DECLIN (hdrv:813-863).
 
-The oracle (oracle/nmp_forcing.c) is a restatement only: the driver file cannot be compiled here (NetCDF), so parity with a
-reference build is UNPINNED for this entry; the restatement is cross-checked against an independent float64 evaluation."""
+COSZEN / JULIAN are PINNED: CALC_DECLIN is an external subroutine that needs only util/module_date_utilities.F, so `make -C oracle
+declin` compiles it unmodified (cut out of the driver file at build time, nothing committed) and the oracle restatement
+(oracle/nmp_forcing.c) is held to it bit for bit -- live where oracle/_ref exists, and through tests/golden/golden_declin.npz
+(produced by tests/golden/make_golden_declin.py from that build) everywhere.  The copies / unit scalings of hdrv:336-354 are
+checked against their numpy float32 statement; the temporal interpolation (netcdf_io:1369-1403, module-internal, needs NetCDF)
+stays a restatement."""
 import ctypes as C
 
 import numpy as np
@@ -26,6 +30,49 @@ def case(ni=96, nj=40, seed=3):
     for k in ("coszin", "dz8w", "rainbl", "eahxy", "tahxy", "chxy", "cmxy"):
         s[k] = -777.0
     return s, lon, rain
+
+
+def _day_of_year(y, mo, d):
+    import datetime
+    return (datetime.date(y, mo, d) - datetime.date(y, 1, 1)).days            # GETH_IDTS(date, YYYY-01-01): days since 1 January
+
+
+def _oracle_cosz(port, lat, lon, when):
+    y, mo, d, h, mi, sec = [int(x) for x in when]
+    s = ColumnStore(lat.size, 1, ModelConfig())
+    s["xlatin"] = lat[None, :]
+    jul = port.forcing_prep(s, lon[None, :].copy(), np.zeros((1, lat.size), np.float32), _day_of_year(y, mo, d), h, mi, sec)
+    return s["coszin"][0].copy(), np.float32(jul)
+
+
+def test_oracle_cosz_equals_reference_calc_declin_fixture(port):
+    """oracle/nmp_forcing.c == the reference's CALC_DECLIN (golden_declin.npz: 11 dates x 4096 points), COSZ and JULIAN bit for bit."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "golden_declin.npz"))
+    for i, when in enumerate(g["when"]):
+        cosz, jul = _oracle_cosz(port, g["lat"], g["lon"], when)
+        assert jul == g["julian%02d" % i], when
+        np.testing.assert_array_equal(cosz, g["cosz%02d" % i], err_msg=str(when))
+
+
+def test_oracle_cosz_equals_compiled_calc_declin_live(port):
+    """The same against the compiled reference subroutine itself, at random dates and points (dev container only)."""
+    import os
+    from golden import make_golden_declin as m
+    if not os.path.exists(m.LIB):
+        pytest.skip("oracle/_ref/libnoahmp_declin_ref.so not built (needs /root/reference)")
+    lib = m.ref_lib()
+    r = np.random.Generator(np.random.Philox(23))
+    for _ in range(40):
+        y = int(r.choice([1999, 2000, 2001, 2004, 2100]))
+        mo, d = int(r.integers(1, 13)), int(r.integers(1, 29))
+        when = (y, mo, d, int(r.integers(0, 24)), int(r.integers(0, 60)), int(r.integers(0, 60)))
+        lat, lon = m.grid(seed=int(r.integers(1, 1 << 30)), n=512)
+        want, wjul = m.run_reference(lib, when, lat, lon)
+        cosz, jul = _oracle_cosz(port, lat, lon, when)
+        assert jul == wjul, when
+        np.testing.assert_array_equal(cosz, want, err_msg=str(when))
 
 
 TIMES = [(0, 0, 0, 0), (45, 13, 30, 0), (79, 23, 59, 59), (80, 0, 0, 1), (171, 12, 0, 0), (200, 6, 15, 30), (364, 18, 45, 12)]
