@@ -210,3 +210,50 @@ def test_fortran_shim_resident_mode(engine, tables, fast):
     for k in plain.a:
         if FIELD_INFO[k][2] != "in":
             np.testing.assert_array_equal(plain.a[k], res.a[k], err_msg=k)
+
+
+def test_same_name_modules_compile_the_reference_use_lines(tmp_path):
+    """"a replacement module must export the same module name".  noahmp_amd/fortran/module_sf_noahmpdrv.F90 defines
+    `module_sf_noahmpdrv` and `module_sf_noahmp_groundwater` themselves: noahmplsm / WTABLE_mmf_noahmp from the HIP shims, everything
+    else from the reference's two files compiled UNCHANGED under other module names (two -D flags for the preprocessor the reference
+    build already runs).  Built here exactly as INTEGRATION.md section 1b says, with a mini-driver whose `use` lines are hdrv:5-6
+    verbatim: it compiles, links, and noahmplsm / WTABLE_mmf_noahmp resolve to the shim's module procedures."""
+    import subprocess
+    from fortran import build_shim
+    ref = "/root/reference/phys"
+    if not (build_shim.available() and os.path.isdir(ref)):
+        pytest.skip("needs flang, oracle/_ref and /root/reference")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "noahmp_amd", "csrc")
+    fdir = os.path.join(root, "noahmp_amd", "fortran")
+    out = str(tmp_path)
+    # module search order: this build's own .mod files first (oracle/_ref/mod_O0 also holds the reference's module_sf_noahmpdrv.mod)
+    fc = [build_shim.FC, "-cpp", "-D_HRLDAS_OFFLINE_", "-w", "-fPIC", "-O0", "-I" + out, "-I" + os.path.join(build_shim.REF, "mod_O0"), "-module-dir", out]
+    dgw = "-Dmodule_sf_noahmp_groundwater=module_sf_noahmp_groundwater_ref"
+    ddrv = "-Dmodule_sf_noahmpdrv=module_sf_noahmpdrv_ref"
+    steps = [
+        fc + ["-ffree-form", dgw, "-c", os.path.join(ref, "module_sf_noahmp_groundwater.F90"), "-o", os.path.join(out, "gw_ref.o")],
+        fc + ["-ffree-form", dgw, ddrv, "-c", os.path.join(ref, "module_sf_noahmpdrv.F90"), "-o", os.path.join(out, "drv_ref.o")],
+        fc + ["-c", os.path.join(fdir, "module_sf_noahmpdrv_hip.F90"), "-o", os.path.join(out, "shim.o")],
+        fc + ["-c", os.path.join(fdir, "module_sf_noahmpdrv.F90"), "-o", os.path.join(out, "same.o")],
+        fc + ["-c", os.path.join(root, "tests", "fortran", "same_name_driver.f90"), "-o", os.path.join(out, "drv.o")],
+    ]
+    for cmd in steps:
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, " ".join(cmd) + "\n" + r.stderr
+    lib = os.path.join(out, "libsame_name.so")
+    r = subprocess.run([build_shim.FC, "-shared", "-fPIC"] + [os.path.join(out, f) for f in ("gw_ref.o", "drv_ref.o", "shim.o", "same.o", "drv.o")] +
+                       ["-o", lib, "-L" + build_shim.REF, "-lnoahmp_ref", "-L" + csrc, "-lnoahmp_hip", "-Wl,-rpath," + build_shim.REF,
+                        "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib/llvm/lib", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(os.path.join(out, "module_sf_noahmpdrv.mod")) and os.path.exists(os.path.join(out, "module_sf_noahmp_groundwater.mod"))
+    und = subprocess.run(["nm", os.path.join(out, "drv.o")], capture_output=True, text=True).stdout.lower()
+    assert "_qmmodule_sf_noahmpdrv_hippnoahmplsm" in und and "_qmmodule_sf_noahmp_groundwater_hippwtable_mmf_noahmp" in und
+    assert "_qmmodule_sf_noahmpdrv_refpnoahmp_init" in und and "_qmmodule_sf_noahmpdrv_refpsoil_veg_gen_parm" in und
+    assert "_qmmodule_sf_noahmpdrvp" not in und and "_qmmodule_sf_noahmp_groundwaterp" not in und      # nothing of the reference's own modules
+    import ctypes as C
+    import torch  # noqa: F401  (libnoahmp_hip.so resolves its HIP runtime to torch's copy)
+    so = C.CDLL(lib)
+    n = C.c_int(0)
+    so.same_name_probe(C.byref(n))
+    assert n.value == 4
