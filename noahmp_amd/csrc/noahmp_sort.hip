@@ -99,6 +99,16 @@ __global__ void __launch_bounds__(256) scatter_plan_kernel(const int* inv, long 
   }
 }
 
+// the same plan for any chunk size: keys = destinations, values = offsets inside the chunk, one stable segmented radix sort
+__global__ void __launch_bounds__(256) plan_slots_kernel(unsigned short* slot, long n, int chunk) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) slot[q] = (unsigned short)(q % chunk);
+}
+struct SegOffset {
+  unsigned chunk, n, shift;
+  __host__ __device__ unsigned operator()(unsigned i) const { const unsigned long long o = ((unsigned long long)i + shift) * chunk; return o < n ? (unsigned)o : n; }
+};
+
 int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_mk) {
   if (a->ims != a->its || a->ime != a->ite || a->jms != a->jts || a->jme != a->jte) {
     g.last_error = "column sort: the memory block must be the tile (a tile that carries a halo keeps its (i,j) order)";
@@ -116,6 +126,8 @@ int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_
 struct SortScratch {
   unsigned* keys_in = nullptr; int* idx_in = nullptr; unsigned* keys_out = nullptr; void* tmp = nullptr; int* inv = nullptr;
   size_t keys_in_b = 0, idx_in_b = 0, keys_out_b = 0, tmp_b = 0, inv_b = 0;
+  unsigned short* slot_in = nullptr; size_t slot_in_b = 0;     // scatter plan: chunk offsets before the segmented sort
+  void* seg_tmp = nullptr; size_t seg_tmp_b = 0;
   unsigned long long* slots = nullptr;      // 256 staleness counters
   long* h_bounds = nullptr;                 // pinned: 2 class boundaries + 256 staleness slots
   long* d_bounds = nullptr;
@@ -125,6 +137,7 @@ struct SortScratch {
 
 namespace nmp_host {
 void sort_finalize() {
+  hipFree(sc.slot_in); hipFree(sc.seg_tmp);
   hipFree(sc.keys_in); hipFree(sc.idx_in); hipFree(sc.keys_out); hipFree(sc.tmp); hipFree(sc.inv); hipFree(sc.slots); hipFree(sc.d_bounds);
   if (sc.h_bounds) hipHostFree(sc.h_bounds);
   sc = SortScratch();
@@ -198,7 +211,23 @@ int noahmp_hip_scatter_plan(const int32_t* perm, int ni, int nj, uint16_t* order
   if (n <= 0) return 0;
   if ((rc = nmp_host::ensure_bytes((void**)&sc.inv, &sc.inv_b, n * 4))) return rc;
   hipLaunchKernelGGL(invert_perm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, sc.inv, n);
-  hipLaunchKernelGGL(scatter_plan_kernel, dim3((unsigned)((n + kChunk - 1) / kChunk)), dim3(256), 0, s, sc.inv, n, order_out, dpos_out);
+  const int chunk = noahmp_hip_scatter_chunk_of(ni, nj);
+  if (chunk == kChunk) {
+    hipLaunchKernelGGL(scatter_plan_kernel, dim3((unsigned)((n + kChunk - 1) / kChunk)), dim3(256), 0, s, sc.inv, n, order_out, dpos_out);
+  } else {
+    if ((rc = nmp_host::ensure_bytes((void**)&sc.slot_in, &sc.slot_in_b, n * 2))) return rc;
+    hipLaunchKernelGGL(plan_slots_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc.slot_in, n, chunk);
+    const unsigned nseg = (unsigned)((n + chunk - 1) / chunk);
+    auto cnt = rocprim::make_counting_iterator<unsigned>(0);
+    auto beg = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)chunk, (unsigned)n, 0u});
+    auto end = rocprim::make_transform_iterator(cnt, SegOffset{(unsigned)chunk, (unsigned)n, 1u});
+    size_t need = 0;
+    HIPCHK(rocprim::segmented_radix_sort_pairs(nullptr, need, (const unsigned*)sc.inv, (unsigned*)dpos_out, (const unsigned short*)sc.slot_in,
+                                               (unsigned short*)order_out, (unsigned)n, nseg, beg, end, 0, 32, s));
+    if ((rc = nmp_host::ensure_bytes(&sc.seg_tmp, &sc.seg_tmp_b, need))) return rc;
+    HIPCHK(rocprim::segmented_radix_sort_pairs(sc.seg_tmp, need, (const unsigned*)sc.inv, (unsigned*)dpos_out, (const unsigned short*)sc.slot_in,
+                                               (unsigned short*)order_out, (unsigned)n, nseg, beg, end, 0, 32, s));
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
