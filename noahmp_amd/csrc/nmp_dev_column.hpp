@@ -135,8 +135,8 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   s.cosz = G2(coszin); s.lat = G2(xlatin);
   s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
   int vegtyp = G2(ivgtyp), soiltyp = G2(isltyp);
-  s.shdfac = G2(vegfra) / 100.f;
-  s.shdmax = G2(vegmax) / 100.f;
+  s.shdfac = div_rc(G2(vegfra), NMP_RCC(100.f));
+  s.shdmax = div_rc(G2(vegmax), NMP_RCC(100.f));
   s.tbot = G2(tmn);
   s.sfctmp = G3(t3d, k.k1, k.nka);
   { float qv = G3(qv3d, k.k1, k.nka); s.q2 = qv / (1.0f + qv); }
@@ -144,7 +144,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   s.soldn = G2(swdown); s.lwdn = G2(glw);
   s.sfcprs = (G3(p8w3d, k.kp_hi, k.nka) + G3(p8w3d, k.kp_lo, k.nka)) * 0.5f;
   s.psfc = G3(p8w3d, k.k1, k.nka);
-  s.prcp = G2(rainbl) / k.a.dt;
+  s.prcp = div_rc(G2(rainbl), k.c.u.dt);
   s.isnow = G2(isnowxy);
 #pragma unroll
   for (int l = 1; l <= NSOIL; l++) {

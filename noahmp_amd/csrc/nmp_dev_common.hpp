@@ -73,6 +73,9 @@ NMP_DEV float nmp_min(float a, float b) { return a < b ? a : b; }
 #if NMP_EXACT_LIBM
 NMP_DEV float nmp_expf(float x) { NMP_CNT(0); return libm::expf_(x); }
 NMP_DEV float nmp_logf(float x) { NMP_CNT(1); return libm::logf_(x); }
+// N independent LOG / EXP evaluated together (same arithmetic; the table look-ups of the batch share one LDS latency)
+template <int N> NMP_DEV void nmp_logfN(const float* x, float* out) { for (int n = 0; n < N; n++) NMP_CNT(1); libm::logfN_<N>(x, out); }
+template <int N> NMP_DEV void nmp_expfN(const float* x, float* out) { for (int n = 0; n < N; n++) NMP_CNT(0); libm::expfN_<N>(x, out); }
 NMP_DEV float nmp_powf(float x, float y) { NMP_CNT(2); return libm::powf_(x, y); }
 NMP_DEV float nmp_log10f(float x) { NMP_CNT(3); return libm::log10f_(x); }
 NMP_DEV float nmp_atanf(float x) { NMP_CNT(4); return libm::atanf_(x); }
@@ -91,6 +94,8 @@ NMP_DEV float pow_neg_quarter(float x) { NMP_CNT(6); return libm::powf_(x, -0.25
 #else
 NMP_DEV float nmp_expf(float x) { return expf(x); }
 NMP_DEV float nmp_logf(float x) { return logf(x); }
+template <int N> NMP_DEV void nmp_logfN(const float* x, float* out) { for (int n = 0; n < N; n++) out[n] = logf(x[n]); }
+template <int N> NMP_DEV void nmp_expfN(const float* x, float* out) { for (int n = 0; n < N; n++) out[n] = expf(x[n]); }
 NMP_DEV float nmp_powf(float x, float y) { return powf(x, y); }
 NMP_DEV float nmp_log10f(float x) { return log10f(x); }
 NMP_DEV float nmp_atanf(float x) { return atanf(x); }
@@ -164,8 +169,27 @@ struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)
 };
 #endif
 
+// Per-type constants that follow from the parameter tables alone: what every column of a soil type (x urban override, lsm:9294-9300)
+// or vegetation type would evaluate again and again -- THKS**(1-SMCMAX) (three powf, lsm:2076-2094), THKDRY, the dry-layer part of
+// RSURF (a powf, lsm:1655), KDT, FRZX, the leaf-orientation integrals of TWOSTREAM (a logf and two divisions, lsm:2891-2897) and
+// the float64 reciprocals of SMCMAX, SMCREF-SMCWLT, PSISAT (div_rc).  Filled once per noahmp_hip_set_tables on the HOST by
+// derive_tables() (nmp_dev_sflx.hpp) with the very functions and float32 operations the device code used to run per column
+// (nmp_libm is host + device and held to the reference libm bit for bit on both).
+constexpr int NSLT = 30, NVEGT = 27;
+struct Derived {
+  float thks_pow[2][NSLT], thkdry[2][NSLT], d_rsurf[2][NSLT], frzx[2][NSLT];      // [urban override][soil type - 1]
+  float kdt[NSLT], neg_inv_bexp[NSLT];
+  double r_smcmax[2][NSLT], r_refwlt[2][NSLT], r_psisat[NSLT];
+  float chil[NVEGT], phi1[NVEGT], phi2[NVEGT], avmu[NVEGT];                       // [vegetation type - 1]
+};
+
+// the device image of the tables: the ABI struct, then what derive_tables() made of it
+struct TablesDev { noahmp_tables t; Derived d; };
+NMP_DEV const Derived* derived_of(const noahmp_tables* T) { return &reinterpret_cast<const TablesDev*>(T)->d; }
+
 struct Parm {  // REDPRM output (lsm:9282-9335): per-column, in registers instead of module globals
   int nroot;
+  int st, u;     // soil type - 1 as REDPRM validated it, urban override 0 / 1: the column's row of Derived
   float rgl, rsmin, hs, rsmax, topt;
   float bexp, smcmax, smcref, psisat, dksat, dwsat, smcwlt, quartz;
   float slope, csoil, zbot, czil, kdt, frzx;
@@ -214,6 +238,7 @@ struct Urc {
 // launch-uniform context (kernel argument, lands in SGPRs)
 struct Ctx {
   const noahmp_tables* __restrict__ T;
+  const Derived* __restrict__ D;
   Opt O;
   float dt;
   float zsoil[NL];   // zsoil[L(1..4)], drv:392-395

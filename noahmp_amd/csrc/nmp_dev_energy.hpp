@@ -35,13 +35,15 @@ NMP_DEV float tdfcnd_thks_pow(const Parm& P) {
   float thks = nmp_powf(7.7f, P.quartz) * nmp_powf(2.0f, 1.f - P.quartz);
   return nmp_powf(thks, 1.f - P.smcmax);
 }
-NMP_DEV float tdfcnd(const Parm& P, double r_smcmax, float thks_pow, float smc, float sh2o) {
+NMP_DEV float tdfcnd_thkdry(const Parm& P) {           // lsm:2100-2101: depends on SMCMAX only
+  float gammd = (1.f - P.smcmax) * 2700.f;
+  return (0.135f * gammd + 64.7f) / (2700.f - 0.947f * gammd);
+}
+NMP_DEV float tdfcnd(const Parm& P, double r_smcmax, float thks_pow, float thkdry, float smc, float sh2o) {
   float satratio = div_rc(smc, r_smcmax);
   float xunfroz = sh2o / smc;
   float xu = xunfroz * P.smcmax;
   float thksat = thks_pow * nmp_powf(TKICE, P.smcmax - xu) * nmp_powf(0.57f, xu);
-  float gammd = (1.f - P.smcmax) * 2700.f;
-  float thkdry = (0.135f * gammd + 64.7f) / (2700.f - 0.947f * gammd);
   float ake;
   if ((sh2o + 0.0005f) < smc) ake = satratio;
   else ake = (satratio > 0.1f) ? (nmp_log10f(satratio) + 1.0f) : 0.0f;
@@ -66,14 +68,14 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
     }
   }
   const bool urban = (s.vegtyp == c.isurban);
-  const float thks_pow = tdfcnd_thks_pow(P);
-  const double r_smcmax = rc64(P.smcmax);
+  const float thks_pow = c.D->thks_pow[P.u][P.st], thkdry = c.D->thkdry[P.u][P.st];     // per soil type (Derived)
+  const double r_smcmax = c.D->r_smcmax[P.u][P.st];
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     float smc = y.smc[L(iz)], sh2o = y.sh2o[L(iz)];
     float sice = smc - sh2o;
     hcpct[L(iz)] = sh2o * CWAT + (1.0f - P.smcmax) * P.csoil + (P.smcmax - smc) * CPAIR + sice * CICE;
-    df[L(iz)] = urban ? 3.24f : tdfcnd(P, r_smcmax, thks_pow, smc, sh2o);
+    df[L(iz)] = urban ? 3.24f : tdfcnd(P, r_smcmax, thks_pow, thkdry, smc, sh2o);
   }
 #pragma unroll
   for (int iz = -2; iz <= NSOIL; iz++)
@@ -104,6 +106,15 @@ NMP_DEV void snow_age(float dt, float tg, float sneqvo, float sneqv, float& taus
 
 struct TwoStreamOut { float fab, fre, ftd, fti, frev, freg; };
 
+// the leaf-orientation part of TWOSTREAM (lsm:2891-2897): a function of the vegetation type's XL only
+NMP_DEV void leaf_orientation(float xl, float& chil, float& phi1, float& phi2, float& avmu) {
+  chil = nmp_min(nmp_max(xl, -0.4f), 0.6f);
+  if (fabsf(chil) <= 0.01f) chil = 0.01f;
+  phi1 = 0.5f - 0.633f * chil - 0.330f * chil * chil;
+  phi2 = 0.877f * (1.f - 2.f * phi1);
+  avmu = (1.f - phi1 / phi2 * nmp_logf((phi1 + phi2) / phi1)) / phi2;
+}
+
 // TWOSTREAM lsm:2768-3016 for one band (rho,tau,albgrd,albgri,omegas of that band), ic 0=direct 1=diffuse
 NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float vai, float fwet, float t,
                                float albgrd, float albgri, float rho, float tau, float omegas,
@@ -132,13 +143,9 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
     if (c.O.rad == 3) { gap = 1.0f - fveg; kopen = 1.0f - fveg; }
   }
   float coszi = nmp_max(0.001f, cosz);
-  float chil = nmp_min(nmp_max(T->xl[v], -0.4f), 0.6f);
-  if (fabsf(chil) <= 0.01f) chil = 0.01f;
-  float phi1 = 0.5f - 0.633f * chil - 0.330f * chil * chil;
-  float phi2 = 0.877f * (1.f - 2.f * phi1);
+  const float chil = c.D->chil[v], phi1 = c.D->phi1[v], phi2 = c.D->phi2[v], avmu = c.D->avmu[v];   // leaf_orientation(XL), per vegetation type
   gdir = phi1 + phi2 * coszi;
   float ext = gdir / coszi;
-  float avmu = (1.f - phi1 / phi2 * nmp_logf((phi1 + phi2) / phi1)) / phi2;
   float omegal = rho + tau;
   float tmp0 = gdir + phi2 * coszi;
   float tmp1 = phi1 * coszi;
@@ -346,12 +353,13 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, 
   if (m.moz < 0.f) {
     float tmp1, tmp12;                       // the two X = (1-16 MOZ)**0.25 are independent: evaluate them interleaved
     pow_quarter2(1.f - 16.f * m.moz, 1.f - 16.f * moz2, tmp1, tmp12);
-    float tmp2 = nmp_logf((1.f + tmp1 * tmp1) / 2.f);
-    float tmp3 = nmp_logf((1.f + tmp1) / 2.f);
+    const float la[4] = {(1.f + tmp1 * tmp1) / 2.f, (1.f + tmp1) / 2.f, (1.f + tmp12 * tmp12) / 2.f, (1.f + tmp12) / 2.f};
+    float lg[4];
+    nmp_logfN<4>(la, lg);                    // the four LOGs are independent: one batch
+    const float tmp2 = lg[0], tmp3 = lg[1];
     fmnew = 2.f * tmp3 + tmp2 - 2.f * nmp_atanf(tmp1) + 1.5707963f;
     fhnew = 2 * tmp2;
-    float tmp22 = nmp_logf((1.f + tmp12 * tmp12) / 2.f);
-    float tmp32 = nmp_logf((1.f + tmp12) / 2.f);
+    const float tmp22 = lg[2], tmp32 = lg[3];
     fm2new = 2.f * tmp32 + tmp22 - 2.f * nmp_atanf(tmp12) + 1.5707963f;
     fh2new = 2 * tmp22;
   } else {
@@ -582,12 +590,15 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     if (FIRST) L.fhg = fhgnew;
     else L.fhg = 0.5f * (L.fhg + fhgnew);
     float cwpc = pow_half(L.cwp * L.vaie * hcan * L.fhg);
-    float tmp1 = nmp_expf(div_rc(-cwpc * z0hg, L.r_hcan));
-    float tmp2 = nmp_expf(div_rc(-cwpc * (z0h + L.zpd), L.r_hcan));
-    float tmprah2 = hcan * nmp_expf(cwpc) / cwpc * (tmp1 - tmp2);
+    const float ea[4] = {div_rc(-cwpc * z0hg, L.r_hcan), div_rc(-cwpc * (z0h + L.zpd), L.r_hcan), cwpc, -cwpc / 2.f};
+    float ex[4];
+    nmp_expfN<4>(ea, ex);                    // the four EXPs of RAGRB are independent: one batch
+    float tmp1 = ex[0];
+    float tmp2 = ex[1];
+    float tmprah2 = hcan * ex[2] / cwpc * (tmp1 - tmp2);
     float kh = nmp_max(VKC * L.mo.fv * (hcan - L.zpd), MPE);
     L.rahg = tmprah2 / kh;
-    float tmprb = cwpc * 50.f / (1.f - nmp_expf(-cwpc / 2.f));
+    float tmprb = cwpc * 50.f / (1.f - ex[3]);
     L.rb = tmprb * L.sqrt_dleaf_uc;
   }
   const float rawg = L.rahg, rb = L.rb;
@@ -1000,7 +1011,7 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     if (c.O.frz == 1) {
       if (stc[L(j)] < TFRZ) {
         float smp = HFUS * (TFRZ - stc[L(j)]) / (GRAV * stc[L(j)]);
-        supercool[L(j)] = P.smcmax * nmp_powf(smp / P.psisat, -1.f / P.bexp);
+        supercool[L(j)] = P.smcmax * nmp_powf(div_rc(smp, c.D->r_psisat[P.st]), c.D->neg_inv_bexp[P.st]);
         supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;
       }
     } else {
@@ -1087,6 +1098,11 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
   s.ponding = ponding;
 }
 
+// the dry-layer factor of the Sakaguchi-Zeng soil surface resistance (lsm:1655): soil parameters only
+NMP_DEV float rsurf_dry_layer(const Parm& P) {
+  return 2.2E-5f * P.smcmax * P.smcmax * nmp_powf(1.0f - P.smcwlt / P.smcmax, 2.0f + 3.0f / P.bexp);
+}
+
 // dynamic-top accessor: value of a 7-slot array at layer ISNOW+1 without run-time indexing
 NMP_DEV float at_top(const float* a, int isnow) {
   return (isnow == 0) ? a[L(1)] : (isnow == -1) ? a[L(0)] : (isnow == -2) ? a[L(-1)] : a[L(-2)];
@@ -1144,8 +1160,8 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   // BTRAN lsm:1617-1640
   s.btran = 0.f;
   const float zroot = -c.zsoil[L(P.nroot)];
-  const double r_zroot = c.u.zs[L(P.nroot)], r_smcmax = rc64(P.smcmax);
-  const double r_refwlt = (c.O.btr == 1) ? rc64(P.smcref - P.smcwlt) : 0.0;
+  const double r_zroot = c.u.zs[L(P.nroot)], r_smcmax = c.D->r_smcmax[P.u][P.st];
+  const double r_refwlt = (c.O.btr == 1) ? c.D->r_refwlt[P.u][P.st] : 0.0;
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     if (iz <= P.nroot) {
@@ -1173,7 +1189,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
     float sh1 = y.sh2o[L(1)];
     float l_rsurf = div_rc((-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - nmp_min(1.0f, div_rc(sh1, r_smcmax)))) - 1.0f),
                            NMP_RCC(2.71828f - 1.0f));
-    float d_rsurf = 2.2E-5f * P.smcmax * P.smcmax * nmp_powf(1.0f - div_rc(P.smcwlt, r_smcmax), 2.0f + 3.0f / P.bexp);
+    float d_rsurf = c.D->d_rsurf[P.u][P.st];           // rsurf_dry_layer(P), per soil type
     q.rsurf = l_rsurf / d_rsurf;
     if (sh1 < 0.01f && s.snowh == 0.f) q.rsurf = 1.E6f;
     float psi = -P.psisat * nmp_powf(div_rc(nmp_max(0.01f, sh1), r_smcmax), -P.bexp);

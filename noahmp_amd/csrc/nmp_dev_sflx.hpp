@@ -6,12 +6,9 @@
 
 namespace nmp {
 
-// REDPRM lsm:9202-9349: table gather into per-thread registers (the reference writes module globals)
-NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
-  const noahmp_tables* T = c.T;
-  if (soiltyp > T->slcats || soiltyp < 1) { raise(s, NOAHMP_ERR_SOILTYP_RANGE); soiltyp = 1; }
-  if (vegtyp > T->lucats || vegtyp < 1) { raise(s, NOAHMP_ERR_VEGTYP_RANGE); vegtyp = 1; }
-  const int st = soiltyp - 1, vt = vegtyp - 1;
+// the soil half of REDPRM (lsm:9282-9300) for soil type st+1 with or without the urban override
+NMP_DEV void redprm_soil(const noahmp_tables* T, int st, bool urban, Parm& P) {
+  P.st = st; P.u = urban ? 1 : 0;
   P.csoil = T->csoil_data;
   P.bexp = T->bb[st];
   P.psisat = T->satpsi[st];
@@ -19,7 +16,19 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   P.smcmax = T->maxsmc[st];
   P.smcref = T->refsmc[st];
   P.smcwlt = T->wltsmc[st];
-  if (vegtyp == c.isurban) { P.smcmax = 0.45f; P.smcref = 0.42f; P.smcwlt = 0.40f; P.csoil = 3.E6f; }
+  if (urban) { P.smcmax = 0.45f; P.smcref = 0.42f; P.smcwlt = 0.40f; P.csoil = 3.E6f; }
+}
+// KDT and FRZX (lsm:9316-9322)
+NMP_DEV float redprm_kdt(const noahmp_tables* T, float dksat) { return T->refkdt_data * dksat / T->refdk_data; }
+NMP_DEV float redprm_frzx(const noahmp_tables* T, const Parm& P) { return T->frzk_data * ((P.smcmax / P.smcref) * (0.412f / 0.468f)); }
+
+// REDPRM lsm:9202-9349: table gather into per-thread registers (the reference writes module globals)
+NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
+  const noahmp_tables* T = c.T;
+  if (soiltyp > T->slcats || soiltyp < 1) { raise(s, NOAHMP_ERR_SOILTYP_RANGE); soiltyp = 1; }
+  if (vegtyp > T->lucats || vegtyp < 1) { raise(s, NOAHMP_ERR_VEGTYP_RANGE); vegtyp = 1; }
+  const int st = soiltyp - 1, vt = vegtyp - 1;
+  redprm_soil(T, st, vegtyp == c.isurban, P);
   P.zbot = T->zbot_data;
   P.czil = T->czil_data;
   P.topt = T->topt_data;
@@ -40,10 +49,33 @@ NMP_DEV void redprm_water(const Ctx& c, Parm& P, int soiltyp) {
   const int st = soiltyp - 1;
   P.dksat = T->satdk[st];
   P.dwsat = T->satdw[st];
-  P.kdt = T->refkdt_data * P.dksat / T->refdk_data;
+  P.kdt = c.D->kdt[st];                               // = redprm_kdt(T, DKSAT), evaluated per soil type by derive_tables
   P.slope = T->slope_data[0];                         // SLOPETYP = 1 (drv:525)
-  P.frzx = T->frzk_data * ((P.smcmax / P.smcref) * (0.412f / 0.468f));
+  P.frzx = c.D->frzx[P.u][st];                        // = redprm_frzx(T, P)
 }
+
+#ifndef __HIPCC_RTC__
+// HOST: the per-type constants of `Derived`, by the functions the device code ran per column before round 3
+inline void derive_tables(const noahmp_tables& T, Derived& D) {
+  memset(&D, 0, sizeof D);
+  for (int st = 0; st < NSLT; st++) {
+    for (int u = 0; u < 2; u++) {
+      Parm P = {};
+      redprm_soil(&T, st, u == 1, P);
+      D.thks_pow[u][st] = tdfcnd_thks_pow(P);
+      D.thkdry[u][st] = tdfcnd_thkdry(P);
+      D.d_rsurf[u][st] = rsurf_dry_layer(P);
+      D.frzx[u][st] = redprm_frzx(&T, P);
+      D.r_smcmax[u][st] = 1.0 / (double)P.smcmax;
+      D.r_refwlt[u][st] = 1.0 / (double)(P.smcref - P.smcwlt);
+    }
+    D.kdt[st] = redprm_kdt(&T, T.satdk[st]);
+    D.neg_inv_bexp[st] = -1.f / T.bb[st];
+    D.r_psisat[st] = 1.0 / (double)T.satpsi[st];
+  }
+  for (int v = 0; v < NVEGT; v++) leaf_orientation(T.xl[v], D.chil[v], D.phi1[v], D.phi2[v], D.avmu[v]);
+}
+#endif
 
 // PHENOLOGY lsm:1010-1104
 NMP_DEV void phenology(const Ctx& c, Col& s) {

@@ -134,8 +134,12 @@ void noahmp_hip_free(void* p) { if (p) hipFree(p); }
 int noahmp_hip_set_tables(const noahmp_tables* t) {
   int rc = ensure_init();
   if (rc) return rc;
-  if (!g.d_tables) HIPCHK(hipMalloc(&g.d_tables, sizeof(noahmp_tables)));
-  HIPCHK(hipMemcpy(g.d_tables, t, sizeof(noahmp_tables), hipMemcpyHostToDevice));
+  // the ABI struct followed by the per-type constants derived from it (Derived, nmp_dev_common.hpp), evaluated here on the host
+  static nmp::TablesDev img;
+  img.t = *t;
+  nmp::derive_tables(img.t, img.d);
+  if (!g.d_tables) HIPCHK(hipMalloc((void**)&g.d_tables, sizeof(nmp::TablesDev)));
+  HIPCHK(hipMemcpy(g.d_tables, &img, sizeof(nmp::TablesDev), hipMemcpyHostToDevice));
   g.have_tables = true;
   return 0;
 }
@@ -218,6 +222,7 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
   k.yearlen = 365;                                                                 // drv:381-390
   if (a->yr % 4 == 0) { k.yearlen = 366; if (a->yr % 100 == 0) { k.yearlen = 365; if (a->yr % 400 == 0) k.yearlen = 366; } }
   k.c.T = g.d_tables;
+  k.c.D = derived_of(g.d_tables);
   k.c.O = Opt{a->idveg, a->iopt_crs, a->iopt_btr, a->iopt_run, a->iopt_sfc, a->iopt_frz, a->iopt_inf,
               a->iopt_rad, a->iopt_alb, a->iopt_snf, a->iopt_tbot, a->iopt_stc};
   k.c.dt = a->dt;

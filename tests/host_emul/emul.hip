@@ -11,9 +11,10 @@
 
 using namespace nmp;
 
-static noahmp_tables g_t;
+static TablesDev g_img;
+#define g_t g_img.t
 
-extern "C" int emul_set_tables(const noahmp_tables* t) { g_t = *t; return 0; }
+extern "C" int emul_set_tables(const noahmp_tables* t) { g_img.t = *t; derive_tables(g_img.t, g_img.d); return 0; }
 
 extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
   memset(st, 0, sizeof(*st));
@@ -30,6 +31,7 @@ extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
   k.yearlen = 365;
   if (a->yr % 4 == 0) { k.yearlen = 366; if (a->yr % 100 == 0) { k.yearlen = 365; if (a->yr % 400 == 0) k.yearlen = 366; } }
   k.c.T = &g_t;
+  k.c.D = &g_img.d;
   k.c.O = Opt{a->idveg, a->iopt_crs, a->iopt_btr, a->iopt_run, a->iopt_sfc, a->iopt_frz, a->iopt_inf,
               a->iopt_rad, a->iopt_alb, a->iopt_snf, a->iopt_tbot, a->iopt_stc};
   k.c.dt = a->dt;
