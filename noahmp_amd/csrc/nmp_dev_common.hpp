@@ -72,10 +72,22 @@ NMP_DEV float nmp_min(float a, float b) { return a < b ? a : b; }
 
 #if NMP_EXACT_LIBM
 NMP_DEV float nmp_expf(float x) { NMP_CNT(0); return libm::expf_(x); }
+NMP_DEV float nmp_expf_const(float x) { NMP_CNT(0); return libm::expf_k_(x); }     // compile-time argument: folds
 NMP_DEV float nmp_logf(float x) { NMP_CNT(1); return libm::logf_(x); }
 // N independent LOG / EXP evaluated together (same arithmetic; the table look-ups of the batch share one LDS latency)
 template <int N> NMP_DEV void nmp_logfN(const float* x, float* out) { for (int n = 0; n < N; n++) NMP_CNT(1); libm::logfN_<N>(x, out); }
 template <int N> NMP_DEV void nmp_expfN(const float* x, float* out) { for (int n = 0; n < N; n++) NMP_CNT(0); libm::expfN_<N>(x, out); }
+template <int N> NMP_DEV void nmp_powfN(const float* x, const float* y, float* out) { for (int n = 0; n < N; n++) NMP_CNT(2); libm::powfN_<N>(x, y, out); }
+// BASE ** y for compile-time positive bases (log2 BASE folds at compile time), and pairs x ** y1, x ** y2 with a shared log2 x
+#define NMP_LOG2K(base) libm::powf_log2_k(libm::asuint(base))
+template <int N> NMP_DEV void nmp_powf_constbaseN(const float* base, const double* log2base, const float* y, float* out) {
+  for (int n = 0; n < N; n++) NMP_CNT(2);
+  libm::powf_constbaseN_<N>(base, log2base, y, out);
+}
+template <int N> NMP_DEV void nmp_powf_pairN(const float* x, float y1, float y2, float* o1, float* o2) {
+  for (int n = 0; n < 2 * N; n++) NMP_CNT(2);
+  libm::powf_pairN_<N>(x, y1, y2, o1, o2);
+}
 NMP_DEV float nmp_powf(float x, float y) { NMP_CNT(2); return libm::powf_(x, y); }
 NMP_DEV float nmp_log10f(float x) { NMP_CNT(3); return libm::log10f_(x); }
 NMP_DEV float nmp_atanf(float x) { NMP_CNT(4); return libm::atanf_(x); }
@@ -85,7 +97,12 @@ NMP_DEV float nmp_acosf(float x) { return libm::acosf_(x); }
 NMP_DEV float nmp_cosf(float x) { return libm::cosf_(x); }
 // x**0.25, x**0.5, x**-0.25 with a literal exponent (SFCDIF1, RAGRB): the reference calls powf
 NMP_DEV float pow_quarter(float x) { NMP_CNT(6); return libm::powf_(x, 0.25f); }
-NMP_DEV void pow_quarter2(float x1, float x2, float& r1, float& r2) { NMP_CNT(6); NMP_CNT(6); libm::powf2_(x1, 0.25f, x2, 0.25f, r1, r2); }
+NMP_DEV void pow_quarter2(float x1, float x2, float& r1, float& r2) {
+  NMP_CNT(6); NMP_CNT(6);
+  const float x[2] = {x1, x2}, y[2] = {0.25f, 0.25f}; float o[2];
+  libm::powfN_<2>(x, y, o);
+  r1 = o[0]; r2 = o[1];
+}
 NMP_DEV float pow_half(float x) { NMP_CNT(6); return libm::powf_(x, 0.5f); }
 // X**2. with a REAL exponent: the pinned reference build calls powf(X, 2.0), whose glibc result differs from the correctly
 // rounded X*X by one ulp for 0.07 % of the arguments (lsm:1536, 2004, 5664, 6325; gla:490, 695).
@@ -93,9 +110,14 @@ NMP_DEV float pow_two(float x) { NMP_CNT(6); return libm::powf_(x, 2.0f); }
 NMP_DEV float pow_neg_quarter(float x) { NMP_CNT(6); return libm::powf_(x, -0.25f); }
 #else
 NMP_DEV float nmp_expf(float x) { return expf(x); }
+NMP_DEV float nmp_expf_const(float x) { return expf(x); }
 NMP_DEV float nmp_logf(float x) { return logf(x); }
 template <int N> NMP_DEV void nmp_logfN(const float* x, float* out) { for (int n = 0; n < N; n++) out[n] = logf(x[n]); }
 template <int N> NMP_DEV void nmp_expfN(const float* x, float* out) { for (int n = 0; n < N; n++) out[n] = expf(x[n]); }
+template <int N> NMP_DEV void nmp_powfN(const float* x, const float* y, float* out) { for (int n = 0; n < N; n++) out[n] = powf(x[n], y[n]); }
+#define NMP_LOG2K(base) 0.0
+template <int N> NMP_DEV void nmp_powf_constbaseN(const float* base, const double*, const float* y, float* out) { for (int n = 0; n < N; n++) out[n] = powf(base[n], y[n]); }
+template <int N> NMP_DEV void nmp_powf_pairN(const float* x, float y1, float y2, float* o1, float* o2) { for (int n = 0; n < N; n++) { o1[n] = powf(x[n], y1); o2[n] = powf(x[n], y2); } }
 NMP_DEV float nmp_powf(float x, float y) { return powf(x, y); }
 NMP_DEV float nmp_log10f(float x) { return log10f(x); }
 NMP_DEV float nmp_atanf(float x) { return atanf(x); }

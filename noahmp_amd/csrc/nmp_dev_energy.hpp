@@ -39,11 +39,10 @@ NMP_DEV float tdfcnd_thkdry(const Parm& P) {           // lsm:2100-2101: depends
   float gammd = (1.f - P.smcmax) * 2700.f;
   return (0.135f * gammd + 64.7f) / (2700.f - 0.947f * gammd);
 }
-NMP_DEV float tdfcnd(const Parm& P, double r_smcmax, float thks_pow, float thkdry, float smc, float sh2o) {
+// pw_ice = TKICE ** (SMCMAX - XU), pw_liq = 0.57 ** XU with XU = (SH2O / SMC) SMCMAX: evaluated by the caller for its four layers at once
+NMP_DEV float tdfcnd(const Parm& P, double r_smcmax, float thks_pow, float thkdry, float smc, float sh2o, float pw_ice, float pw_liq) {
   float satratio = div_rc(smc, r_smcmax);
-  float xunfroz = sh2o / smc;
-  float xu = xunfroz * P.smcmax;
-  float thksat = thks_pow * nmp_powf(TKICE, P.smcmax - xu) * nmp_powf(0.57f, xu);
+  float thksat = thks_pow * pw_ice * pw_liq;
   float ake;
   if ((sh2o + 0.0005f) < smc) ake = satratio;
   else ake = (satratio > 0.1f) ? (nmp_log10f(satratio) + 1.0f) : 0.0f;
@@ -70,12 +69,24 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
   const bool urban = (s.vegtyp == c.isurban);
   const float thks_pow = c.D->thks_pow[P.u][P.st], thkdry = c.D->thkdry[P.u][P.st];     // per soil type (Derived)
   const double r_smcmax = c.D->r_smcmax[P.u][P.st];
+  // TDFCND of the four soil layers: TKICE ** (SMCMAX - XU) and 0.57 ** XU have compile-time bases (their log2 folds), the eight exp2
+  // look-ups form one batch
+  float pw_y[2 * NSOIL], pw[2 * NSOIL], pw_b[2 * NSOIL];
+  double pw_l[2 * NSOIL];
+#pragma unroll
+  for (int iz = 1; iz <= NSOIL; iz++) {
+    const float smc = y.smc[L(iz)], sh2o = y.sh2o[L(iz)];
+    const float xu = (sh2o / smc) * P.smcmax;
+    pw_b[2 * iz - 2] = TKICE; pw_l[2 * iz - 2] = NMP_LOG2K(TKICE); pw_y[2 * iz - 2] = P.smcmax - xu;
+    pw_b[2 * iz - 1] = 0.57f; pw_l[2 * iz - 1] = NMP_LOG2K(0.57f); pw_y[2 * iz - 1] = xu;
+  }
+  if (!urban) nmp_powf_constbaseN<2 * NSOIL>(pw_b, pw_l, pw_y, pw);
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     float smc = y.smc[L(iz)], sh2o = y.sh2o[L(iz)];
     float sice = smc - sh2o;
     hcpct[L(iz)] = sh2o * CWAT + (1.0f - P.smcmax) * P.csoil + (P.smcmax - smc) * CPAIR + sice * CICE;
-    df[L(iz)] = urban ? 3.24f : tdfcnd(P, r_smcmax, thks_pow, thkdry, smc, sh2o);
+    df[L(iz)] = urban ? 3.24f : tdfcnd(P, r_smcmax, thks_pow, thkdry, smc, sh2o, pw[2 * iz - 2], pw[2 * iz - 1]);
   }
 #pragma unroll
   for (int iz = -2; iz <= NSOIL; iz++)
@@ -93,8 +104,8 @@ NMP_DEV void snow_age(float dt, float tg, float sneqvo, float sneqv, float& taus
   else {
     float dela0 = 1.E-6f * dt;
     float arg = 5.E3f * (1.f / TFRZ - 1.f / tg);
-    float age1 = nmp_expf(arg);
-    float age2 = nmp_expf(nmp_min(0.f, 10.f * arg));
+    float age1, age2;
+    { const float aa[2] = {arg, nmp_min(0.f, 10.f * arg)}; float ae[2]; nmp_expfN<2>(aa, ae); age1 = ae[0]; age2 = ae[1]; }
     float tage = age1 + age2 + 0.3f;
     float dela = dela0 * tage;
     float dels = nmp_max(0.0f, sneqv - sneqvo) / SWEMX;
@@ -171,7 +182,8 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
   float sigma = tmp0 * tmp0 - tmp1;
   if (fabsf(sigma) < 1.e-6f) sigma = copysignf(1.e-6f, sigma);
   float p1 = b + avmu * h, p2 = b - avmu * h, p3 = b + tmp0, p4 = b - tmp0;
-  float s1 = nmp_expf(-h * vai), s2 = nmp_expf(-ext * vai);
+  float s1, s2;
+  { const float sa[2] = {-h * vai, -ext * vai}; float se[2]; nmp_expfN<2>(sa, se); s1 = se[0]; s2 = se[1]; }
   float alb = (ic == 0) ? albgrd : albgri;
   float u1 = b - cc / alb, u2 = b - cc * alb, u3 = f + cc * alb;
   tmp2 = u1 - avmu * h;
@@ -262,7 +274,9 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
     float gdir = 0.f;
 #pragma unroll 1
     for (int ib = 0; ib < 2; ib++) {
-#pragma unroll 1
+      // the direct (ic = 0) and the diffuse (ic = 1) call of a band share everything up to the ground albedo: unrolled, the compiler
+      // evaluates the common part once (same operations, same bits)
+#pragma unroll
       for (int ic = 0; ic < 2; ic++) {
         TwoStreamOut o = twostream(c, ic, v, s.cosz, vai, s.fwet, s.tv, albgrd[ib], albgri[ib],
                                    rho[ib], tau[ib], T->omegas[ib], s.fveg, gdir, s.bgap, s.wgap);
@@ -455,8 +469,11 @@ NMP_DEV StomataT stomata_temperature(const Ctx& c, int v, float tv, float o2) {
   const noahmp_tables* T = c.T;
   StomataT r;
   float tc = tv - TFRZ;
-  float kc = T->kc25[v] * nmp_powf(T->akc[v], (tc - 25.0f) / 10.0f);
-  float ko = T->ko25[v] * nmp_powf(T->ako[v], (tc - 25.0f) / 10.0f);
+  const float ex = div_rc(tc - 25.0f, NMP_RCC(10.0f));
+  float pk[2];
+  { const float pb[2] = {T->akc[v], T->ako[v]}, py[2] = {ex, ex}; nmp_powfN<2>(pb, py, pk); }    // AKC ** ex, AKO ** ex as one batch
+  float kc = T->kc25[v] * pk[0];
+  float ko = T->ko25[v] * pk[1];
   r.awc = kc * (1.0f + o2 / ko);
   r.cp = 0.5f * kc / ko * o2 * 0.21f;
   // VCMX = VCMX25 / F2(TC) * FNF * BTRAN * AVCMX**((TC-25)/10): the first quotient and the last factor are kept
@@ -612,7 +629,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     float avcmx_pow = 0.f;
     if (c.O.crs == 1 && (f->parsun > 0.0f || f->parsha > 0.0f)) {   // STOMATA returns early for APAR <= 0
       st = stomata_temperature(c, f->v, L.tv, f->o2air);
-      avcmx_pow = nmp_powf(c.T->avcmx[f->v], ((L.tv - TFRZ) - 25.0f) / 10.0f);
+      avcmx_pow = nmp_powf(c.T->avcmx[f->v], div_rc((L.tv - TFRZ) - 25.0f, NMP_RCC(10.0f)));
     }
 #pragma unroll 1
     for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
@@ -1006,14 +1023,30 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
 #pragma unroll
   for (int j = -2; j <= NSOIL; j++)
     if (j > isnow) { wice0[L(j)] = mice[L(j)]; wmass0[L(j)] = mice[L(j)] + mliq[L(j)]; }
+  if (c.O.frz == 1) {          // the four layers' (SMP / PSISAT) ** (-1 / BEXP) as one batch; layers at or above TFRZ get the benign base 1
+    float sx[NSOIL], sy[NSOIL], sp[NSOIL];
+    bool any = false;
+#pragma unroll
+    for (int j = 1; j <= NSOIL; j++) {
+      const bool frozen = stc[L(j)] < TFRZ;
+      const float smp = HFUS * (TFRZ - stc[L(j)]) / (GRAV * stc[L(j)]);
+      sx[j - 1] = frozen ? div_rc(smp, c.D->r_psisat[P.st]) : 1.0f;
+      sy[j - 1] = c.D->neg_inv_bexp[P.st];
+      any = any || frozen;
+    }
+    if (any) {
+      nmp_powfN<NSOIL>(sx, sy, sp);
+#pragma unroll
+      for (int j = 1; j <= NSOIL; j++)
+        if (stc[L(j)] < TFRZ) {
+          supercool[L(j)] = P.smcmax * sp[j - 1];
+          supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;
+        }
+    }
+  }
 #pragma unroll
   for (int j = 1; j <= NSOIL; j++) {
     if (c.O.frz == 1) {
-      if (stc[L(j)] < TFRZ) {
-        float smp = HFUS * (TFRZ - stc[L(j)]) / (GRAV * stc[L(j)]);
-        supercool[L(j)] = P.smcmax * nmp_powf(div_rc(smp, c.D->r_psisat[P.st]), c.D->neg_inv_bexp[P.st]);
-        supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;
-      }
     } else {
       supercool[L(j)] = frh2o(P, stc[L(j)], y.smc[L(j)], y.sh2o[L(j)]);
       supercool[L(j)] = supercool[L(j)] * y.dzsnso[L(j)] * 1000.f;

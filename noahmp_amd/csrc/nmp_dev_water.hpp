@@ -287,11 +287,14 @@ NMP_DEV void compact(const Ctx& c, const Col& s, const Lay<A>& y) {
       if (void_ > 0.001f && snice > 0.1f) {
         float bi = snice / dz;
         float td = nmp_max(0.f, TFRZ - y.stc[L(j)]);
-        float dexpf = nmp_expf(-C4 * td);
+        const float ca[3] = {-C4 * td, -46.0E-3f * (bi - DM), -0.08f * td - C2 * bi};
+        float ce[3];
+        nmp_expfN<3>(ca, ce);                  // (the second one is used only above DM: evaluating it anyway costs nothing extra)
+        float dexpf = ce[0];
         float ddz1 = -C3 * dexpf, ddz3;
-        if (bi > DM) ddz1 = ddz1 * nmp_expf(-46.0E-3f * (bi - DM));
+        if (bi > DM) ddz1 = ddz1 * ce[1];
         if (snliq > 0.01f * dz) ddz1 = ddz1 * C5;
-        float ddz2 = div_rc(-(burden + 0.5f * wx) * nmp_expf(-0.08f * td - C2 * bi), NMP_RCC(ETA0));
+        float ddz2 = div_rc(-(burden + 0.5f * wx) * ce[2], NMP_RCC(ETA0));
         if (y.imelt[L(j)] == 1.f) {
           float fo = y.ficeold[L(j)];
           ddz3 = nmp_max(0.f, (fo - fice) / nmp_max(1.E-6f, fo));
@@ -487,11 +490,14 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     rsat = rsat + nmp_max(0.f, sh2o[L(k)] - epore) * dz[L(k)];
     sh2o[L(k)] = nmp_min(epore, sh2o[L(k)]);
   }
-  const float ea4 = nmp_expf(-4.0f);
+  const float ea4 = nmp_expf_const(-4.0f);
+  float fcr_arg[NSOIL], fcr_exp[NSOIL];
+#pragma unroll
+  for (int k = 1; k <= NSOIL; k++) fcr_arg[k - 1] = -4.0f * (1.f - nmp_min(1.0f, div_rc(sice[L(k)], r_smcmax)));
+  nmp_expfN<NSOIL>(fcr_arg, fcr_exp);          // the four layers' EXP as one batch
 #pragma unroll
   for (int k = 1; k <= NSOIL; k++) {
-    float fice = nmp_min(1.0f, div_rc(sice[L(k)], r_smcmax));
-    fcr[L(k)] = div_rc(nmp_max(0.0f, nmp_expf(-4.0f * (1.f - fice)) - ea4), c.u.one_m_ea4);
+    fcr[L(k)] = div_rc(nmp_max(0.0f, fcr_exp[k - 1] - ea4), c.u.one_m_ea4);
     if (sice[L(k)] > sicemax) sicemax = sice[L(k)];
     if (fcr[L(k)] > fcrmax) fcrmax = fcr[L(k)];
   }
@@ -509,7 +515,7 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
       wd2 = wd2 + P.smcmax * (1.f - nmp_powf(temp, -1.f / P.bexp)) * dzfine;
       if (fabsf(wd2 - wd1) <= 0.01f) { s.zwt = zfine; break; }
     }
-    s.runsub = (1.0f - fcrmax) * 4.0f * nmp_expf(-TIMEAN) * nmp_expf(-2.0f * s.zwt);
+    s.runsub = (1.0f - fcrmax) * 4.0f * nmp_expf_const(-TIMEAN) * nmp_expf(-2.0f * s.zwt);
   }
   if (s.vegtyp == c.isurban) fcr[L(1)] = 0.95f;
   if (c.O.run == 1 || c.O.run == 2 || c.O.run == 4 || c.O.run == 5) {
@@ -586,10 +592,22 @@ NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, flo
     // ---- SRT
     float wdf[NL], smx[NL], ddz[NL], dsmdz[NL], ai[NL], bi[NL], ci[NL], rhstt[NL];
     float smxwtd = 0.f;
+    if (c.O.inf == 1) {        // WDFCND1 of the four layers as one batch: 4 log2 look-ups, then 8 exp2 look-ups (nmp_powf_pairN)
+      float factr[NSOIL], pw1[NSOIL], pw2[NSOIL];
 #pragma unroll
-    for (int k = 1; k <= NSOIL; k++) {
-      if (c.O.inf == 1) { wdfcnd1(P, r_smcmax, wdf[L(k)], wcnd[L(k)], smc[L(k)], fcr[L(k)]); smx[L(k)] = smc[L(k)]; }
-      else { wdfcnd2(P, r_smcmax, wdf[L(k)], wcnd[L(k)], sh2o[L(k)], sicemax); smx[L(k)] = sh2o[L(k)]; }
+      for (int k = 1; k <= NSOIL; k++) factr[k - 1] = nmp_max(0.01f, div_rc(smc[L(k)], r_smcmax));
+      nmp_powf_pairN<NSOIL>(factr, P.bexp + 2.0f, 2.0f * P.bexp + 3.0f, pw1, pw2);
+#pragma unroll
+      for (int k = 1; k <= NSOIL; k++) {
+        wdf[L(k)] = P.dwsat * pw1[k - 1];
+        wdf[L(k)] = wdf[L(k)] * (1.0f - fcr[L(k)]);
+        wcnd[L(k)] = P.dksat * pw2[k - 1];
+        wcnd[L(k)] = wcnd[L(k)] * (1.0f - fcr[L(k)]);
+        smx[L(k)] = smc[L(k)];
+      }
+    } else {
+#pragma unroll
+      for (int k = 1; k <= NSOIL; k++) { wdfcnd2(P, r_smcmax, wdf[L(k)], wcnd[L(k)], sh2o[L(k)], sicemax); smx[L(k)] = sh2o[L(k)]; }
     }
     if (c.O.run == 5) smxwtd = (c.O.inf == 1) ? s.smcwtd : s.smcwtd * sh2o[L(NSOIL)] / smc[L(NSOIL)];
 #pragma unroll
@@ -756,7 +774,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
     for (int iz = 2; iz <= NSOIL; iz++)
       if (!found && s.zwt <= -c.zsoil[L(iz)]) { iwt = iz - 1; found = true; }
   }
-  qdis = (1.0f - fcrmax) * 5.0f * nmp_expf(-TIMEAN) * nmp_expf(-6.0f * (s.zwt - 2.0f));
+  qdis = (1.0f - fcrmax) * 5.0f * nmp_expf_const(-TIMEAN) * nmp_expf(-6.0f * (s.zwt - 2.0f));
   float smc_iwt = (iwt == 1) ? smc[L(1)] : (iwt == 2) ? smc[L(2)] : (iwt == 3) ? smc[L(3)] : smc[L(4)];
   float hk_iwt = (iwt == 1) ? hk[L(1)] : (iwt == 2) ? hk[L(2)] : (iwt == 3) ? hk[L(3)] : hk[L(4)];
   float zn_iwt = (iwt == 1) ? znode[L(1)] : (iwt == 2) ? znode[L(2)] : (iwt == 3) ? znode[L(3)] : znode[L(4)];
