@@ -57,10 +57,35 @@ const char* kNames[12] = {"DVEG", "CRS", "BTR", "RUN", "SFC", "FRZ", "INF", "RAD
 #ifndef NMP_LIBM_LDS
 #define NMP_LIBM_LDS 1
 #endif
+// Experiment builds (build(extra_flags=...)) define further macros the kernel headers read: they travel too, so that a run-time
+// compiled kernel never runs other physics than this library's ahead-of-time ones.
 const char* kBuildMacros =
     "#define NMP_EXACT_LIBM " NMP_STR(NMP_EXACT_LIBM) "\n"
     "#define NMP_WAVES_PER_EU " NMP_STR(NMP_WAVES_PER_EU) "\n"
-    "#define NMP_LIBM_LDS " NMP_STR(NMP_LIBM_LDS) "\n";
+    "#define NMP_LIBM_LDS " NMP_STR(NMP_LIBM_LDS) "\n"
+#ifdef NMP_TRUNC
+    "#define NMP_TRUNC " NMP_STR(NMP_TRUNC) "\n"
+#endif
+#ifdef NMP_TRUNC_LIGHT
+    "#define NMP_TRUNC_LIGHT 1\n"
+#endif
+#ifdef NMP_SKIP_ENERGY
+    "#define NMP_SKIP_ENERGY 1\n"
+#endif
+#ifdef NMP_EXP_STOMATA_ITERS
+    "#define NMP_EXP_STOMATA_ITERS " NMP_STR(NMP_EXP_STOMATA_ITERS) "\n"
+#endif
+#ifdef NMP_PHASE_TIMERS
+    "#define NMP_PHASE_TIMERS 1\n"
+#endif
+    ;
+// the wrapper around the headers (kernel names, launch bounds): part of the cache key like the headers themselves
+const char* kWrapper =
+    "#include \"nmp_kernel.hpp\"\n"
+    "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m0(const nmp::KArgs k) {\n"
+    "  column_kernel_body<256, true, 0>(k); }\n"
+    "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m1(const nmp::KArgs k) {\n"
+    "  column_kernel_body<256, true, 1>(k); }\n";
 const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
 
 uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -100,6 +125,7 @@ uint64_t source_hash() {
   std::sort(files.begin(), files.end());
   files.push_back(dir + "/../../include/noahmp_hip.h");
   uint64_t acc = fnv1a(kBuildMacros, strlen(kBuildMacros));
+  acc = fnv1a(kWrapper, strlen(kWrapper), acc);
   for (const char* f : kCompileFlags) acc = fnv1a(f, strlen(f), acc);
   int major = 0, minor = 0;
   hiprtcVersion(&major, &minor);
@@ -182,12 +208,7 @@ bool compile(const int* o, JitKernels& out, std::string& log) {
       "using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;\n";
   src += kBuildMacros;
   for (int i = 0; i < 12; i++) src += std::string("#define NMP_FIXED_") + kNames[i] + " " + std::to_string(o[i]) + "\n";
-  src +=
-      "#include \"nmp_kernel.hpp\"\n"
-      "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m0(const nmp::KArgs k) {\n"
-      "  column_kernel_body<256, true, 0>(k); }\n"
-      "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m1(const nmp::KArgs k) {\n"
-      "  column_kernel_body<256, true, 1>(k); }\n";
+  src += kWrapper;
   hiprtcProgram prog = nullptr;
   if (hiprtcCreateProgram(&prog, src.c_str(), "nmp_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram"; return false; }
   const std::string dir = source_dir();

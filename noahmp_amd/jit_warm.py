@@ -74,6 +74,8 @@ def _drop_stale():
     if not d or h == "0" * 16:
         return
     d = d.decode()
+    if os.path.realpath(d) != os.path.realpath(os.path.join(ROOT, "noahmp_amd", "csrc", "jit_cache")):
+        return          # a shared directory ($NOAHMP_HIP_CACHE_DIR, ~/.cache) may hold the objects of other library versions: leave it alone
     for f in os.listdir(d):
         if f.startswith("nmp_gfx950_") and f.endswith(".hsaco") and not f.endswith("_" + h + ".hsaco"):
             try:

@@ -17,7 +17,7 @@ SRC = os.path.join(HERE, "host_emul", "div_check.hip")
 LIB = os.path.join(HERE, "host_emul", "libdiv_check.so")
 # the divisors behind NMP_RCC(...) in the physics headers, and the uniform ones of Urc at the namelist values
 CONSTANTS = {"DT=3600": 3600.0, "HVAP": 2.5104E06, "HSUB": 2.8440E06, "HFUS": 0.3336E06, "DENICE": 917.0, "DENH2O": 1000.0, "2.59": 2.59,
-             "1.87E5": 1.87E5, "1.56E5": 1.56E5, "ETA0": 0.8e6, "3": 3.0, "6": 6.0, "ROUS": 0.2, "100": 100.0,
+             "1.87E5": 1.87E5, "1.56E5": 1.56E5, "ETA0": 0.8e6, "3": 3.0, "6": 6.0, "ROUS": 0.2, "100": 100.0, "10": 10.0,
              "E-1": 2.71828 - 1.0, "0.622*HSUB": None, "0.622*HVAP": None, "DT=600": 600.0, "DT=900": 900.0, "DT*HFUS": None,
              "DZ(1)": 0.1, "DZ(2)*1000": None, "ZSOIL(1)-ZSOIL(3)": None}
 
@@ -54,7 +54,7 @@ def _value(name):
 
 def test_every_constant_divisor_of_the_headers_is_listed():
     """NMP_RCC(...) arguments in the physics headers: each one has an entry above (so that a new constant gets its sweep)."""
-    known = {"2.59f", "HVAP", "HSUB", "1.87E5f", "1.56E5f", "DENICE", "DENH2O", "ETA0", "3.f", "6.f", "1000.f", "ROUS", "HFUS", "100.f",
+    known = {"2.59f", "HVAP", "HSUB", "1.87E5f", "1.56E5f", "DENICE", "DENH2O", "ETA0", "3.f", "6.f", "1000.f", "ROUS", "HFUS", "100.f", "10.0f",
              "2.71828f - 1.0f", "0.622f * HSUB", "0.622f * HVAP"}
     seen = set()
     for f in os.listdir(CSRC):

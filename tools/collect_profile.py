@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -24,7 +24,7 @@ KNAME = krow["Name"]                 # the dominant instantiation (land range of
 
 pmc = {}
 meta = {}
-for d in ("fetch", "write", "sq", "sq2"):
+for d in ("fetch", "write", "sq", "sq2", "sq3"):
     fs = glob.glob(os.path.join(src, d, "*_counter_collection.csv")) + glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
@@ -74,7 +74,7 @@ for r in csv.DictReader(open(stats)):
     L.append("| %s | %s | %.0f | %s | %s | %s |" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
 L += ["", "Launch: grid %(Grid_Size)s, workgroup %(Workgroup_Size)s, LDS %(LDS_Block_Size)s B/block, scratch %(Scratch_Size)s B/lane, "
       "VGPR %(VGPR_Count)s, AGPR %(Accum_VGPR_Count)s, SGPR %(SGPR_Count)s (rocprofv3's fields; the compiler's "
-      "`-Rpass-analysis=kernel-resource-usage` report for this kernel is 255 unified VGPRs, 4 spilled, 32 B/lane scratch (option-specialised land-only kernel), 2 waves/SIMD)." % meta, "",
+      "`-Rpass-analysis=kernel-resource-usage` report for this kernel is 256 unified VGPRs, 4 spilled, 32 B/lane scratch (option-specialised land-only kernel), 2 waves/SIMD)." % meta, "",
       "## PMC (separate `--pmc` passes, mean per launch of the column kernel)", "", "| counter | mean per launch |", "|---|---|"]
 for k in sorted(pmc):
     L.append("| %s | %.4g |" % (k, pmc[k]))
@@ -85,10 +85,35 @@ L += ["", "## Derived", "",
       "- VALU instructions per column-step (per wave) = %.0f; lane utilisation %.1f %%; VALU-active %.0f %% and waiting %.0f %% of wave cycles"
       % (out["derived"]["valu_insts_per_column_step"], 100 * out["derived"]["lane_utilisation"],
          100 * out["derived"]["valu_active_share_of_wave_cycles"], 100 * out["derived"]["wait_any_share_of_wave_cycles"]),
-      "- VALU-issue roofline: %.4g wave64 VALU instructions per launch x 2 issue cycles / (1024 SIMDs x 2.4 GHz x %.3f ms) = **%.1f %%** of the chip's VALU issue slots (two waves per SIMD, each issuing at most every 4 cycles)"
-      % (pmc.get("SQ_INSTS_VALU", 0), float(krow["AverageNs"]) / 1e6, 100 * pmc.get("SQ_INSTS_VALU", 0) * 2 / (1024 * 2.4e9 * float(krow["AverageNs"]) * 1e-9)),
-      "- the kernel is VALU-issue / register-occupancy bound, not HBM bound (SURVEY.md 8d): ~5 flop-equivalents per byte with long dependent chains",
+      "- VALU-busy roofline: SQ_ACTIVE_INST_VALU = %.4g quad-cycles per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x %.3f ms) = **%.1f %%** of the kernel's duration "
+      "(a wave64 instruction occupies the 16-lane SIMD for 4 cycles: %.3f quads per VALU instruction measured, float64 / transcendental ones longer)"
+      % (pmc.get("SQ_ACTIVE_INST_VALU", 0), float(krow["AverageNs"]) / 1e6, 100 * pmc.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * 2.4e9 * float(krow["AverageNs"]) * 1e-9),
+         pmc.get("SQ_ACTIVE_INST_VALU", 0) / max(pmc.get("SQ_INSTS_VALU", 1), 1)),
+      "- instruction cache: %.3g misses per %.3g requests (%.2f %%); LDS instructions per wave %.0f; float64 VALU instructions %.1f %% and conversions %.1f %% of all VALU instructions"
+      % (pmc.get("SQC_ICACHE_MISSES", 0), pmc.get("SQC_ICACHE_REQ", 1), 100 * pmc.get("SQC_ICACHE_MISSES", 0) / max(pmc.get("SQC_ICACHE_REQ", 1), 1),
+         pmc.get("SQ_INSTS_LDS", 0) / waves,
+         100 * (pmc.get("SQ_INSTS_VALU_FMA_F64", 0) + pmc.get("SQ_INSTS_VALU_MUL_F64", 0) + pmc.get("SQ_INSTS_VALU_ADD_F64", 0)) / max(pmc.get("SQ_INSTS_VALU", 1), 1),
+         100 * pmc.get("SQ_INSTS_VALU_CVT", 0) / max(pmc.get("SQ_INSTS_VALU", 1), 1)),
+      "- the kernel is bound by VALU work and by the latency of its dependent chains at two waves per SIMD (every wave waits ~%.0f %% of its cycles, mostly on LDS look-ups of the libm tables and the layer arrays), not by HBM (SURVEY.md 8d)"
+      % (100 * out["derived"]["wait_any_share_of_wave_cycles"]),
       "", "## bench.py line of the same build (un-profiled run)", "", "```", json.dumps(bench), "```", ""]
+# ---- the per-step forcing permutation of the bench (six 2-D planes of the whole tile: read + write + 6 B of plan per column)
+ntile = bench["config"]["columns_per_gpu"]
+for r in csv.DictReader(open(stats)):
+    if "noahmp_scatter" in r["Name"]:
+        b = ntile * (6 * 8 + 6)
+        L += ["## Forcing permutation (`%s`, %s calls)" % (r["Name"].split("(")[0].split("::")[-1][:40], r["Calls"]), "",
+              "six planes x %d columns x (4 B read + 4 B written) + 6 B of plan per column = %.0f MB in %.1f us = **%.2f TB/s = %.0f %% of 8 TB/s** (round 2: 203 us, 23 %%)"
+              % (ntile, b / 1e6, float(r["AverageNs"]) / 1e3, b / float(r["AverageNs"]) / 1e3, 100 * b / float(r["AverageNs"]) / 8000), ""]
+for sub, name in (("trace4", "config 4"), ("trace5", "config 5")):
+    fs = glob.glob(os.path.join(src, sub, "*_kernel_stats.csv")) + glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    if fs:
+        shutil.copy(fs[0], os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, sub)))
+        L += ["## %s (`bench.py --workload %s`, copied: %s_%s_kernel_stats.csv)" % (name, name.replace(" ", ""), tag, sub), "",
+              "| kernel | calls | avg ns | % |", "|---|---|---|---|"]
+        for r in list(csv.DictReader(open(fs[0])))[:8]:
+            L.append("| %s | %s | %.0f | %s |" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
+        L.append("")
 # ---- MMF groundwater kernels (tools/gw_check.py perf, 4608 x 1536 cells)
 gws = glob.glob(os.path.join(src, "gw", "*_kernel_stats.csv"))
 if gws:
