@@ -232,6 +232,8 @@ void launch_scatter(const ScatterArgs& k, hipStream_t s) {
   const dim3 grid((unsigned)((ncol + chunk - 1) / chunk));
   if (chunk == 16384) hipLaunchKernelGGL(noahmp_scatter_big_kernel<16384>, grid, dim3(1024), 0, s, k);
   else if (chunk == 8192) hipLaunchKernelGGL(noahmp_scatter_big_kernel<8192>, grid, dim3(1024), 0, s, k);
+  else if (chunk == 4096) hipLaunchKernelGGL(noahmp_scatter_big_kernel<4096>, grid, dim3(1024), 0, s, k);
+  else if (chunk == 2048) hipLaunchKernelGGL(noahmp_scatter_big_kernel<2048>, grid, dim3(1024), 0, s, k);
   else hipLaunchKernelGGL(noahmp_scatter_kernel, grid, dim3(256), 0, s, k);
 }
 }  // namespace
@@ -243,8 +245,10 @@ extern "C" {
 int noahmp_hip_scatter_chunk_of(int ni, int nj) {
   const long ncol = (long)ni * nj;
   if (nj > 65535) return kChunk;                 // the big kernel packs the destination row into 16 bits
-  if (ncol >= 3L * 1024 * 1024) return 16384;        // (32768 would need 2 x 32 registers per thread for the plan: it spills)
-  if (ncol >= 512L * 1024) return 8192;
+  // the largest chunk that still gives the launch ~200 workgroups (256 CUs; a workgroup of 1024 threads fills a CU's LDS share);
+  // 32768 would need 2 x 32 registers per thread for the plan: it spills
+  for (int chunk = 16384; chunk >= 2048; chunk >>= 1)
+    if (ncol >= 200L * chunk) return chunk;
   return kChunk;
 }
 

@@ -61,7 +61,7 @@ def test_device_sort_is_the_stable_sort_of_the_key(engine, tables, kw):
     assert engine.sort_staleness(d) == 0
 
 
-@pytest.mark.parametrize("ni,nj", [(333, 37), (1111, 517), (2051, 1601), (3100, 2049)])     # chunks of 1024 / 8192 / 16384 / 16384 columns
+@pytest.mark.parametrize("ni,nj", [(333, 37), (1111, 517), (1153, 769), (2051, 1601), (3100, 2049)])     # chunks of 1024 / 2048 / 4096 / 16384 / 16384 columns
 def test_scatter_plan_on_device_equals_host_plan(engine, tables, ni, nj):
     import torch
     r = np.random.Generator(np.random.Philox(5))
@@ -73,7 +73,7 @@ def test_scatter_plan_on_device_equals_host_plan(engine, tables, ni, nj):
     dst = [torch.zeros_like(t) for t in src]
     sc = engine.scatter(dst, src, perm, ni, nj)
     chunk = engine.lib.noahmp_hip_scatter_chunk_of(ni, nj)
-    assert chunk == {333: 1024, 1111: 8192, 2051: 16384, 3100: 16384}[ni]
+    assert chunk == {333: 1024, 1111: 2048, 1153: 4096, 2051: 16384, 3100: 16384}[ni]
     inv = np.empty(n, dtype=np.int64)
     inv[p] = np.arange(n)
     npad = (n + chunk - 1) // chunk * chunk

@@ -9,11 +9,11 @@ rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --no-cpu-baseline 2> $O/bench_plain.err | tail -1 > $O/bench_plain.json
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference > $O/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 12 --warmup 2 > $O/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 12 --warmup 2 > $O/bench_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $O/sq -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 12 --warmup 2 > $O/bench_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY -d $O/sq2 -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 12 --warmup 2 > $O/bench_sq2.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_WAIT_INST_LDS -d $O/sq3 -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 12 --warmup 2 > $O/bench_sq3.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 0 > $O/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/write -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 0 > $O/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY -d $O/sq -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 0 > $O/bench_sq.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY -d $O/sq2 -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 0 > $O/bench_sq2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_CVT SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_WAIT_INST_LDS -d $O/sq3 -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-scaling-reference --steps 24 --warmup 0 > $O/bench_sq3.log 2>&1
 # config 4 (the plane exchanges around WTABLE_mmf_noahmp, the groundwater kernels inside a run) and config 5: kernel traces
 rocprofv3 --kernel-trace --stats -d $O/trace4 -o bench --output-format csv -- python3 $R/bench.py --workload config4 --no-cpu-baseline > $O/bench_trace4.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/trace5 -o bench --output-format csv -- python3 $R/bench.py --workload config5 --no-cpu-baseline > $O/bench_trace5.log 2>&1
