@@ -215,6 +215,9 @@ struct Parm {  // REDPRM output (lsm:9282-9335): per-column, in registers instea
   float rgl, rsmin, hs, rsmax, topt;
   float bexp, smcmax, smcref, psisat, dksat, dwsat, smcwlt, quartz;
   float slope, csoil, zbot, czil, kdt, frzx;
+  // per-type constants of `Derived`, fetched in REDPRM's own batch of table gathers (a gather that is waited on later, on its own,
+  // costs a ~1500-cycle round trip at two waves per SIMD; the float64 reciprocals are cheaper to form from registers, rc64: 37 cycles)
+  float thks_pow, thkdry, d_rsurf, chil, phi1, phi2, avmu;
 };
 
 // ---- Exact division through a float64 reciprocal (round 3) --------------------------------------------------------------

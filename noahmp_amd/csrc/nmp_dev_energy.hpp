@@ -67,8 +67,8 @@ NMP_DEV void thermoprop(const Ctx& c, const Parm& P, const Col& s, const Lay<A>&
     }
   }
   const bool urban = (s.vegtyp == c.isurban);
-  const float thks_pow = c.D->thks_pow[P.u][P.st], thkdry = c.D->thkdry[P.u][P.st];     // per soil type (Derived)
-  const double r_smcmax = c.D->r_smcmax[P.u][P.st];
+  const float thks_pow = P.thks_pow, thkdry = P.thkdry;     // per soil type (Derived, fetched by REDPRM)
+  const double r_smcmax = rc64(P.smcmax);
   // TDFCND of the four soil layers: TKICE ** (SMCMAX - XU) and 0.57 ** XU have compile-time bases (their log2 folds), the eight exp2
   // look-ups form one batch
   float pw_y[2 * NSOIL], pw[2 * NSOIL], pw_b[2 * NSOIL];
@@ -127,7 +127,7 @@ NMP_DEV void leaf_orientation(float xl, float& chil, float& phi1, float& phi2, f
 }
 
 // TWOSTREAM lsm:2768-3016 for one band (rho,tau,albgrd,albgri,omegas of that band), ic 0=direct 1=diffuse
-NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float vai, float fwet, float t,
+NMP_DEV TwoStreamOut twostream(const Ctx& c, const Parm& P, int ic, int v, float cosz, float vai, float fwet, float t,
                                float albgrd, float albgri, float rho, float tau, float omegas,
                                float fveg, float& gdir, float& bgap, float& wgap) {
   const noahmp_tables* T = c.T;
@@ -154,7 +154,7 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
     if (c.O.rad == 3) { gap = 1.0f - fveg; kopen = 1.0f - fveg; }
   }
   float coszi = nmp_max(0.001f, cosz);
-  const float chil = c.D->chil[v], phi1 = c.D->phi1[v], phi2 = c.D->phi2[v], avmu = c.D->avmu[v];   // leaf_orientation(XL), per vegetation type
+  const float chil = P.chil, phi1 = P.phi1, phi2 = P.phi2, avmu = P.avmu;   // leaf_orientation(XL), per vegetation type (Derived, fetched by REDPRM)
   gdir = phi1 + phi2 * coszi;
   float ext = gdir / coszi;
   float omegal = rho + tau;
@@ -188,34 +188,38 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
   float u1 = b - cc / alb, u2 = b - cc * alb, u3 = f + cc * alb;
   tmp2 = u1 - avmu * h;
   float tmp3 = u1 + avmu * h;
-  float d1 = p1 * tmp2 / s1 - p2 * tmp3 * s1;
+  // S1, SIGMA, D1, D2 each divide three to five times: one float64 reciprocal each (rc64 / div_rc, nmp_dev_common.hpp)
+  const double r_s1 = rc64(s1), r_sigma = rc64(sigma);
+  float d1 = div_rc(p1 * tmp2, r_s1) - p2 * tmp3 * s1;
   float tmp4 = u2 + avmu * h;
   float tmp5 = u2 - avmu * h;
-  float d2 = tmp4 / s1 - tmp5 * s1;
+  float d2 = div_rc(tmp4, r_s1) - tmp5 * s1;
+  const double r_d1 = rc64(d1), r_d2 = rc64(d2);
   float h1 = -d * p4 - cc * f;
-  float tmp6 = d - h1 * p3 / sigma;
-  float tmp7 = (d - cc - h1 / sigma * (u1 + tmp0)) * s2;
-  float h2 = (tmp6 * tmp2 / s1 - p2 * tmp7) / d1;
-  float h3 = -(tmp6 * tmp3 * s1 - p1 * tmp7) / d1;
+  const float h1_sigma = div_rc(h1, r_sigma);
+  float tmp6 = d - div_rc(h1 * p3, r_sigma);
+  float tmp7 = (d - cc - h1_sigma * (u1 + tmp0)) * s2;
+  float h2 = div_rc(div_rc(tmp6 * tmp2, r_s1) - p2 * tmp7, r_d1);
+  float h3 = -div_rc(tmp6 * tmp3 * s1 - p1 * tmp7, r_d1);
   float h4 = -f * p3 - cc * d;
-  float tmp8 = h4 / sigma;
+  float tmp8 = div_rc(h4, r_sigma);
   float tmp9 = (u3 - tmp8 * (u2 - tmp0)) * s2;
-  float h5 = -(tmp8 * tmp4 / s1 + tmp9) / d2;
-  float h6 = (tmp8 * tmp5 * s1 + tmp9) / d2;
+  float h5 = -div_rc(div_rc(tmp8 * tmp4, r_s1) + tmp9, r_d2);
+  float h6 = div_rc(tmp8 * tmp5 * s1 + tmp9, r_d2);
   float h7 = (cc * tmp2) / (d1 * s1);
-  float h8 = (-cc * tmp3 * s1) / d1;
+  float h8 = div_rc(-cc * tmp3 * s1, r_d1);
   float h9 = tmp4 / (d2 * s1);
-  float h10 = (-tmp5 * s1) / d2;
+  float h10 = div_rc(-tmp5 * s1, r_d2);
   TwoStreamOut o;
   if (ic == 0) {
     o.ftd = s2 * (1.0f - gap) + gap;
-    o.fti = (h4 * s2 / sigma + h5 * s1 + h6 / s1) * (1.0f - gap);
-    o.fre = (h1 / sigma + h2 + h3) * (1.0f - gap) + albgrd * gap;
-    o.frev = (h1 / sigma + h2 + h3) * (1.0f - gap);
+    o.fti = (div_rc(h4 * s2, r_sigma) + h5 * s1 + div_rc(h6, r_s1)) * (1.0f - gap);
+    o.fre = (h1_sigma + h2 + h3) * (1.0f - gap) + albgrd * gap;
+    o.frev = (h1_sigma + h2 + h3) * (1.0f - gap);
     o.freg = albgrd * gap;
   } else {
     o.ftd = 0.f;
-    o.fti = (h9 * s1 + h10 / s1) * (1.0f - kopen) + kopen;
+    o.fti = (h9 * s1 + div_rc(h10, r_s1)) * (1.0f - kopen) + kopen;
     o.fre = (h7 + h8) * (1.0f - kopen) + albgri * kopen;
     o.frev = (h7 + h8) * (1.0f - kopen) + albgri * kopen;
     o.freg = 0.f;
@@ -227,7 +231,7 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, int ic, int v, float cosz, float va
 struct RadOut { float fsun, laisun, laisha, parsun, parsha; };
 
 // RADIATION lsm:2120-2240 (ALBEDO lsm:2243-2423 + SURRAD lsm:2426-2544)
-NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
+NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1) {
   const noahmp_tables* T = c.T;
   const int v = s.vegtyp - 1;
   const float MPE = 1.E-6f;
@@ -278,7 +282,7 @@ NMP_DEV RadOut radiation(const Ctx& c, Col& s, float smc1) {
       // evaluates the common part once (same operations, same bits)
 #pragma unroll
       for (int ic = 0; ic < 2; ic++) {
-        TwoStreamOut o = twostream(c, ic, v, s.cosz, vai, s.fwet, s.tv, albgrd[ib], albgri[ib],
+        TwoStreamOut o = twostream(c, P, ic, v, s.cosz, vai, s.fwet, s.tv, albgrd[ib], albgri[ib],
                                    rho[ib], tau[ib], T->omegas[ib], s.fveg, gdir, s.bgap, s.wgap);
         if (ic == 0) { fabd[ib] = o.fab; albd[ib] = o.fre; ftdd[ib] = o.ftd; ftid[ib] = o.fti;
                        frevd[ib] = o.frev; fregd[ib] = o.freg; }
@@ -1026,12 +1030,14 @@ NMP_DEV void phasechange(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
   if (c.O.frz == 1) {          // the four layers' (SMP / PSISAT) ** (-1 / BEXP) as one batch; layers at or above TFRZ get the benign base 1
     float sx[NSOIL], sy[NSOIL], sp[NSOIL];
     bool any = false;
+    const double r_psisat = rc64(P.psisat);
+    const float neg_inv_bexp = -1.f / P.bexp;
 #pragma unroll
     for (int j = 1; j <= NSOIL; j++) {
       const bool frozen = stc[L(j)] < TFRZ;
       const float smp = HFUS * (TFRZ - stc[L(j)]) / (GRAV * stc[L(j)]);
-      sx[j - 1] = frozen ? div_rc(smp, c.D->r_psisat[P.st]) : 1.0f;
-      sy[j - 1] = c.D->neg_inv_bexp[P.st];
+      sx[j - 1] = frozen ? div_rc(smp, r_psisat) : 1.0f;
+      sy[j - 1] = neg_inv_bexp;
       any = any || frozen;
     }
     if (any) {
@@ -1185,7 +1191,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   NMP_TIC(2);    // energy: preamble
   thermoprop(c, P, s, y, df, hcpct, fact);
   NMP_TIC(3);    // thermoprop
-  r = radiation(c, s, y.smc[L(1)]);
+  r = radiation(c, P, s, y.smc[L(1)]);
   NMP_TIC(4);    // radiation
   q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
   q.emv = 1.f - nmp_expf(-(s.elai + s.esai) / 1.0f);
@@ -1193,8 +1199,8 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   // BTRAN lsm:1617-1640
   s.btran = 0.f;
   const float zroot = -c.zsoil[L(P.nroot)];
-  const double r_zroot = c.u.zs[L(P.nroot)], r_smcmax = c.D->r_smcmax[P.u][P.st];
-  const double r_refwlt = (c.O.btr == 1) ? c.D->r_refwlt[P.u][P.st] : 0.0;
+  const double r_zroot = c.u.zs[L(P.nroot)], r_smcmax = rc64(P.smcmax);
+  const double r_refwlt = (c.O.btr == 1) ? rc64(P.smcref - P.smcwlt) : 0.0;
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {
     if (iz <= P.nroot) {
@@ -1222,7 +1228,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
     float sh1 = y.sh2o[L(1)];
     float l_rsurf = div_rc((-c.zsoil[L(1)]) * (nmp_expf(powi5(1.0f - nmp_min(1.0f, div_rc(sh1, r_smcmax)))) - 1.0f),
                            NMP_RCC(2.71828f - 1.0f));
-    float d_rsurf = c.D->d_rsurf[P.u][P.st];           // rsurf_dry_layer(P), per soil type
+    float d_rsurf = P.d_rsurf;                         // rsurf_dry_layer(P), per soil type (Derived, fetched by REDPRM)
     q.rsurf = l_rsurf / d_rsurf;
     if (sh1 < 0.01f && s.snowh == 0.f) q.rsurf = 1.E6f;
     float psi = -P.psisat * nmp_powf(div_rc(nmp_max(0.01f, sh1), r_smcmax), -P.bexp);

@@ -38,6 +38,9 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   P.hs = T->hstbl[vt];
   P.nroot = T->nrotbl[vt];
   if (vegtyp == c.isurban) P.rsmin = 400.0f;
+  const Derived* D = c.D;                                   // same batch of gathers as the table rows above
+  P.thks_pow = D->thks_pow[P.u][st]; P.thkdry = D->thkdry[P.u][st]; P.d_rsurf = D->d_rsurf[P.u][st];
+  P.chil = D->chil[vt]; P.phi1 = D->phi1[vt]; P.phi2 = D->phi2[vt]; P.avmu = D->avmu[vt];
   if (P.nroot > NSOIL) { raise(s, NOAHMP_ERR_NROOT_GT_NSOIL); P.nroot = NSOIL; }
 }
 

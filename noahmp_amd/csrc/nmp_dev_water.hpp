@@ -474,7 +474,7 @@ template <class A>
 NMP_DEV void soilwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float qinsur, float qseva,
                        const float* etrani, float& qdrain, float* wcnd, float& fcrmax) {
   const float dt = c.dt;
-  const double r_smcmax = c.D->r_smcmax[P.u][P.st];      // SMCMAX divides ~20 times below (FICE, WDFCND x 4 layers x NITER)
+  const double r_smcmax = rc64(P.smcmax);      // SMCMAX divides ~20 times below (FICE, WDFCND x 4 layers x NITER)
   float sh2o[NL], smc[NL], sice[NL], dz[NL], fcr[NL];
   float pddum = 0.0f, rsat = 0.0f, sicemax = 0.0f;
   s.runsrf = 0.0f;
