@@ -51,16 +51,19 @@ NMP_DEV Lay<LArr<STRIDE>> make_lay(float* base) {
 #define G3(f, lev, nk) k.a.f[((size_t)jj * (nk) + (lev)) * k.ni + ii]
 
 
-// Classify column t and apply the water / sea-ice shortcuts (drv:399-441).
-// returns 0 land, 1 glacier, 2 skipped, 3 outside the tile
-NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij) {
-  if (t >= (long)k.nti * k.ntj) return 3;
+// memory position of tile column t (no memory access); false: outside the tile
+NMP_DEV bool column_index(const KArgs& k, long t, int& ii, int& jj, size_t& ij) {
+  if (t >= (long)k.nti * k.ntj) return false;
   const int tj = (int)(t / k.nti), ti = (int)(t - (long)tj * k.nti);
   ii = k.a.its - k.a.ims + ti;
   jj = k.a.jts - k.a.jms + tj;
   ij = (size_t)jj * k.ni + ii;
-  const float xland = G2(xland), xice = G2(xice);
-  const int ivg = G2(ivgtyp);
+  return true;
+}
+
+// Classify a column from its XLAND, XICE, IVGTYP and apply the water / sea-ice shortcuts (drv:399-441).
+// returns 0 land, 1 glacier, 2 skipped
+NMP_DEV int column_classify_values(const KArgs& k, float xland, float xice, int ivg, int ii, int jj, size_t ij) {
   int ice = (xice >= k.a.xice_thres) ? 1 : ((ivg == k.a.isice) ? -1 : 0);      // drv:426-432
   const bool water = (xland - 1.5f) >= 0.f;
   if (k.a.itimestep == 1) {                                                      // drv:399-419
@@ -79,6 +82,14 @@ NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij
     return 2;
   }
   return (ice == -1) ? 1 : 0;
+}
+
+// Classify column t (loads its XLAND, XICE, IVGTYP).  returns 0 land, 1 glacier, 2 skipped, 3 outside the tile
+NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij) {
+  if (!column_index(k, t, ii, jj, ij)) return 3;
+  const float xland = G2(xland), xice = G2(xice);
+  const int ivg = G2(ivgtyp);
+  return column_classify_values(k, xland, xice, ivg, ii, jj, ij);
 }
 
 // Outputs that are final once the ENERGY phase is done (nothing in WATER / CARBON / the SFLX tail touches
@@ -119,8 +130,11 @@ NMP_DEV void gather_water_state(const KArgs& k, Col& s, size_t ij) {
 // function too and every phase is guarded by `live`; see DESIGN.md section 6 for the lane-compaction runner that
 // was measured and dropped.
 // MODE 0: any mix of land and glacier columns; 1: land columns only (no glacier code in the kernel); 2: glacier columns only.
-template <int STRIDE, int MODE = 0, class Runner>
-NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base, Runner& runner) {
+// EARLY (class-range kernels, MODE 1 / 2): the caller has NOT classified the column; its XLAND / XICE / IVGTYP travel with the gather,
+// one memory round trip instead of two in a row at the start of every wave, and the class comes back through *cls_out -- a column
+// of another class than the range was declared to hold is left untouched (the caller raises NOAHMP_ERR_CLASS_RANGE).
+template <int STRIDE, int MODE = 0, bool EARLY = false, class Runner>
+NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base, Runner& runner, int* cls_out = nullptr) {
   Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
   // value-initialise (NOT memset(): HIP's device memset is a byte loop through a pointer PHI, which
   // pins the whole struct in scratch and defeats scalar replacement -- 556 B/lane of scratch traffic)
@@ -130,7 +144,10 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   int failed = 0;
   int soiltyp_w = 1;               // the validated soil type, kept for redprm_water
   NMP_TIC0();
-  if (cls <= 1) {
+  float c_xland = 0.f, c_xice = 0.f;
+  int c_ivg = 0;
+  if (EARLY) { c_xland = G2(xland); c_xice = G2(xice); c_ivg = G2(ivgtyp); }
+  if (EARLY || cls <= 1) {
   // ---- gather, drv:449-545
   s.cosz = G2(coszin); s.lat = G2(xlatin);
   s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
@@ -174,6 +191,12 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   s.co2air = 395.e-06f * s.sfcprs;
   s.o2air = 0.209f * s.sfcprs;
   s.foln = 1.0f;
+  if (EARLY) {                                   // everything above was loads: now the class
+    cls = column_classify_values(k, c_xland, c_xice, c_ivg, ii, jj, ij);
+    if (cls_out) *cls_out = cls;
+    if (cls != MODE - 1) return 0;
+    live = (cls == 0);
+  }
   s.ist = 1; s.isc = 4; s.ice = (cls == 1) ? -1 : 0;
   s.yearlen = k.yearlen; s.julian = k.a.julian;
   if (soiltyp == 14 && G2(xice) == 0.f) soiltyp = 7;
@@ -213,7 +236,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
         lh_out = s.fcev + s.fgev + s.fctr;                                         // drv:714
         scatter_energy_outputs(k, s, ij);
         gather_water_state(k, s, ij);
-        redprm_water(k.c, P, soiltyp_w);
+        redprm_water(k.c, P, soiltyp_w, s.vegtyp);
         NMP_TIC(11);   // energy tail + early scatter
         sflx_water(k.c, P, s, y, beg_wb);
         beg_wb_trunc = beg_wb;

@@ -218,6 +218,11 @@ struct Parm {  // REDPRM output (lsm:9282-9335): per-column, in registers instea
   // per-type constants of `Derived`, fetched in REDPRM's own batch of table gathers (a gather that is waited on later, on its own,
   // costs a ~1500-cycle round trip at two waves per SIMD; the float64 reciprocals are cheaper to form from registers, rc64: 37 cycles)
   float thks_pow, thkdry, d_rsurf, chil, phi1, phi2, avmu;
+  // rows of the vegetation tables that later phases read right at their start, fetched in the same batch: PHENOLOGY's monthly
+  // LAI / SAI at the column's two months and HVT / HVB / TMIN, ENERGY's Z0MVT / CWPVT, VEGE_FLUX's DLEAF
+  float lai1, lai2, sai1, sai2, hvt, hvb, tmin, z0mvt, cwpvt, dleaf;
+  float ph_wt1;                     // PHENOLOGY's interpolation weight WT1 (lsm:1065)
+  float ch2op;                      // CANWATER's CH2OP(VEGTYP), fetched with the water-phase rows (redprm_water)
 };
 
 // ---- Exact division through a float64 reciprocal (round 3) --------------------------------------------------------------

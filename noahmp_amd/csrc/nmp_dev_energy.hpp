@@ -741,7 +741,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     if ((L.hcan - q.zpd) <= 0.f) raise(s, NOAHMP_ERR_HCAN_LE_ZPD);
     L.air = -q.emv * (1.f + (1.f - q.emv) * (1.f - q.emg)) * s.lwdn - q.emv * q.emg * SB * powi4(L.tg);
     L.cir = (2.f - q.emv * (1.f - q.emg)) * q.emv * SB;
-    L.sqrt_dleaf_uc = sqrtf(T->dleaf[v] / uc);          // loop-invariant factor of RB (lsm:4054)
+    L.sqrt_dleaf_uc = sqrtf(P.dleaf / uc);          // loop-invariant factor of RB (lsm:4054)
     L.irc = s.irc; L.shc = s.shc; L.evc = s.evc; L.tr = s.tr;
     L.done = 0; L.iter = 1;
     VegFirst f = {&P, v, q.parsun, q.parsha, s.foln, s.o2air, s.co2air, s.igs, s.btran, 0.f, 0.f};
@@ -1178,7 +1178,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   q.z0mg = Z0 * (1.0f - s.fsno) + s.fsno * Z0SNO;
   zpdg = s.snowh;
   if (veg) {
-    q.z0m = T->z0mvt[v];
+    q.z0m = P.z0mvt;
     q.zpd = 0.65f * s.htop;
     if (s.snowh > q.zpd) q.zpd = s.snowh;
   } else {
@@ -1187,7 +1187,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   }
   q.zlvl = nmp_max(q.zpd, s.htop) + s.zlvl;
   if (zpdg >= q.zlvl) q.zlvl = zpdg + s.zlvl;
-  q.cwp = T->cwpvt[v];
+  q.cwp = P.cwpvt;
   NMP_TIC(2);    // energy: preamble
   thermoprop(c, P, s, y, df, hcpct, fact);
   NMP_TIC(3);    // thermoprop

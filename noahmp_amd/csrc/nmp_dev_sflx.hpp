@@ -41,13 +41,29 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   const Derived* D = c.D;                                   // same batch of gathers as the table rows above
   P.thks_pow = D->thks_pow[P.u][st]; P.thkdry = D->thkdry[P.u][st]; P.d_rsurf = D->d_rsurf[P.u][st];
   P.chil = D->chil[vt]; P.phi1 = D->phi1[vt]; P.phi2 = D->phi2[vt]; P.avmu = D->avmu[vt];
+  {                                                         // PHENOLOGY's month interpolation (lsm:1054-1071): its table rows join the batch
+    float day;
+    if (s.lat >= 0.f) day = s.julian;
+    else day = fmodf(s.julian + (0.5f * s.yearlen), (float)s.yearlen);
+    float t = 12.f * day / (float)s.yearlen;
+    int it1 = (int)(t + 0.5f);                              // REAL -> INTEGER truncation (lsm:1063)
+    int it2 = it1 + 1;
+    P.ph_wt1 = (it1 + 0.5f) - t;
+    if (it1 < 1) it1 = 12;
+    if (it2 > 12) it2 = 1;
+    P.lai1 = T->laim[it1 - 1][vt]; P.lai2 = T->laim[it2 - 1][vt];
+    P.sai1 = T->saim[it1 - 1][vt]; P.sai2 = T->saim[it2 - 1][vt];
+  }
+  P.hvt = T->hvt[vt]; P.hvb = T->hvb[vt]; P.tmin = T->tmin[vt];
+  P.z0mvt = T->z0mvt[vt]; P.cwpvt = T->cwpvt[vt]; P.dleaf = T->dleaf[vt];
   if (P.nroot > NSOIL) { raise(s, NOAHMP_ERR_NROOT_GT_NSOIL); P.nroot = NSOIL; }
 }
 
 // The REDPRM outputs only the WATER phase reads (DKSAT, DWSAT, KDT, SLOPE, FRZX; lsm:9286-9287, 9316-9322): looked up when
 // that phase starts, so that they do not sit in registers through ENERGY.  `soiltyp` as REDPRM validated it.
-NMP_DEV void redprm_water(const Ctx& c, Parm& P, int soiltyp) {
+NMP_DEV void redprm_water(const Ctx& c, Parm& P, int soiltyp, int vegtyp) {
   const noahmp_tables* T = c.T;
+  P.ch2op = T->ch2op[vegtyp - 1];
   if (soiltyp > T->slcats || soiltyp < 1) soiltyp = 1;
   const int st = soiltyp - 1;
   P.dksat = T->satdk[st];
@@ -81,22 +97,13 @@ inline void derive_tables(const noahmp_tables& T, Derived& D) {
 #endif
 
 // PHENOLOGY lsm:1010-1104
-NMP_DEV void phenology(const Ctx& c, Col& s) {
+NMP_DEV void phenology(const Ctx& c, const Parm& P, Col& s) {
   const noahmp_tables* T = c.T;
-  const int v = s.vegtyp - 1;
-  if (c.O.dveg == 1 || c.O.dveg == 3 || c.O.dveg == 4) {
-    float day;
-    if (s.lat >= 0.f) day = s.julian;
-    else day = fmodf(s.julian + (0.5f * s.yearlen), (float)s.yearlen);
-    float t = 12.f * day / (float)s.yearlen;
-    int it1 = (int)(t + 0.5f);                        // REAL -> INTEGER truncation (lsm:1063)
-    int it2 = it1 + 1;
-    float wt1 = (it1 + 0.5f) - t;
-    float wt2 = 1.f - wt1;
-    if (it1 < 1) it1 = 12;
-    if (it2 > 12) it2 = 1;
-    s.lai = wt1 * T->laim[it1 - 1][v] + wt2 * T->laim[it2 - 1][v];
-    s.sai = wt1 * T->saim[it1 - 1][v] + wt2 * T->saim[it2 - 1][v];
+  if (c.O.dveg == 1 || c.O.dveg == 3 || c.O.dveg == 4) {      // months, weight and table rows: REDPRM fetched them (same values)
+    const float wt1 = P.ph_wt1;
+    const float wt2 = 1.f - wt1;
+    s.lai = wt1 * P.lai1 + wt2 * P.lai2;
+    s.sai = wt1 * P.sai1 + wt2 * P.sai2;
   }
   if (s.sai < 0.01f) s.sai = 0.0f;
   if (s.lai < 0.05f || s.sai == 0.0f) s.lai = 0.0f;
@@ -104,7 +111,7 @@ NMP_DEV void phenology(const Ctx& c, Col& s) {
       (s.vegtyp == c.isurban)) {
     s.lai = 0.f; s.sai = 0.f;
   }
-  const float hvt = T->hvt[v], hvb = T->hvb[v];
+  const float hvt = P.hvt, hvb = P.hvb;
   float db = nmp_min(nmp_max(s.snowh - hvb, 0.f), hvt - hvb);
   float fb = db / nmp_max(1.E-06f, hvt - hvb);
   if (hvt > 0.f && hvt <= 1.0f) {
@@ -115,7 +122,7 @@ NMP_DEV void phenology(const Ctx& c, Col& s) {
   s.esai = s.sai * (1.f - fb);
   if (s.esai < 0.01f) s.esai = 0.0f;
   if (s.elai < 0.05f || s.esai == 0.0f) s.elai = 0.0f;
-  s.igs = (s.tv > T->tmin[v]) ? 1.f : 0.f;
+  s.igs = (s.tv > P.tmin) ? 1.f : 0.f;
   s.htop = hvt;
 }
 
@@ -250,7 +257,7 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
   beg_wb = s.canliq + s.canice + s.sneqv + s.wa;
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) beg_wb = beg_wb + y.smc[L(iz)] * y.dzsnso[L(iz)] * 1000.f;
-  phenology(c, s);
+  phenology(c, P, s);
   if (c.O.dveg == 1) {
     s.fveg = s.shdfac;
     if (s.fveg <= 0.01f) s.fveg = 0.01f;

@@ -10,9 +10,7 @@
 namespace nmp {
 
 // CANWATER lsm:6615-6865
-NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
-  const noahmp_tables* T = c.T;
-  const int v = s.vegtyp - 1;
+NMP_DEV void canwater(const Ctx& c, const Parm& P, Col& s, float& qrain, float& snowhin) {
   const float dt = c.dt, sfctmp = s.sfctmp, fveg = s.fveg;
   const double rdt = c.u.dt;
   float fp = 0.0f, qintr, qdripr, qthror, qints, qdrips, qthros, qevac, qdewc, qsubc, qfroc;
@@ -33,7 +31,7 @@ NMP_DEV void canwater(const Ctx& c, Col& s, float& qrain, float& snowhin) {
   float snow = (s.qprecc + s.qprecl) * fpice;
   if (s.qprecc + s.qprecl > 0.f) fp = (s.qprecc + s.qprecl) / (10.f * s.qprecc + s.qprecl);
   const float vai = s.elai + s.esai;
-  float maxliq = T->ch2op[v] * vai;
+  float maxliq = P.ch2op * vai;
   if (vai > 0.f) {
     qintr = fveg * rain * fp;
     qintr = nmp_min(qintr, div_rc(maxliq - s.canliq, rdt) * (1.f - nmp_expf(-rain * dt / maxliq)));
@@ -916,7 +914,7 @@ NMP_DEV void water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float q
   float etrani[NL], wcnd[NL];
   float snoflow = 0.f, qrain, snowhin, qdrain = 0.f, fcrmax = 0.f;
   s.runsub = 0.f;
-  canwater(c, s, qrain, snowhin);
+  canwater(c, P, s, qrain, snowhin);
   float qsnsub = 0.f;
   if (s.sneqv > 0.f) qsnsub = nmp_min(qvap, div_rc(s.sneqv, c.u.dt));
   float qseva = qvap - qsnsub;

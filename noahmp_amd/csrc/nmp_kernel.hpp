@@ -37,7 +37,16 @@ __device__ __forceinline__ void column_kernel_body(const KArgs& k) {
   const long t = k.t_first + tl;
   int ii = 0, jj = 0;
   size_t ij = 0;
-  const int cls = (MODE != 0 && tl >= k.t_count) ? 3 : column_classify(k, t, ii, jj, ij);
+  int cls = 3, err = 0;
+  if (MODE == 1 || MODE == 2) {
+    // class range of a sorted layout: the gather does not wait for the classification (column_step<.., EARLY>)
+    if (tl < k.t_count && column_index(k, t, ii, jj, ij)) {
+      SimpleLoop runner;
+      err = column_step<STRIDE, MODE, true>(k, -1, ii, jj, ij, base, runner, &cls);
+    }
+  } else {
+    cls = (MODE != 0 && tl >= k.t_count) ? 3 : column_classify(k, t, ii, jj, ij);
+  }
   {                                           // per-wave tallies (64-wide wavefront)
     unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
     if ((threadIdx.x & 63) == 0) {
@@ -51,9 +60,13 @@ __device__ __forceinline__ void column_kernel_body(const KArgs& k) {
     atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)NOAHMP_ERR_CLASS_RANGE);
     return;
   }
+  if (MODE == 1 || MODE == 2) {
+    if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)err);   // first column wins
+    return;
+  }
   if (cls > 1 || MODE == 3) return;
   SimpleLoop runner;
-  const int err = column_step<STRIDE, (MODE == 3 ? 0 : MODE)>(k, cls, ii, jj, ij, base, runner);
+  err = column_step<STRIDE, (MODE == 3 ? 0 : MODE)>(k, cls, ii, jj, ij, base, runner);
   if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)err);   // first column wins
 }
 
