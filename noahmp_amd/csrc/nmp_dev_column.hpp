@@ -228,15 +228,22 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, floa
   float beg_wb_trunc = 0.f;
   if constexpr (MODE != 2) {
     float beg_wb = 0.f;
-    sflx_energy(k.c, P, s, y, beg_wb, live, runner);                               // all threads (see above)
+    // the WATER phase's own inputs (state words only it reads, its rows of the soil tables) are requested before TSNOSOI and
+    // consumed after PHASECHANGE: their round trip is hidden (they used to be gathered, and waited for, at the start of WATER)
+    bool water_inputs = false;
+    auto prefetch_water = [&]() {
+      gather_water_state(k, s, ij);
+      redprm_water(k.c, P, soiltyp_w, s.vegtyp);
+      water_inputs = true;
+    };
+    sflx_energy(k.c, P, s, y, beg_wb, live, runner, prefetch_water);               // all threads (see above)
     if (NMP_TRUNC && NMP_TRUNC <= 8) live = false;
     if (live) {
       if (s.err) failed = s.err;
       else {
         lh_out = s.fcev + s.fgev + s.fctr;                                         // drv:714
         scatter_energy_outputs(k, s, ij);
-        gather_water_state(k, s, ij);
-        redprm_water(k.c, P, soiltyp_w, s.vegtyp);
+        if (!water_inputs) prefetch_water();          // (an ENERGY that returned early, e.g. a truncated profiling build)
         NMP_TIC(11);   // energy tail + early scatter
         sflx_water(k.c, P, s, y, beg_wb);
         beg_wb_trunc = beg_wb;

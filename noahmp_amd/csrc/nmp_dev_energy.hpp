@@ -1150,8 +1150,11 @@ NMP_DEV float at_top(const float* a, int isnow) {
 // ENERGY lsm:1231-1843
 // All threads of the workgroup call it: `live` says whether this thread carries a land column; the canopy
 // iteration runner in the middle may synchronise the workgroup (CompactLoop).
-template <class A, class Runner>
-NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const bool live, Runner& runner) {
+// `before_soil_heat`: a hook of the caller, run once the surface fluxes are final and before TSNOSOI -- the column step issues the
+// loads of the WATER phase there (its state words and table rows), so that their memory round trip runs under TSNOSOI / PHASECHANGE
+// instead of being waited for at the start of WATER.
+template <class A, class Runner, class Hook>
+NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const bool live, Runner& runner, Hook& before_soil_heat) {
   const noahmp_tables* T = c.T;
   const int v = s.vegtyp - 1;
   const float MPE = 1.E-6f, PSIWLT = -150.f, Z0 = 0.01f;
@@ -1290,6 +1293,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   s.apar = r.parsun * r.laisun + r.parsha * r.laisha;
   s.psn = psnsun * r.laisun + psnsha * r.laisha;
   NMP_TIC(8);    // flux merge, trad
+  before_soil_heat();
   tsnosoi(c, P, s, y, df, hcpct);
   NMP_TIC(9);    // tsnosoi
   if (c.O.stc == 2) {

@@ -225,9 +225,9 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
 // NOAHMP_SFLX lsm:518-947 (with ATM lsm:949-1007 and ERROR lsm:1106-1228)
 // Split in two phases so that the caller can store the energy-phase outputs before the water phase.
 // Called by ALL threads of the workgroup (`live` = this thread carries a land column): see energy().
-template <class A, class Runner>
+template <class A, class Runner, class Hook>
 NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float& beg_wb_out, const bool live,
-                         Runner& runner) {
+                         Runner& runner, Hook& before_soil_heat) {
   const noahmp_tables* T = c.T;
   float beg_wb = 0.f;
   if (live) {
@@ -276,7 +276,7 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
   NMP_TRUNC_AT(2);
   }  // live
 
-  energy(c, P, s, y, live, runner);
+  energy(c, P, s, y, live, runner, before_soil_heat);
   if (!live) return;
   NMP_TRUNC_CHK();
 
