@@ -231,7 +231,12 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, const Parm& P, int ic, int v, float
 struct RadOut { float fsun, laisun, laisha, parsun, parsha; };
 
 // RADIATION lsm:2120-2240 (ALBEDO lsm:2243-2423 + SURRAD lsm:2426-2544)
-NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1) {
+// the vegetation type's leaf / stem optical rows (lsm:2361-2366), requested by ENERGY before THERMOPROP for sunlit columns
+struct RadP { float rhol[2], rhos[2], taul[2], taus[2]; };
+NMP_DEV RadP radiation_rows(const noahmp_tables* T, int v) {
+  return RadP{{T->rhol[0][v], T->rhol[1][v]}, {T->rhos[0][v], T->rhos[1][v]}, {T->taul[0][v], T->taul[1][v]}, {T->taus[0][v], T->taus[1][v]}};
+}
+NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1, const RadP& rp) {
   const noahmp_tables* T = c.T;
   const int v = s.vegtyp - 1;
   const float MPE = 1.E-6f;
@@ -247,8 +252,8 @@ NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1) {
     float rho[2], tau[2], albsnd[2], albsni[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {
-      rho[ib] = nmp_max(T->rhol[ib][v] * wl + T->rhos[ib][v] * ws, MPE);
-      tau[ib] = nmp_max(T->taul[ib][v] * wl + T->taus[ib][v] * ws, MPE);
+      rho[ib] = nmp_max(rp.rhol[ib] * wl + rp.rhos[ib] * ws, MPE);
+      tau[ib] = nmp_max(rp.taul[ib] * wl + rp.taus[ib] * ws, MPE);
     }
     float fage;
     snow_age(c.dt, s.tg, s.sneqvo, s.sneqv, s.tauss, fage);
@@ -469,15 +474,20 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
 // The temperature-only part of STOMATA (lsm:5505-5516): the sunlit and the shaded call of an iteration get the
 // same TV, so KC/KO/AWC/CP and the Arrhenius factors of VCMX are evaluated once for both (3 powf + 1 expf each).
 struct StomataT { float awc, cp, vcmx_t; };
-NMP_DEV StomataT stomata_temperature(const Ctx& c, int v, float tv, float o2) {
-  const noahmp_tables* T = c.T;
+// the vegetation type's rows of the photosynthesis tables: requested when VEGE_FLUX starts, consumed in its first iteration
+// (their memory round trip runs under the set-up, SFCDIF1 and RAGRB instead of in front of STOMATA)
+struct StomataP { float bp, c3psn, mp, folnmx, qe25, vcmx25, kc25, akc, ko25, ako, avcmx; };
+NMP_DEV StomataP stomata_rows(const noahmp_tables* T, int v) {
+  return StomataP{T->bp[v], T->c3psn[v], T->mp[v], T->folnmx[v], T->qe25[v], T->vcmx25[v], T->kc25[v], T->akc[v], T->ko25[v], T->ako[v], T->avcmx[v]};
+}
+NMP_DEV StomataT stomata_temperature(const StomataP& T, float tv, float o2) {
   StomataT r;
   float tc = tv - TFRZ;
   const float ex = div_rc(tc - 25.0f, NMP_RCC(10.0f));
   float pk[2];
-  { const float pb[2] = {T->akc[v], T->ako[v]}, py[2] = {ex, ex}; nmp_powfN<2>(pb, py, pk); }    // AKC ** ex, AKO ** ex as one batch
-  float kc = T->kc25[v] * pk[0];
-  float ko = T->ko25[v] * pk[1];
+  { const float pb[2] = {T.akc, T.ako}, py[2] = {ex, ex}; nmp_powfN<2>(pb, py, pk); }    // AKC ** ex, AKO ** ex as one batch
+  float kc = T.kc25 * pk[0];
+  float ko = T.ko25 * pk[1];
   r.awc = kc * (1.0f + o2 / ko);
   r.cp = 0.5f * kc / ko * o2 * 0.21f;
   // VCMX = VCMX25 / F2(TC) * FNF * BTRAN * AVCMX**((TC-25)/10): the first quotient and the last factor are kept
@@ -486,21 +496,20 @@ NMP_DEV StomataT stomata_temperature(const Ctx& c, int v, float tv, float o2) {
   return r;
 }
 
-NMP_DEV void stomata(const Ctx& c, int v, float mpe, float apar, float foln, float tv, float ei,
+NMP_DEV void stomata(const StomataP& T, float mpe, float apar, float foln, float tv, float ei,
                      float ea, float sfctmp, float sfcprs, float o2, float co2, float igs,
                      float btran, float rb, const StomataT& st, float avcmx_pow, float& rs, float& psn) {
-  const noahmp_tables* T = c.T;
-  const float bpv = T->bp[v];
+  const float bpv = T.bp;
   float cf = sfcprs / (8.314f * sfctmp) * 1.0e06f;
   rs = 1.0f / bpv * cf;
   psn = 0.0f;
   if (apar <= 0.0f) return;
-  const float c3 = T->c3psn[v], mpv = T->mp[v];
-  float fnf = nmp_min(foln / nmp_max(mpe, T->folnmx[v]), 1.0f);
+  const float c3 = T.c3psn, mpv = T.mp;
+  float fnf = nmp_min(foln / nmp_max(mpe, T.folnmx), 1.0f);
   float ppf = 4.6f * apar;
-  float j = ppf * T->qe25[v];
+  float j = ppf * T.qe25;
   const float awc = st.awc, cp = st.cp;
-  float vcmx = T->vcmx25[v] / (1.0f + st.vcmx_t) * fnf * btran * avcmx_pow;
+  float vcmx = T.vcmx25 / (1.0f + st.vcmx_t) * fnf * btran * avcmx_pow;
   float rlb = rb / cf;
   float cihi = 1.5f * co2, cilow = 0.0f;
   const double r_sfcprs = rc64(sfcprs);                 // divides once per bisection step
@@ -580,6 +589,7 @@ constexpr int VEGLOOP_WORDS = sizeof(VegLoop) / 4;
 
 struct VegFirst {   // what only iteration 1 needs (STOMATA / CANRES run there, lsm:3287-3320)
   const Parm* P; int v; float parsun, parsha, foln, o2air, co2air, igs, btran; float psnsun, psnsha;
+  StomataP sp;
 };
 
 // one pass of the loop body, lsm:3236-3456
@@ -632,14 +642,14 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     StomataT st = {0.f, 0.f, 0.f};
     float avcmx_pow = 0.f;
     if (c.O.crs == 1 && (f->parsun > 0.0f || f->parsha > 0.0f)) {   // STOMATA returns early for APAR <= 0
-      st = stomata_temperature(c, f->v, L.tv, f->o2air);
-      avcmx_pow = nmp_powf(c.T->avcmx[f->v], div_rc((L.tv - TFRZ) - 25.0f, NMP_RCC(10.0f)));
+      st = stomata_temperature(f->sp, L.tv, f->o2air);
+      avcmx_pow = nmp_powf(f->sp.avcmx, div_rc((L.tv - TFRZ) - 25.0f, NMP_RCC(10.0f)));
     }
 #pragma unroll 1
     for (int leaf = 0; leaf < 2; leaf++) {            // sunlit, then shaded
       float par = leaf ? f->parsha : f->parsun, rs_, psn_;
       if (c.O.crs == 1)
-        stomata(c, f->v, MPE, par, f->foln, L.tv, estv, L.eah, sfctmp, L.sfcprs, f->o2air, f->co2air, f->igs,
+        stomata(f->sp, MPE, par, f->foln, L.tv, estv, L.eah, sfctmp, L.sfcprs, f->o2air, f->co2air, f->igs,
                 f->btran, rb, st, avcmx_pow, rs_, psn_);
       else
         canres(*f->P, par, L.tv, f->btran, L.eah, L.sfcprs, rs_, psn_);
@@ -720,6 +730,9 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   L.done = 1;
   if (canopy) {
     const int v = s.vegtyp - 1;
+    VegFirst f = {};
+    f.P = &P; f.v = v;
+    if (c.O.crs == 1) f.sp = stomata_rows(T, v);          // requested first: eleven table rows
     const float fveg = s.fveg, ur = q.ur;
     L.sfctmp = s.sfctmp; L.rhoair = s.rhoair; L.qair = s.qair; L.zlvl = q.zlvl; L.zpd = q.zpd; L.z0m = q.z0m;
     L.ur = ur; L.z0mg = q.z0mg; L.cwp = q.cwp; L.fveg = fveg; L.rsurf = q.rsurf; L.eair = s.eair;
@@ -744,7 +757,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.sqrt_dleaf_uc = sqrtf(P.dleaf / uc);          // loop-invariant factor of RB (lsm:4054)
     L.irc = s.irc; L.shc = s.shc; L.evc = s.evc; L.tr = s.tr;
     L.done = 0; L.iter = 1;
-    VegFirst f = {&P, v, q.parsun, q.parsha, s.foln, s.o2air, s.co2air, s.igs, s.btran, 0.f, 0.f};
+    f.parsun = q.parsun; f.parsha = q.parsha; f.foln = s.foln; f.o2air = s.o2air; f.co2air = s.co2air; f.igs = s.igs; f.btran = s.btran;
     vege_iter<true>(c, L, 1, &f);                       // iteration 1 (with STOMATA / CANRES)
     psnsun = f.psnsun; psnsha = f.psnsha;
   }
@@ -1192,9 +1205,11 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   if (zpdg >= q.zlvl) q.zlvl = zpdg + s.zlvl;
   q.cwp = P.cwpvt;
   NMP_TIC(2);    // energy: preamble
+  RadP rp = {};
+  if (s.cosz > 0.f) rp = radiation_rows(T, v);          // their round trip runs under THERMOPROP
   thermoprop(c, P, s, y, df, hcpct, fact);
   NMP_TIC(3);    // thermoprop
-  r = radiation(c, P, s, y.smc[L(1)]);
+  r = radiation(c, P, s, y.smc[L(1)], rp);
   NMP_TIC(4);    // radiation
   q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
   q.emv = 1.f - nmp_expf(-(s.elai + s.esai) / 1.0f);
