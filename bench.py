@@ -221,8 +221,8 @@ def self_launch(args, argv):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-GW_SHARED = ("smois", "sh2o", "smcwtdxy", "zwtxy", "deeprechxy", "rechxy")   # what the column step and WTABLE_mmf_noahmp both update
 GW_ONLY_OUT = ("qrf", "qspring", "qslat", "qrfs", "qsprings")
+GW_LATERAL = ("zwtxy", "fdepth", "topo", "isltyp", "xland", "xice", "ivgtyp", "area")     # what the QLAT stencil reads, in (i,j) order
 
 
 class Run:
@@ -232,9 +232,13 @@ class Run:
     Sorted layout (default): the rank's tile lives in HBM sorted by (class, vegetation type, snow-layer count, TSK bin); forcing
     arrives in tile order and is permuted per step.  With OPT_RUN = 5 (config 4) the groundwater planes additionally live in
     a tile-order memory block that carries the 1-cell ring: around every WTABLE_mmf_noahmp call the six planes it shares with the
-    column step return to (i,j) order, the ZWTXY ring is exchanged, the stencil runs, and the planes go back to sorted order."""
+    column step return to (i,j) order, the ZWTXY ring is exchanged, the stencil runs, and the planes go back to sorted order.
+    Round 3: only the QLAT stencil needs the (i,j) neighbourhood, so WTABLE_mmf_noahmp runs in two halves
+    (noahmp_hip_wtable_lateral_async on the tile-order ZWTXY, noahmp_hip_wtable_columns_async on the sorted store): ONE plane travels
+    to (i,j) order (ZWTXY) and ONE back (QLAT) per call instead of twelve each way."""
 
     def __init__(self, args, workload, comm, eng, tb, dev):
+        import numpy as np
         import torch
         from noahmp_amd import synth
         from noahmp_amd.partition import tile_geometry
@@ -264,7 +268,6 @@ class Run:
         self.tile_cells = nti * ntj
         self.gw = None
         self.tsk_bin = None
-        self.pending_back = False
         self.block_forcing = None
         if self.lateral and self.sorted:
             # forcing arrives shaped like the rank's memory block (tile + ring), as the groundwater planes are: its permutation into
@@ -276,13 +279,14 @@ class Run:
             # the groundwater planes stay in a tile-order block with the ring; the column state is the tile without it
             gwb = DeviceColumnStore.__new__(DeviceColumnStore)
             gwb.ni, gwb.nj, gwb.cfg, gwb.device, gwb.idx = s.ni, s.nj, cfg, torch.device(dev), dict(s.idx)
-            names = sorted(set(GW_ALIAS.values()) - {"dzs"} | set(GW_EXTRA))
-            gwb.a = {k: torch.from_numpy(s.a[k]).to(dev) for k in names}
+            gwb.a = {k: torch.from_numpy(s.a[k]).to(dev) for k in GW_LATERAL}       # what the stencil half reads (tile + ring, (i,j) order)
+            gwb.a["qlat"] = torch.zeros((s.nj, s.ni), dtype=torch.float32, device=dev)
             gwb.a["dzs"] = s.a["dzs"].copy()
             self.gw = gwb
-            inner = ColumnStore(nti, ntj, cfg)
+            inner = ColumnStore(nti, ntj, cfg).add_groundwater()                    # the sorted store carries every per-column MMF plane
+            inner.a["qlat"] = np.zeros((ntj, nti), dtype=np.float32)
             for k in inner.a:
-                if k != "dzs":
+                if k not in ("dzs", "qlat"):
                     inner.a[k][...] = s.a[k][self.j_off:self.j_off + ntj, ..., self.i_off:self.i_off + nti]
             inner.t_offset = s.t_offset[self.j_off:self.j_off + ntj, self.i_off:self.i_off + nti].copy()
             inner.set_index(**dict({k: geom[k] for k in idx_keys}, ims=geom["its"], ime=geom["ite"], jms=geom["jts"], jme=geom["jte"]))
@@ -302,7 +306,7 @@ class Run:
         self.halo_mover = None
         if self.lateral:
             self.halo_mover = comm.probe_halo()                                      # agree on a working mover before the first exchange
-            self.wargs = halo_store.wtable_args()
+            self.wargs = self._lateral_args() if self.gw is not None else halo_store.wtable_args()
             with torch.cuda.stream(self.ts):                                         # static planes of the stencil: once
                 comm.exchange_halo([halo_store.a["fdepth"], halo_store.a["topo"]], geom)
                 comm.exchange_halo([halo_store.a["isltyp"]], geom)
@@ -319,8 +323,27 @@ class Run:
                 d.a.update(self.forcing[h])
                 self.sargs.append(d.step_args(1, 2000, 180.0))
 
+    def _lateral_args(self):
+        """noahmp_wtable_args of the (i,j)-order block for the stencil half: only GW_LATERAL is read; the other members point at ZWTXY."""
+        from noahmp_amd.abi import WtableArgs
+        from noahmp_amd.abi_spec import WTABLE_FIELDS
+        from noahmp_amd.state import GW_ALIAS
+        gw, cfg = self.gw, self.cfg
+        w = WtableArgs()
+        scal = dict(nsoil=cfg.nsoil, xice_threshold=cfg.xice_thres, isice=cfg.isice, wtddt=cfg.wtddt, isurban=cfg.isurban)
+        scal.update(gw.index())
+        for n, k, lev, io, ln in WTABLE_FIELDS:
+            if k in ("pf", "pi"):
+                name = GW_ALIAS.get(n, n)
+                setattr(w, n, gw.ptr(name if name in gw.a else "zwtxy"))
+            else:
+                setattr(w, n, scal[n])
+        return w
+
     def _bind_sorted(self):
         d, eng = self.d, self.eng
+        if self.gw is not None:
+            self.wargs_col = d.wtable_args()                  # the per-column half works on the sorted store itself
         self.work = {k: d.a[k] for k in FKEYS}
         src0 = [self.work[k] for k in FKEYS] if self.block_forcing else [self.forcing[0][k] for k in FKEYS]   # (plan only; sources are set per step)
         self.scat = eng.scatter([self.work[k] for k in FKEYS], src0, self.perm, self.ni, self.nj)
@@ -336,10 +359,6 @@ class Run:
             # step's WTABLE call return to sorted order in the same launch
             srt = [self.work[k] for k in FKEYS]
             til = [self.forcing[h][k] for k in FKEYS]
-            if self.pending_back:
-                srt += [self.d.a[k] for k in GW_SHARED]
-                til += [self.gw.a[k] for k in GW_SHARED]
-                self.pending_back = False
             self.scat.exchange(srt, til, False, self.gw.ni, self.i_off, self.j_off, self.sp)
             self.sarg.itimestep = it
             self.eng.noahmplsm_async(self.sarg, self.sp)
@@ -361,25 +380,24 @@ class Run:
         """WTABLE_mmf_noahmp (gw:14) after the ZWTXY ring exchange (gw:231-252), enqueued on the run's stream."""
         torch = self.torch
         halo_store = self.gw if self.gw is not None else self.d
-        if self.gw is not None:                                                      # sorted -> (i,j) order, into the ring-carrying block
-            self.scat.exchange([self.d.a[k] for k in GW_SHARED], [self.gw.a[k] for k in GW_SHARED], True, self.gw.ni,
-                               self.i_off, self.j_off, self.sp)
+        if self.gw is not None:                                                      # ZWTXY: sorted -> (i,j) order, into the ring-carrying block
+            self.scat.exchange([self.d.a["zwtxy"]], [self.gw.a["zwtxy"]], True, self.gw.ni, self.i_off, self.j_off, self.sp)
         with torch.cuda.stream(self.ts):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.comm.exchange_halo([halo_store.a["zwtxy"]], self.geom)              # ZWTXY ring before every call
             e1.record()
         self.halo_events.append((e0, e1))
-        self.eng.wtable_mmf_async(self.wargs, self.sp)
-        self.pending_back = self.gw is not None        # back to sorted order: with the next step's forcing permutation, or at flush()
+        if self.gw is not None:
+            self.eng.wtable_lateral_async(self.wargs, self.gw.a["qlat"], self.sp)     # KCELL / HEAD + QLAT stencil, (i,j) order
+            self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order
+            self.eng.wtable_columns_async(self.wargs_col, self.d.a["qlat"], self.sp)  # everything else, on the sorted store
+        else:
+            self.eng.wtable_mmf_async(self.wargs, self.sp)
         self.gw_calls += 1
 
     def flush(self):
-        """The groundwater planes of the last WTABLE call back into the sorted store (when no further step does it)."""
-        if self.pending_back:
-            self.scat.exchange([self.d.a[k] for k in GW_SHARED], [self.gw.a[k] for k in GW_SHARED], False, self.gw.ni,
-                               self.i_off, self.j_off, self.sp)
-            self.pending_back = False
+        pass
 
     def collect(self):
         self.flush()
@@ -430,9 +448,9 @@ class Run:
                      if v.ndim == 3 else v.reshape(-1)[inv].reshape(v.shape))
             out[k] = v if self.gw is not None else v[j0:j1, ..., i0:i1]      # the sorted config-4 state is the tile without the ring
         if self.lateral:
-            src = self.gw.a if self.gw is not None else self.d.a
             for k in GW_ONLY_OUT:
-                out[k] = src[k].cpu().numpy()[j0:j1, i0:i1]
+                v = self.d.a[k].cpu().numpy()
+                out[k] = v.reshape(-1)[inv].reshape(v.shape) if self.gw is not None else v[j0:j1, i0:i1]
         np.savez(path, **out)
 
     def reset_counters(self):

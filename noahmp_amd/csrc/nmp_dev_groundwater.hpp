@@ -30,6 +30,7 @@ struct GwArgs {
   int qi0, qi1, qj0, qj1;          // QLAT rectangle, gw:254-257
   unsigned long long* err;
   int* counts;
+  float* qlat;                     // split form (sorted layout): QLAT plane written by gw_qlat_cell / read by gw_column_t<false>
 };
 
 // KLATFACTOR, gw:224-225 (indexed by soil category 1..19)
@@ -235,7 +236,46 @@ NMP_DEV void gw_updatewtd(GwCol& c, const Soil4& smceq, const float* zsoil, cons
 // of each other, so they are all issued before the first use (one HBM round trip per wave instead of a
 // chain of dependent ones behind the land-mask and regime branches), and nothing is stored until the end,
 // so the compiler never has to order a load behind a possibly aliasing store.
-NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) {
+// the 9-point stencil of LATERALFLOW (gw:259-292) for one cell: QLAT [m] over DELTAT; zero outside the QLAT rectangle (gw:254-257)
+NMP_DEV float gw_qlat_stencil(const GwArgs& g, size_t x, bool inq, float area) {
+  const int ni = g.ni;
+  // outside the QLAT rectangle the offsets collapse onto the cell itself so that the loads stay inside the caller's memory
+  const size_t up = inq ? x + ni : x, dn = inq ? x - ni : x, e = inq ? 1 : 0;
+  const float kc = g.kcell[x], hd = g.head[x];
+  const float k_ul = g.kcell[up - e], k_l = g.kcell[x - e], k_dl = g.kcell[dn - e], k_u = g.kcell[up],
+              k_d = g.kcell[dn], k_ur = g.kcell[up + e], k_r = g.kcell[x + e], k_dr = g.kcell[dn + e];
+  const float h_ul = g.head[up - e], h_l = g.head[x - e], h_dl = g.head[dn - e], h_u = g.head[up],
+              h_d = g.head[dn], h_ur = g.head[up + e], h_r = g.head[x + e], h_dr = g.head[dn + e];
+  if (!inq) return 0.f;
+  const float SQRT2 = 1.41421354f;          // SQRT(2.) in float32
+  float q = 0.f;
+  q = q + (k_ul + kc) * (h_ul - hd) / SQRT2;
+  q = q + (k_l + kc) * (h_l - hd);
+  q = q + (k_dl + kc) * (h_dl - hd) / SQRT2;
+  q = q + (k_u + kc) * (h_u - hd);
+  q = q + (k_d + kc) * (h_d - hd);
+  q = q + (k_ur + kc) * (h_ur - hd) / SQRT2;
+  q = q + (k_r + kc) * (h_r - hd);
+  q = q + (k_dr + kc) * (h_dr - hd) / SQRT2;
+  return 0.45508986056f * q * g.deltat / area;                                  // FANGLE, gw:229
+}
+NMP_DEV bool gw_is_land(const noahmp_wtable_args& a, float xland, float xice, int ivgtyp) {
+  return (xland - 1.5f < 0.f) && (xice < a.xice_threshold) && (ivgtyp != a.isice);                // gw:97-101
+}
+// Split form, first half (tile order): QLAT of cell (i, j) into the plane g.qlat -- zero on non-land cells and outside the rectangle
+NMP_DEV void gw_qlat_cell(const GwArgs& g, int i, int j, int gi, int gj) {
+  const noahmp_wtable_args& a = g.a;
+  const size_t x = (size_t)j * g.ni + i;
+  const bool inq = (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1);
+  const bool land = gw_is_land(a, a.xland[x], a.xice[x], a.ivgtyp[x]);
+  const float q = gw_qlat_stencil(g, x, inq, a.area[x]);
+  g.qlat[x] = land ? q : 0.f;
+}
+
+// STENCIL = true: the whole cell update (stencil included; tile order).  false: the per-column half of the split form -- QLAT comes from
+// the plane g.qlat (same column order as the other arrays, any order), nothing else of the call depends on the neighbours.
+template <bool STENCIL>
+NMP_DEV int gw_column_t(const GwArgs& g, int i, int j, int gi, int gj) {
   const noahmp_wtable_args& a = g.a;
   const int ni = g.ni;
   const size_t x = (size_t)j * ni + i;
@@ -255,34 +295,16 @@ NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) {
     c.sh2o.v[k] = a.sh2oxy[x3 + k * plane];
     smceq.v[k] = a.smoiseq[x3 + k * plane];
   }
-  // stencil operands; outside the QLAT rectangle (gw:254-257) the offsets collapse onto the cell itself so
-  // that the loads stay inside the caller's memory, and the result is discarded
-  const bool inq = (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1);
-  const size_t up = inq ? x + ni : x, dn = inq ? x - ni : x, e = inq ? 1 : 0;
-  const float kc = g.kcell[x], hd = g.head[x];
-  const float k_ul = g.kcell[up - e], k_l = g.kcell[x - e], k_dl = g.kcell[dn - e], k_u = g.kcell[up],
-              k_d = g.kcell[dn], k_ur = g.kcell[up + e], k_r = g.kcell[x + e], k_dr = g.kcell[dn + e];
-  const float h_ul = g.head[up - e], h_l = g.head[x - e], h_dl = g.head[dn - e], h_u = g.head[up],
-              h_d = g.head[dn], h_ur = g.head[up + e], h_r = g.head[x + e], h_dr = g.head[dn + e];
+  // stencil operands (whole form) or the QLAT plane (split form)
+  const bool inq = STENCIL && (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1);
+  const float qlat_in = STENCIL ? gw_qlat_stencil(g, x, inq, area) : g.qlat[x];
 
   // ---- compute
-  const bool land = (xland - 1.5f < 0.f) && (xice < a.xice_threshold) && (ivgtyp != a.isice);   // gw:97-101
+  const bool land = gw_is_land(a, xland, xice, ivgtyp);
   float qlat = 0.f, qrf = 0.f, deeprech = deeprech0;
   float qspring = qspring0;                     // non-land cells keep the caller's value (gw:172-174)
   if (land) {
-    if (inq) {                                                                    // gw:259-292
-      const float SQRT2 = 1.41421354f;          // SQRT(2.) in float32
-      float q = 0.f;
-      q = q + (k_ul + kc) * (h_ul - hd) / SQRT2;
-      q = q + (k_l + kc) * (h_l - hd);
-      q = q + (k_dl + kc) * (h_dl - hd) / SQRT2;
-      q = q + (k_u + kc) * (h_u - hd);
-      q = q + (k_d + kc) * (h_d - hd);
-      q = q + (k_ur + kc) * (h_ur - hd) / SQRT2;
-      q = q + (k_r + kc) * (h_r - hd);
-      q = q + (k_dr + kc) * (h_dr - hd) / SQRT2;
-      qlat = 0.45508986056f * q * g.deltat / area;                                // FANGLE, gw:229
-    }
+    qlat = qlat_in;                                                               // gw:259-292
     {                                                                             // gw:116-124
       float rcond = rivercond;
       if (wtd > riverbed && eqwtd > riverbed) rcond = rcond * nmp_expf(pexp * (wtd - eqwtd));
@@ -333,6 +355,7 @@ NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) {
   a.deeprech[x] = 0.f;
   return land ? 1 : 0;
 }
+NMP_DEV int gw_column(const GwArgs& g, int i, int j, int gi, int gj) { return gw_column_t<true>(g, i, j, gi, gj); }
 
 
 // ---- GROUNDWATER_INIT + EQSMOISTURE (reference phys/module_sf_noahmpdrv.F90:1286-1522, "drv"): the one-time

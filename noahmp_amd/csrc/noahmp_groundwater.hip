@@ -52,14 +52,22 @@ __global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
   }
 }
 
-// stencil + per-cell update over the tile (gw:105-195)
+// split form, first half: the QLAT stencil over the tile into the plane k.qlat (tile order)
+__global__ void __launch_bounds__(BX * BY) gw_qlat_kernel(const GwArgs k) {
+  const int gi = k.a.its + blockIdx.x * BX + threadIdx.x;
+  const int gj = k.a.jts + blockIdx.y * BY + threadIdx.y;
+  if (gi <= k.a.ite && gj <= k.a.jte) gw_qlat_cell(k, gi - k.a.ims, gj - k.a.jms, gi, gj);
+}
+
+// stencil + per-cell update over the tile (gw:105-195); STENCIL = false: the per-column half of the split form (any column order)
+template <bool STENCIL>
 __global__ void __launch_bounds__(BX * BY) gw_column_kernel(const GwArgs k) {
   libm::libm_stage_tables();
   const int gi = k.a.its + blockIdx.x * BX + threadIdx.x;
   const int gj = k.a.jts + blockIdx.y * BY + threadIdx.y;
   const bool in = (gi <= k.a.ite && gj <= k.a.jte);
   int land = 0;
-  if (in) land = gw_column(k, gi - k.a.ims, gj - k.a.jms, gi, gj);
+  if (in) land = gw_column_t<STENCIL>(k, gi - k.a.ims, gj - k.a.jms, gi, gj);
   const unsigned long long m = __ballot(land != 0), mi = __ballot(in);
   if (((threadIdx.y * BX + threadIdx.x) & 63) == 0) {
     int* cnt = k.counts + ((blockIdx.y * gridDim.x + blockIdx.x) % nmp_host::kCountSlots) * nmp_host::kCountStride;
@@ -93,7 +101,10 @@ extern "C" {
 
 size_t noahmp_hip_sizeof_wtable_args(void) { return sizeof(noahmp_wtable_args); }
 
-static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only = false);
+// part: 0 = the whole WTABLE_mmf_noahmp; 1 = KCELL / HEAD + the QLAT stencil into `qlat` (tile order); 2 = the per-column half with
+// QLAT read from `qlat` (the block may hold the columns in any order)
+static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only = false,
+                   int part = 0, float* qlat = nullptr);
 
 int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, false, 0);
@@ -105,13 +116,29 @@ int noahmp_hip_wtable_mmf_async(const noahmp_wtable_args* a, void* stream) {
   return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true);
 }
 
+// WTABLE_mmf_noahmp in two halves for a run that keeps its columns in the sorted layout: only the QLAT stencil
+// needs the (i,j) neighbourhood.  noahmp_hip_wtable_lateral_async: KCELL / HEAD and the stencil (gw:231-292) on TILE-order planes --
+// it reads wtd, fdepth, topo, isltyp (tile + ring) and xland, xice, ivgtyp, area of block `a` and writes QLAT [m per call] of every
+// tile cell into `qlat` (shaped like the memory block; zero on non-land cells and outside the QLAT rectangle).
+// noahmp_hip_wtable_columns_async: everything else of the call (river flux, deep recharge, UPDATEWTD, accumulators: gw:105-195) for a
+// block whose columns are in ANY order, with QLAT taken from `qlat` in that order.  One plane each way instead of twelve.
+int noahmp_hip_wtable_lateral_async(const noahmp_wtable_args* a, float* qlat, void* stream) {
+  if (!qlat) { g.last_error = "noahmp_hip_wtable_lateral_async: qlat is required"; return -105; }
+  return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true, 1, qlat);
+}
+int noahmp_hip_wtable_columns_async(const noahmp_wtable_args* a, const float* qlat, void* stream) {
+  if (!qlat) { g.last_error = "noahmp_hip_wtable_columns_async: qlat is required"; return -105; }
+  return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true, 2, const_cast<float*>(qlat));
+}
+
 int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, true, iswater);
 }
 
 }  // extern "C"
 
-static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only) {
+static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only,
+                   int part, float* qlat) {
   if (st) memset(st, 0, sizeof(*st));
   int rc = nmp_host::ensure_init();
   if (rc) return rc;
@@ -137,6 +164,10 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   k.qj0 = imax(a->jts, a->jds + 1); k.qj1 = imin(a->jte, a->jde - 2);
   // The reference indexes KCELL/HEAD(ims:ime,...) at these bounds too; a tile whose ring is not inside the
   // caller's memory is a caller bug there (out-of-bounds) and a refused call here.
+  if (part == 2) {                  // no stencil: the block needs no ring (and its columns no (i,j) meaning)
+    k.hi0 = k.qi0 = a->its; k.hi1 = k.qi1 = a->ite; k.hj0 = k.qj0 = a->jts; k.hj1 = k.qj1 = a->jte;
+  }
+  k.qlat = qlat;
   if (k.hi0 < a->ims || k.hi1 > a->ime || k.hj0 < a->jms || k.hj1 > a->jme ||
       a->its < a->ims || a->ite > a->ime || a->jts < a->jms || a->jte > a->jme) {
     g.last_error = "noahmp_hip_wtable_mmf: memory dims (ims:ime,jms:jme) do not hold the tile plus its 1-cell ring";
@@ -183,7 +214,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   }
   const int hni = k.hi1 - k.hi0 + 1, hnj = k.hj1 - k.hj0 + 1;
   const int tni = a->ite - a->its + 1, tnj = a->jte - a->jts + 1;
-  if (hni > 0 && hnj > 0)
+  if (hni > 0 && hnj > 0 && part != 2)
     hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX * HEAD_ILP - 1) / (BX * HEAD_ILP), (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
   if (init) {
     const int itf = imin(a->ite, a->ide - 1), jtf = imin(a->jte, a->jde - 1);
@@ -191,8 +222,12 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     if (ini_ > 0 && inj_ > 0)
       hipLaunchKernelGGL(gw_init_kernel, dim3((ini_ + BX - 1) / BX, (inj_ + BY - 1) / BY), dim3(BX, BY), 0, s, k, itf, jtf,
                          iswater);
-  } else if (tni > 0 && tnj > 0)
-    hipLaunchKernelGGL(gw_column_kernel, dim3((tni + BX - 1) / BX, (tnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
+  } else if (tni > 0 && tnj > 0) {
+    const dim3 grid((tni + BX - 1) / BX, (tnj + BY - 1) / BY), block(BX, BY);
+    if (part == 1) hipLaunchKernelGGL(gw_qlat_kernel, grid, block, 0, s, k);
+    else if (part == 2) hipLaunchKernelGGL(gw_column_kernel<false>, grid, block, 0, s, k);
+    else hipLaunchKernelGGL(gw_column_kernel<true>, grid, block, 0, s, k);
+  }
   HIPCHK(hipGetLastError());
   if (enqueue_only) return 0;
   HIPCHK(hipEventRecord(g.ev1, s));

@@ -107,6 +107,20 @@ class Engine:
         if rc:
             raise RuntimeError("noahmp_hip_wtable_mmf_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
 
+    def wtable_lateral_async(self, wargs, qlat, stream=None):
+        """First half of WTABLE_mmf_noahmp for a sorted run: KCELL / HEAD + the QLAT stencil on the TILE-order planes of `wargs`
+        (wtd, fdepth, topo, isltyp with the ring; xland, xice, ivgtyp, area) -> `qlat` (device tensor shaped like the memory block)."""
+        rc = self.lib.noahmp_hip_wtable_lateral_async(C.byref(wargs), qlat.data_ptr(), stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_wtable_lateral_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+
+    def wtable_columns_async(self, wargs, qlat, stream=None):
+        """Second half: river flux, deep recharge, UPDATEWTD and the accumulators on a block whose columns are in any order, QLAT
+        taken from `qlat` (same order)."""
+        rc = self.lib.noahmp_hip_wtable_columns_async(C.byref(wargs), qlat.data_ptr(), stream)
+        if rc:
+            raise RuntimeError("noahmp_hip_wtable_columns_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+
     def forcing_prep(self, store, lon, rain_rate, iday, ihour, iminute=0, isecond=0, scale_vegfra=False, stream=None,
                      first_step=False, wait=True):
         """Device-resident forcing preparation (reference hdrv:336-354 + CALC_DECLIN): `lon` and `rain_rate` are
