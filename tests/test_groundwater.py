@@ -131,3 +131,45 @@ def test_halo_tiles_reproduce_single_domain(tables, port):
         for k in GW_OUT:
             out.a[k][jts - 1:jte, ..., its - 1:ite] = loc.a[k][jts - jms:jte - jms + 1, ..., its - ims:ite - ims + 1]
     assert_same(whole, out, what="tiles")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES[:3], ids=lambda c: "stress%g_area%g" % (c["stress"], c["area"]))
+def test_gpu_two_halves_equal_the_whole_call_in_any_column_order(tables, port, engine, case):
+    """noahmp_hip_wtable_lateral_async (KCELL / HEAD + QLAT stencil, tile order) + noahmp_hip_wtable_columns_async (the per-column rest,
+    columns in ANY order) = noahmp_hip_wtable_mmf = the oracle, bit for bit: the per-column half runs on a randomly permuted copy of
+    the store with QLAT permuted the same way."""
+    import torch
+    from noahmp_amd.abi import FIELD_INFO
+    s0 = gw_store(tables, ni=96, nj=50, seed=9, **case)
+    want = s0.copy()
+    port.wtable_mmf(want)
+    whole = s0.to_device("cuda:0")
+    engine.wtable_mmf(whole)
+    assert_same(want, whole.to_host(), what="whole call")
+    # the two halves: stencil on the tile-order store, the rest on a permuted one
+    tile = s0.to_device("cuda:0")
+    qlat = torch.zeros((s0.nj, s0.ni), dtype=torch.float32, device="cuda:0")
+    engine.wtable_lateral_async(tile.wtable_args(), qlat)
+    r = np.random.Generator(np.random.Philox(77))
+    perm = r.permutation(s0.ni * s0.nj)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+
+    def shuffle(v, p):
+        return (v.transpose(1, 0, 2).reshape(v.shape[1], -1)[:, p].reshape(v.shape[1], v.shape[0], v.shape[2]).transpose(1, 0, 2)
+                if v.ndim == 3 else v.reshape(-1)[p].reshape(v.shape))
+    sh = s0.copy()
+    for k, v in sh.a.items():
+        if k != "dzs":
+            sh.a[k] = np.ascontiguousarray(shuffle(v, perm))
+    dsh = sh.to_device("cuda:0")
+    engine.stream_sync()
+    q_sh = torch.from_numpy(np.ascontiguousarray(qlat.cpu().numpy().reshape(-1)[perm].reshape(s0.nj, s0.ni))).cuda()
+    engine.wtable_columns_async(dsh.wtable_args(), q_sh)
+    engine.stream_sync()
+    got = dsh.to_host()
+    for k in GW_OUT:
+        got.a[k] = shuffle(got.a[k], inv)
+    assert_same(want, got, what="two halves")
+    assert (want.a["qslat"] != 0).any()
