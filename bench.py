@@ -691,6 +691,16 @@ def main():
 
     if args.dump:
         run.dump(args.dump + ".rank%d.npz" % rank)
+    if rank == 0 and os.environ.get("NMP_PHASE_PROF"):
+        # profiling library only (-DNMP_PHASE_TIMERS, tools/phase_prof.py): shares of the kernel's time by phase, to stderr
+        import ctypes as C
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        from phase_prof import NAMES
+        ticks = (C.c_ulonglong * 32)()
+        eng.lib.noahmp_hip_debug_phase_ticks(ticks, 32)
+        tot = float(sum(ticks)) or 1.0
+        for ph in sorted(NAMES, key=lambda ph: -ticks[ph]):
+            print("phase %-42s %5.1f %%" % (NAMES[ph], 100.0 * ticks[ph] / tot), file=sys.stderr)
 
     # The default N > 1 workload is config 4 (the same grid with the groundwater exchange).  So that a scaling curve over
     # N = 1, 2, 4, 8 has its N = 1 point on the SAME workload, the default N = 1 run measures it too, after the headline (a second,

@@ -91,6 +91,7 @@ template <int N> NMP_DEV void nmp_powf_pairN(const float* x, float y1, float y2,
 NMP_DEV float nmp_powf(float x, float y) { NMP_CNT(2); return libm::powf_(x, y); }
 NMP_DEV float nmp_log10f(float x) { NMP_CNT(3); return libm::log10f_(x); }
 NMP_DEV float nmp_atanf(float x) { NMP_CNT(4); return libm::atanf_(x); }
+NMP_DEV float nmp_atanf_ge1(float x) { NMP_CNT(4); return libm::atanf_ge1_(x); }     // x >= 1 (SFCDIF1)
 NMP_DEV float nmp_tanhf(float x) { NMP_CNT(5); return libm::tanhf_(x); }
 NMP_DEV float nmp_tanf(float x) { return libm::tanf_(x); }     // OPT_RAD=1 only (lsm:2531-2539)
 NMP_DEV float nmp_acosf(float x) { return libm::acosf_(x); }
@@ -121,6 +122,7 @@ template <int N> NMP_DEV void nmp_powf_pairN(const float* x, float y1, float y2,
 NMP_DEV float nmp_powf(float x, float y) { return powf(x, y); }
 NMP_DEV float nmp_log10f(float x) { return log10f(x); }
 NMP_DEV float nmp_atanf(float x) { return atanf(x); }
+NMP_DEV float nmp_atanf_ge1(float x) { return atanf(x); }
 NMP_DEV float nmp_tanhf(float x) { return tanhf(x); }
 NMP_DEV float nmp_tanf(float x) { return tanf(x); }
 NMP_DEV float nmp_acosf(float x) { return acosf(x); }
@@ -138,7 +140,7 @@ NMP_DEV float pow_neg_quarter(float x) { return 1.0f / sqrtf(sqrtf(x)); }
 // With 2 waves interleaved per SIMD a tick interval contains the other wave's issue slots too, so the numbers
 // are shares of the kernel's time, not instruction counts.
 #if defined(NMP_PHASE_TIMERS)
-constexpr int NMP_NPHASE = 24;
+constexpr int NMP_NPHASE = 32;
 static __device__ unsigned long long g_nmp_prof[NMP_NPHASE * 256];
 #endif
 #if defined(NMP_PHASE_TIMERS) && defined(__HIP_DEVICE_COMPILE__)

@@ -380,10 +380,10 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, 
     float lg[4];
     nmp_logfN<4>(la, lg);                    // the four LOGs are independent: one batch
     const float tmp2 = lg[0], tmp3 = lg[1];
-    fmnew = 2.f * tmp3 + tmp2 - 2.f * nmp_atanf(tmp1) + 1.5707963f;
+    fmnew = 2.f * tmp3 + tmp2 - 2.f * nmp_atanf_ge1(tmp1) + 1.5707963f;
     fhnew = 2 * tmp2;
     const float tmp22 = lg[2], tmp32 = lg[3];
-    fm2new = 2.f * tmp32 + tmp22 - 2.f * nmp_atanf(tmp12) + 1.5707963f;
+    fm2new = 2.f * tmp32 + tmp22 - 2.f * nmp_atanf_ge1(tmp12) + 1.5707963f;
     fh2new = 2 * tmp22;
   } else {
     fmnew = -5.f * m.moz; fhnew = fmnew;

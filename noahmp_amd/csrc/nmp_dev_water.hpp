@@ -915,6 +915,7 @@ NMP_DEV void water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float q
   float snoflow = 0.f, qrain, snowhin, qdrain = 0.f, fcrmax = 0.f;
   s.runsub = 0.f;
   canwater(c, P, s, qrain, snowhin);
+  NMP_TIC(22);   // canwater
   float qsnsub = 0.f;
   if (s.sneqv > 0.f) qsnsub = nmp_min(qvap, div_rc(s.sneqv, c.u.dt));
   float qseva = qvap - qsnsub;
@@ -922,6 +923,7 @@ NMP_DEV void water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float q
   if (s.sneqv > 0.f) qsnfro = qdew;
   float qsdew = qdew - qsnfro;
   snowwater(c, s, y, snowhin, qsnfro, qsnsub, qrain, snoflow);
+  NMP_TIC(23);   // snowwater
   if (s.frozen_ground) {
     float si = y.sice[L(1)] + div_rc((qsdew - qseva) * dt, c.u.dzmm[L(1)]);     // DZSNSO(1) as rebuild_layers left it
     qsdew = 0.0f;
@@ -939,6 +941,7 @@ NMP_DEV void water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, float q
     if (iz <= P.nroot) etrani[L(iz)] = s.etran * y.btrani[L(iz)] * 0.001f;
   }
   soilwater(c, P, s, y, qinsur, qseva, etrani, qdrain, wcnd, fcrmax);
+  NMP_TIC(24);   // soilwater
   if (c.O.run == 1) {
     float qdis;
     groundwater(c, P, s, y, wcnd, fcrmax, qdis);

@@ -98,6 +98,10 @@ struct LaunchDesc {
 };
 // mode: 0 mixed tile, 1 land-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
 void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);
+#ifdef NMP_PHASE_TIMERS
+void prof_fixed_d1_r1(unsigned long long*, int); void prof_fixed_d3_r1(unsigned long long*, int); void prof_fixed_d3_r5(unsigned long long*, int);
+void prof_fixed_d4_r1(unsigned long long*, int); void prof_fixed_d4_r3(unsigned long long*, int);
+#endif
 void launch_fixed_d3_r1(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d3_r5(const LaunchDesc& d, int mode, hipStream_t s);
 void launch_fixed_d4_r1(const LaunchDesc& d, int mode, hipStream_t s);

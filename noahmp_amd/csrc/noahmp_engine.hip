@@ -864,7 +864,8 @@ const char* noahmp_hip_error_string(int code) {
 const char* noahmp_hip_last_error(void) { return g.last_error.c_str(); }
 
 #ifdef NMP_PHASE_TIMERS
-// profiling build only: read and clear the phase tick counters (summed over their 256 slots)
+// profiling build only: read and clear the phase tick counters (summed over their 256 slots, over the generic and the
+// option-specialised translation units: each has its own copy of the counters)
 int noahmp_hip_debug_phase_ticks(unsigned long long* out, int n) {
   std::vector<unsigned long long> h(nmp::NMP_NPHASE * 256);
   HIPCHK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(nmp::g_nmp_prof), h.size() * 8));
@@ -874,6 +875,10 @@ int noahmp_hip_debug_phase_ticks(unsigned long long* out, int n) {
   }
   std::fill(h.begin(), h.end(), 0ull);
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nmp::g_nmp_prof), h.data(), h.size() * 8));
+#ifndef NMP_NO_FIXED_KERNELS
+  nmp_host::prof_fixed_d1_r1(out, n); nmp_host::prof_fixed_d3_r1(out, n); nmp_host::prof_fixed_d3_r5(out, n);
+  nmp_host::prof_fixed_d4_r1(out, n); nmp_host::prof_fixed_d4_r3(out, n);
+#endif
   return 0;
 }
 #endif

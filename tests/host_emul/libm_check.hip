@@ -16,7 +16,7 @@ static inline bool same(float a, float b) {
   return asuint(a) == asuint(b);
 }
 
-// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f, 7 acosf, 8 tanf, 9 cosf, 10 sinf (|x| < 120).  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
+// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f, 7 acosf, 8 tanf, 9 cosf, 10 sinf (|x| < 120), 11 atanf_ge1_ (SFCDIF1's form of atanf).  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
 extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t* first_bad) {
   std::vector<long> bad(nthreads, 0);
   std::vector<uint32_t> fb(nthreads, 0);
@@ -32,6 +32,7 @@ extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t
           case 1: a = logf_(x); b = ::logf(x); break;
           case 2: a = log10f_(x); b = ::log10f(x); break;
           case 3: a = atanf_(x); b = ::atanf(x); break;
+          case 11: a = atanf_ge1_(x); b = ::atanf(x); break;
           case 4: a = tanhf_(x); b = ::tanhf(x); break;
           case 7: a = acosf_(x); b = ::acosf(x); break;
           case 8: a = tanf_(x); b = (fabsf(x) < 120.0f) ? ::tanf(x) : a; break;
@@ -118,6 +119,7 @@ __global__ void libm_eval_kernel(int fn, uint32_t start, uint32_t stride, long n
     case 1: r = logf_(x); break;
     case 2: r = log10f_(x); break;
     case 3: r = atanf_(x); break;
+    case 11: r = atanf_ge1_(x); break;
     case 4: r = tanhf_(x); break;
     case 5: r = expm1f_(x); break;
     case 7: r = acosf_(x); break;
@@ -154,6 +156,7 @@ extern "C" long libm_gpu_check(int fn, uint32_t start, uint32_t stride, long n, 
       case 1: b = ::logf(x); break;
       case 2: b = ::log10f(x); break;
       case 3: b = ::atanf(x); break;
+      case 11: b = ::atanf(x); break;
       case 4: b = ::tanhf(x); break;
       case 5: b = ::expm1f(x); break;
       case 7: b = ::acosf(x); break;
@@ -176,6 +179,7 @@ extern "C" uint32_t libm_eval_unary(int fn, uint32_t xbits) {
     case 1: r = logf_(x); break;
     case 2: r = log10f_(x); break;
     case 3: r = atanf_(x); break;
+    case 11: r = atanf_ge1_(x); break;
     case 4: r = tanhf_(x); break;
     case 5: r = expm1f_(x); break;
   }

@@ -19,8 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "host_emul", "libm_check.hip")
 LIB = os.path.join(HERE, "host_emul", "liblibm_check.so")
-NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f", "powf", "acosf", "tanf", "cosf", "sinf"]
-UNARY = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10]      # 6 = powf (binary)
+NAMES = ["expf", "logf", "log10f", "atanf", "tanhf", "expm1f", "powf", "acosf", "tanf", "cosf", "sinf", "atanf_ge1"]
+UNARY = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]      # 6 = powf (binary)
 
 
 def build():
@@ -136,7 +136,7 @@ def test_tables_regenerate_identically(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fn", range(11), ids=NAMES)
+@pytest.mark.parametrize("fn", range(12), ids=NAMES)
 def test_device_code_matches_libm(fn):
     lib = _lib()
     fb = C.c_uint32(0)
