@@ -336,7 +336,7 @@ NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1, const 
 }
 
 struct MoState {
-  float moz, fm, fh, fm2, fh2, fv; int mozsgn;
+  float moz, fm, fh, fh2, fv; int mozsgn;      // FM2 (lsm:4165, 4178, 4189) feeds nothing: not evaluated
   // LOG((ZLVL-ZPD)/Z0M) etc. (lsm:4117-4120): the reference re-evaluates them in every iteration of the
   // flux loops with unchanged arguments; here they are evaluated when the arguments change (iteration 1)
   float tmpcm, tmpch, tmpcm2, tmpch2, z0h_c;
@@ -348,7 +348,7 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, 
                      float zpd, float z0m, float z0h, float ur, float mpe, MoState& m, float& cm,
                      float& ch) {
   float mozold = m.moz;
-  float moz2, fmnew, fhnew, fm2new, fh2new;
+  float moz2, fmnew, fhnew, fh2new;
   if (zlvl <= zpd) { if (!err) err = NOAHMP_ERR_STABILITY_STOP; }
   if (iter == 1) {                     // zlvl, zpd, z0m are fixed over the caller's loop
     m.tmpcm = nmp_logf((zlvl - zpd) / z0m);
@@ -359,7 +359,7 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, 
     else { m.tmpch = nmp_logf((zlvl - zpd) / z0h); m.tmpch2 = nmp_logf((2.0f + z0h) / z0h); }
     m.z0h_c = z0h;
   }
-  const float tmpcm = m.tmpcm, tmpch = m.tmpch, tmpcm2 = m.tmpcm2, tmpch2 = m.tmpch2;
+  const float tmpcm = m.tmpcm, tmpch = m.tmpch, tmpch2 = m.tmpch2;
   if (iter == 1) {
     m.fv = 0.0f; m.moz = 0.0f; moz2 = 0.0f;
   } else {
@@ -372,35 +372,32 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, 
     moz2 = nmp_min(div_rc(2.0f + z0h, r_mol), 1.f);
   }
   if (mozold * m.moz < 0.f) m.mozsgn = m.mozsgn + 1;
-  if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fm2 = 0.f; m.fh2 = 0.f; }
+  if (m.mozsgn >= 2) { m.moz = 0.f; m.fm = 0.f; m.fh = 0.f; moz2 = 0.f; m.fh2 = 0.f; }
   if (m.moz < 0.f) {
     float tmp1, tmp12;                       // the two X = (1-16 MOZ)**0.25 are independent: evaluate them interleaved
     pow_quarter2(1.f - 16.f * m.moz, 1.f - 16.f * moz2, tmp1, tmp12);
-    const float la[4] = {(1.f + tmp1 * tmp1) / 2.f, (1.f + tmp1) / 2.f, (1.f + tmp12 * tmp12) / 2.f, (1.f + tmp12) / 2.f};
-    float lg[4];
-    nmp_logfN<4>(la, lg);                    // the four LOGs are independent: one batch
+    const float la[3] = {(1.f + tmp1 * tmp1) / 2.f, (1.f + tmp1) / 2.f, (1.f + tmp12 * tmp12) / 2.f};
+    float lg[3];
+    nmp_logfN<3>(la, lg);                    // the LOGs are independent: one batch
     const float tmp2 = lg[0], tmp3 = lg[1];
     fmnew = 2.f * tmp3 + tmp2 - 2.f * nmp_atanf_ge1(tmp1) + 1.5707963f;
     fhnew = 2 * tmp2;
-    const float tmp22 = lg[2], tmp32 = lg[3];
-    fm2new = 2.f * tmp32 + tmp22 - 2.f * nmp_atanf_ge1(tmp12) + 1.5707963f;
+    const float tmp22 = lg[2];
     fh2new = 2 * tmp22;
   } else {
     fmnew = -5.f * m.moz; fhnew = fmnew;
-    fm2new = -5.f * moz2; fh2new = fm2new;
+    fh2new = -5.f * moz2;
   }
   if (iter == 1) {
-    m.fm = fmnew; m.fh = fhnew; m.fm2 = fm2new; m.fh2 = fh2new;
+    m.fm = fmnew; m.fh = fhnew; m.fh2 = fh2new;
   } else {
     m.fm = 0.5f * (m.fm + fmnew);
     m.fh = 0.5f * (m.fh + fhnew);
-    m.fm2 = 0.5f * (m.fm2 + fm2new);
     m.fh2 = 0.5f * (m.fh2 + fh2new);
   }
   m.fh = nmp_min(m.fh, 0.9f * tmpch);
   m.fm = nmp_min(m.fm, 0.9f * tmpcm);
   m.fh2 = nmp_min(m.fh2, 0.9f * tmpch2);
-  m.fm2 = nmp_min(m.fm2, 0.9f * tmpcm2);
   float cmfm = tmpcm - m.fm, chfh = tmpch - m.fh;
   if (fabsf(cmfm) <= mpe) cmfm = mpe;
   if (fabsf(chfh) <= mpe) chfh = mpe;
@@ -738,7 +735,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.ur = ur; L.z0mg = q.z0mg; L.cwp = q.cwp; L.fveg = fveg; L.rsurf = q.rsurf; L.eair = s.eair;
     L.gammav = q.gammav; L.canliq = s.canliq; L.canice = s.canice; L.latheav = s.latheav; L.sav = s.sav;
     L.fwet = s.fwet; L.sfcprs = s.sfcprs; L.thair = s.thair; L.czil = P.czil;
-    L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
+    L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
     L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
     L.r_rhocp = q.r_rhocp; L.r_gammav = q.r_gammav;
     const double r_fveg = rc64(fveg);
@@ -826,7 +823,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float zpdg, float& cmb) {
   const float MPE = 1E-6f;
   const float rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur, z0m = q.z0mg;
-  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
+  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
   float h = 0.f, wstar = 0.f;
   float t, estg = 0.f, destg, csh = 0.f, cev = 0.f, ehb = 0.f;
   float& tgb = s.tgb; float& ch = s.chb; float& cm = cmb;

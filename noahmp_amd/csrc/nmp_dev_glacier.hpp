@@ -300,7 +300,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
   const float emg = 0.98f, rhsur = 1.0f, rsurf = 1.0f, lathea = HSUB;
   const float gamma = CPAIR * s.sfcprs / (0.622f * lathea);
   {                                                       // GLACIER_FLUX gla:942-1148
-    MoState mo = {0.f, 0.f, 0.f, 0.f, 0.f, 0.1f, 0};
+    MoState mo = {0.f, 0.f, 0.f, 0.f, 0.1f, 0};
     float h = 0.f, t, estg = 0.f, destg, csh = 0.f, cev = 0.f, rahb = 1.f;
     const float cir = emg * SB;
     const float df_top = at_top(df, s.isnow);

@@ -16,7 +16,22 @@ static inline bool same(float a, float b) {
   return asuint(a) == asuint(b);
 }
 
-// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f, 7 acosf, 8 tanf, 9 cosf, 10 sinf (|x| < 120), 11 atanf_ge1_ (SFCDIF1's form of atanf).  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
+// the batched forms (logfN_<3>, expfN_<4>, powfN_<2>): the argument under test sits at position pos of the batch, the other
+// positions hold arguments derived from its bits (specials included, since the walk covers every class of bit pattern)
+__host__ __device__ static inline float batched_unary(int fn, uint32_t bits, int pos) {
+  if (fn == 12) {
+    float a[3], o[3];
+    for (int q = 0; q < 3; q++) a[(pos + q) % 3] = asfloat(q == 0 ? bits : (q == 1 ? bits ^ 0x00400000u : bits * 2654435761u));
+    logfN_<3>(a, o);
+    return o[pos % 3];
+  }
+  float a[4], o[4];
+  for (int q = 0; q < 4; q++) a[(pos + q) % 4] = asfloat(q == 0 ? bits : (q == 1 ? bits ^ 0x80000000u : (q == 2 ? bits ^ 0x00400000u : bits * 2654435761u)));
+  expfN_<4>(a, o);
+  return o[pos % 4];
+}
+
+// fn: 0 expf, 1 logf, 2 log10f, 3 atanf, 4 tanhf, 5 expm1f, 7 acosf, 8 tanf, 9 cosf, 10 sinf (|x| < 120), 11 atanf_ge1_ (SFCDIF1's form of atanf), 12 logfN_<3>, 13 expfN_<4> (batched forms; 14 = powfN_<2> on the GPU).  Walks bit patterns start, start+stride, ... over the whole 2^32 space.
 extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t* first_bad) {
   std::vector<long> bad(nthreads, 0);
   std::vector<uint32_t> fb(nthreads, 0);
@@ -33,6 +48,8 @@ extern "C" long libm_check_unary(int fn, uint32_t stride, int nthreads, uint32_t
           case 2: a = log10f_(x); b = ::log10f(x); break;
           case 3: a = atanf_(x); b = ::atanf(x); break;
           case 11: a = atanf_ge1_(x); b = ::atanf(x); break;
+          case 12: a = batched_unary(12, (uint32_t)u, (int)(u / stride % 3)); b = ::logf(x); break;
+          case 13: a = batched_unary(13, (uint32_t)u, (int)(u / stride % 4)); b = ::expf(x); break;
           case 4: a = tanhf_(x); b = ::tanhf(x); break;
           case 7: a = acosf_(x); b = ::acosf(x); break;
           case 8: a = tanf_(x); b = (fabsf(x) < 120.0f) ? ::tanf(x) : a; break;
@@ -98,6 +115,20 @@ extern "C" long libm_check_pow(int mode, long n, int nthreads, uint32_t* bad_xy)
         }
         const float a = powf_(x, y), b = ::powf(x, y);
         if (!same(a, b)) { if (!bad[t]) { bx[t] = asuint(x); by[t] = asuint(y); } bad[t]++; }
+        // the batched forms on the same arguments: powfN_<2>, powf_pairN_<2> (shared log2 x), powf_constbaseN_<1> (log2 x given)
+        const float xs[2] = {x, asfloat(asuint(x) ^ 0x00200000u)}, ys[2] = {y, -y};
+        float o[2], o1[2], o2[2];
+        powfN_<2>(xs, ys, o);
+        powf_pairN_<2>(xs, y, ys[1], o1, o2);
+        int nb = !same(o[0], b) + !same(o[1], ::powf(xs[1], ys[1])) + !same(o1[0], b) + !same(o1[1], ::powf(xs[1], y)) +
+                 !same(o2[0], ::powf(x, ys[1])) + !same(o2[1], ::powf(xs[1], ys[1]));
+        if (asuint(x) - 0x00800000u < 0x7f000000u) {
+          const double l2[1] = {powf_log2_k(asuint(x))};
+          float oc[1];
+          powf_constbaseN_<1>(&x, l2, &y, oc);
+          nb += !same(oc[0], b);
+        }
+        if (nb) { if (!bad[t]) { bx[t] = asuint(x); by[t] = asuint(y); } bad[t] += nb; }
       }
     });
   for (auto& x : th) x.join();
@@ -120,6 +151,16 @@ __global__ void libm_eval_kernel(int fn, uint32_t start, uint32_t stride, long n
     case 2: r = log10f_(x); break;
     case 3: r = atanf_(x); break;
     case 11: r = atanf_ge1_(x); break;
+    case 12: r = batched_unary(12, start + (uint32_t)i * stride, (int)(i % 3)); break;
+    case 13: r = batched_unary(13, start + (uint32_t)i * stride, (int)(i % 4)); break;
+    case 14: {                                  // powfN_<2>: (x, y) at position i % 2, a derived pair at the other
+      float xs[2], ys[2], o[2];
+      const int p = (int)(i & 1);
+      xs[p] = x; ys[p] = y[i]; xs[1 - p] = asfloat(asuint(x) ^ 0x00200000u); ys[1 - p] = -y[i];
+      powfN_<2>(xs, ys, o);
+      r = o[p];
+      break;
+    }
     case 4: r = tanhf_(x); break;
     case 5: r = expm1f_(x); break;
     case 7: r = acosf_(x); break;
@@ -136,7 +177,7 @@ extern "C" long libm_gpu_check(int fn, uint32_t start, uint32_t stride, long n, 
   float *d_out = nullptr, *d_y = nullptr;
   std::vector<float> out(n), y;
   if (hipMalloc(&d_out, n * sizeof(float)) != hipSuccess) return -1;
-  if (fn == 6) {
+  if (fn == 6 || fn == 14) {
     y.resize(n);
     uint64_t s = 99;
     for (long i = 0; i < n; i++) y[i] = ((float)((uint32_t)(splitmix(s) >> 40)) * 0x1p-24f - 0.5f) * 64.f;
@@ -157,6 +198,8 @@ extern "C" long libm_gpu_check(int fn, uint32_t start, uint32_t stride, long n, 
       case 2: b = ::log10f(x); break;
       case 3: b = ::atanf(x); break;
       case 11: b = ::atanf(x); break;
+      case 12: b = ::logf(x); break;
+      case 13: b = ::expf(x); break;
       case 4: b = ::tanhf(x); break;
       case 5: b = ::expm1f(x); break;
       case 7: b = ::acosf(x); break;
@@ -180,6 +223,8 @@ extern "C" uint32_t libm_eval_unary(int fn, uint32_t xbits) {
     case 2: r = log10f_(x); break;
     case 3: r = atanf_(x); break;
     case 11: r = atanf_ge1_(x); break;
+    case 12: r = batched_unary(12, xbits, 0); break;
+    case 13: r = batched_unary(13, xbits, 0); break;
     case 4: r = tanhf_(x); break;
     case 5: r = expm1f_(x); break;
   }
