@@ -831,6 +831,11 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   const float cir = q.emg * SB;
   const float cgh = 2.f * q.df_top / q.dz_top;
   const float gamma = q.gammag, lathea = s.latheag;
+  // ESAT of the ground temperature (lsm:3789, 3836): the call that follows TGB's update in one iteration has the argument of the call
+  // that opens the next one, so each TGB is evaluated once; the flux corrections by DTG and QSFC (lsm:3821-3824, 3842) are
+  // overwritten by the next iteration before anything reads them, so only the fifth evaluates them
+  t = tdc(tgb);
+  esat_sel(t, estg, destg);
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
     if (c.O.sfc == 1) {
@@ -845,8 +850,6 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     float rawb = rahb;
     const double r_rahb = rc64(rahb);
     ehb = div_rc(1.f, r_rahb);
-    t = tdc(tgb);
-    esat_sel(t, estg, destg);
     csh = div_rc(rhoair * CPAIR, r_rahb);
     cev = div_rc(rhoair * CPAIR, q.r_gammag) / (q.rsurf + rawb);
     s.irb = cir * powi4(tgb) - q.emg * s.lwdn;
@@ -856,15 +859,17 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     float b = s.sag - s.irb - s.shb - s.evb - s.ghb;
     float a = 4.f * cir * powi3(tgb) + csh + cev * destg + cgh;
     float dtg = b / a;
-    s.irb = s.irb + 4.f * cir * powi3(tgb) * dtg;
-    s.shb = s.shb + csh * dtg;
-    s.evb = s.evb + cev * destg * dtg;
-    s.ghb = s.ghb + cgh * dtg;
+    if (iter == 5) {
+      s.irb = s.irb + 4.f * cir * powi3(tgb) * dtg;
+      s.shb = s.shb + csh * dtg;
+      s.evb = s.evb + cev * destg * dtg;
+      s.ghb = s.ghb + cgh * dtg;
+    }
     tgb = tgb + dtg;
     h = csh * (tgb - sfctmp);
     t = tdc(tgb);
-    { float dummy; esat_sel(t, estg, dummy); }
-    s.qsfc = 0.622f * (estg * q.rhsur) / (s.psfc - 0.378f * (estg * q.rhsur));
+    esat_sel(t, estg, destg);
+    if (iter == 5) s.qsfc = 0.622f * (estg * q.rhsur) / (s.psfc - 0.378f * (estg * q.rhsur));
   }
   if (c.O.stc == 1) {
     if (s.snowh > 0.05f && tgb > TFRZ) {
