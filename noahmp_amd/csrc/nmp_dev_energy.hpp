@@ -578,8 +578,7 @@ struct VegLoop {
   double r_rhocp, r_hcan, r_gammav;     // 1 / (RHOAIR*CPAIR), 1 / HCAN, 1 / GAMMAV: divisors of every iteration (div_rc)
   // carried from iteration to iteration / read after the loop
   MoState mo;
-  float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, qsfc,
-        wstar;
+  float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, wstar;
   int liter, err, iter, done;    // iter = the next iteration to run (2..21); done = loop1 has exited
 };
 constexpr int VEGLOOP_WORDS = sizeof(VegLoop) / 4;
@@ -693,7 +692,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   L.tv = L.tv + L.dtv;
   L.h = div_rc(rhoair * CPAIR * (L.tah - sfctmp), r_rahc);
   L.hg = div_rc(rhoair * CPAIR * (tg - L.tah), r_rahg);
-  L.qsfc = (0.622f * L.eah) / (L.sfcprs - 0.378f * L.eah);
+  // QSFC (lsm:3447) is a function of EAH that nothing inside the loop reads: evaluated once, after the loop (vege_flux)
   NMP_TIC(20);   // vege loop1: flux solve
   NMP_CNT(7);    // (host-emulation instrumentation) loop1 iterations
   // loop control, lsm:3451-3456
@@ -744,7 +743,6 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.laishae = nmp_min(6.f, div_rc(q.laisha, r_fveg));
     float t = tdc(L.tg), destg_unused;
     esat_sel(t, L.estg, destg_unused);
-    L.qsfc = 0.622f * s.eair / (s.psfc - 0.378f * s.eair);
     L.hcan = s.htop;
     L.r_hcan = rc64(L.hcan);
     float uc = ur * nmp_logf(L.hcan / q.z0m) / nmp_logf(q.zlvl / q.z0m);
@@ -758,17 +756,18 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     vege_iter<true>(c, L, 1, &f);                       // iteration 1 (with STOMATA / CANRES)
     psnsun = f.psnsun; psnsha = f.psnsha;
   }
-  if (NMP_TRUNC == 4) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.qsfc + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch; s.err = 99; return; }
+  if (NMP_TRUNC == 4) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch; s.err = 99; return; }
   runner.run(c, L, canopy);                             // iterations 2..20
   NMP_TIC(21);
-  if (NMP_TRUNC == 5) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.qsfc + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch + L.mo.fv + L.mo.fh2; s.err = 99; return; }
+  if (NMP_TRUNC == 5) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch + L.mo.fv + L.mo.fh2; s.err = 99; return; }
   if (!canopy) return;
   if (L.err) raise(s, L.err);
   float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah;
   const float rhoair = s.rhoair;
   tv = L.tv; tah = L.tah; eah = L.eah; cmv = L.cm;
   s.rssun = L.rssun; s.rssha = L.rssha;
-  s.irc = L.irc; s.shc = L.shc; s.evc = L.evc; s.tr = L.tr; s.qsfc = L.qsfc;
+  s.irc = L.irc; s.shc = L.shc; s.evc = L.evc; s.tr = L.tr;
+  s.qsfc = (0.622f * L.eah) / (L.sfcprs - 0.378f * L.eah);        // lsm:3447, with the loop's last EAH
   const float rahg = L.rahg, rawg = L.rahg, cah = L.cah, cvh = L.cvh, z0h = q.z0m, fveg = s.fveg;
   float t, estg = L.estg, destg = 0.f;
   // under-canopy ground, lsm:3495-3542
