@@ -339,14 +339,15 @@ struct MoState {
   float moz, fm, fh, fh2, fv; int mozsgn;      // FM2 (lsm:4165, 4178, 4189) feeds nothing: not evaluated
   // LOG((ZLVL-ZPD)/Z0M) etc. (lsm:4117-4120): the reference re-evaluates them in every iteration of the
   // flux loops with unchanged arguments; here they are evaluated when the arguments change (iteration 1)
-  float tmpcm, tmpch, tmpcm2, tmpch2, z0h_c;
+  float tmpcm, tmpcm2;     // every caller passes Z0H = Z0M (lsm:3311-3314, 3772-3774; gla:1059), so TMPCH = TMPCM and TMPCH2 = TMPCM2
 };
 
 // SFCDIF1 lsm:4061-4220
 // r_rhocp: float64 reciprocal of RHOAIR*CPAIR (the callers' loops divide by it once per iteration; div_rc, nmp_dev_common.hpp)
 NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, float qair, float zlvl,
-                     float zpd, float z0m, float z0h, float ur, float mpe, MoState& m, float& cm,
+                     float zpd, float z0m, float ur, float mpe, MoState& m, float& cm,
                      float& ch) {
+  const float z0h = z0m;
   float mozold = m.moz;
   float moz2, fmnew, fhnew, fh2new;
   if (zlvl <= zpd) { if (!err) err = NOAHMP_ERR_STABILITY_STOP; }
@@ -354,12 +355,7 @@ NMP_DEV void sfcdif1(int& err, int iter, float sfctmp, double r_rhocp, float h, 
     m.tmpcm = nmp_logf((zlvl - zpd) / z0m);
     m.tmpcm2 = nmp_logf((2.0f + z0m) / z0m);
   }
-  if (iter == 1 || z0h != m.z0h_c) {   // z0h is fixed too unless the caller updates it (glacier / IZ0TLND)
-    if (z0h == z0m) { m.tmpch = m.tmpcm; m.tmpch2 = m.tmpcm2; }
-    else { m.tmpch = nmp_logf((zlvl - zpd) / z0h); m.tmpch2 = nmp_logf((2.0f + z0h) / z0h); }
-    m.z0h_c = z0h;
-  }
-  const float tmpcm = m.tmpcm, tmpch = m.tmpch, tmpch2 = m.tmpch2;
+  const float tmpcm = m.tmpcm, tmpch = m.tmpcm, tmpch2 = m.tmpcm2;
   if (iter == 1) {
     m.fv = 0.0f; m.moz = 0.0f; moz2 = 0.0f;
   } else {
@@ -595,7 +591,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   const float sfctmp = L.sfctmp, rhoair = L.rhoair, ur = L.ur, fveg = L.fveg, tg = L.tg;
   const float z0h = L.z0m, z0hg = L.z0mg, hcan = L.hcan;
   if (c.O.sfc == 1) {
-    sfcdif1(L.err, iter, sfctmp, L.r_rhocp, L.h, L.qair, L.zlvl, L.zpd, L.z0m, z0h, ur, MPE, L.mo, L.cm, L.ch);
+    sfcdif1(L.err, iter, sfctmp, L.r_rhocp, L.h, L.qair, L.zlvl, L.zpd, L.z0m, ur, MPE, L.mo, L.cm, L.ch);
   } else {
     sfcdif2(iter, L.z0m, L.tah, L.thair, ur, L.czil, L.zlvl, L.cm, L.ch, L.mo.moz, L.wstar, L.mo.fv);
     L.ch = L.ch / ur;
@@ -734,7 +730,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.ur = ur; L.z0mg = q.z0mg; L.cwp = q.cwp; L.fveg = fveg; L.rsurf = q.rsurf; L.eair = s.eair;
     L.gammav = q.gammav; L.canliq = s.canliq; L.canice = s.canice; L.latheav = s.latheav; L.sav = s.sav;
     L.fwet = s.fwet; L.sfcprs = s.sfcprs; L.thair = s.thair; L.czil = P.czil;
-    L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
+    L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f};
     L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
     L.r_rhocp = q.r_rhocp; L.r_gammav = q.r_gammav;
     const double r_fveg = rc64(fveg);
@@ -822,7 +818,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, float zpdg, float& cmb) {
   const float MPE = 1E-6f;
   const float rhoair = s.rhoair, sfctmp = s.sfctmp, ur = q.ur, z0m = q.z0mg;
-  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f, 0.f, 0.f, 0.f};
+  MoState mo = {0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f};
   float h = 0.f, wstar = 0.f;
   float t, estg = 0.f, destg, csh = 0.f, cev = 0.f, ehb = 0.f;
   float& tgb = s.tgb; float& ch = s.chb; float& cm = cmb;
@@ -838,7 +834,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
     if (c.O.sfc == 1) {
-      sfcdif1(s.err, iter, sfctmp, q.r_rhocp, h, s.qair, q.zlvl, zpdg, z0m, z0h, ur, MPE, mo, cm, ch);
+      sfcdif1(s.err, iter, sfctmp, q.r_rhocp, h, s.qair, q.zlvl, zpdg, z0m, ur, MPE, mo, cm, ch);
     } else {
       sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
       ch = ch / ur;

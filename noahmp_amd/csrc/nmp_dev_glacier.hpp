@@ -310,7 +310,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     const double r_rhocp = rc64(s.rhoair * CPAIR);
 #pragma unroll 1
     for (int iter = 1; iter <= 5; iter++) {
-      sfcdif1(s.err, iter, s.sfctmp, r_rhocp, h, s.qair, zlvl, zpd, z0m, z0m, ur, MPE, mo, s.cm, s.ch);
+      sfcdif1(s.err, iter, s.sfctmp, r_rhocp, h, s.qair, zlvl, zpd, z0m, ur, MPE, mo, s.cm, s.ch);
       rahb = nmp_max(1.f, 1.f / (s.ch * ur));
       float rawb = rahb;
       t = tdc(tgb);
