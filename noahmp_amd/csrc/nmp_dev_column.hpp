@@ -47,23 +47,37 @@ NMP_DEV Lay<LArr<STRIDE>> make_lay(float* base) {
   return y;
 }
 
+// Memory position of a column's word in one of the caller's arrays.  NMP_WIDE_INDEX (the generic translation unit): 64-bit element
+// indices, any array size.  Otherwise (option-specialised units): 32-bit BYTE offsets from the array's base, which is a kernel argument in
+// scalar registers -- an access can be `global_load_dword v, v_offset, s[base:base+1]` with no vector address arithmetic, and the offsets
+// that stay live are single registers instead of pairs (land kernel: 13 spilled registers -> 0, -1.4 %).  The explicit raw-buffer form
+// (`buffer_load_dword ... offen` for every access) measured no better.  The host sends a call whose largest array reaches 4 GiB to the
+// generic unit (noahmp_hip_index_width, noahmp_engine.hip: fixed_level).
+#ifdef NMP_WIDE_INDEX
+typedef size_t nmp_ij_t;
 #define G2(f) k.a.f[ij]
 #define G3(f, lev, nk) k.a.f[((size_t)jj * (nk) + (lev)) * k.ni + ii]
+#else
+typedef uint32_t nmp_ij_t;
+template <class T> NMP_DEV T& at32(T* base, uint32_t idx) { return *(T*)((char*)base + (size_t)(idx * (uint32_t)sizeof(T))); }
+#define G2(f) nmp::at32(k.a.f, ij)
+#define G3(f, lev, nk) nmp::at32(k.a.f, ((uint32_t)jj * (uint32_t)(nk) + (uint32_t)(lev)) * (uint32_t)k.ni + (uint32_t)ii)
+#endif
 
 
 // memory position of tile column t (no memory access); false: outside the tile
-NMP_DEV bool column_index(const KArgs& k, long t, int& ii, int& jj, size_t& ij) {
+NMP_DEV bool column_index(const KArgs& k, long t, int& ii, int& jj, nmp_ij_t& ij) {
   if (t >= (long)k.nti * k.ntj) return false;
   const int tj = (int)(t / k.nti), ti = (int)(t - (long)tj * k.nti);
   ii = k.a.its - k.a.ims + ti;
   jj = k.a.jts - k.a.jms + tj;
-  ij = (size_t)jj * k.ni + ii;
+  ij = (nmp_ij_t)jj * (nmp_ij_t)k.ni + (nmp_ij_t)ii;
   return true;
 }
 
 // Classify a column from its XLAND, XICE, IVGTYP and apply the water / sea-ice shortcuts (drv:399-441).
 // returns 0 land, 1 glacier, 2 skipped
-NMP_DEV int column_classify_values(const KArgs& k, float xland, float xice, int ivg, int ii, int jj, size_t ij) {
+NMP_DEV int column_classify_values(const KArgs& k, float xland, float xice, int ivg, int ii, int jj, nmp_ij_t ij) {
   int ice = (xice >= k.a.xice_thres) ? 1 : ((ivg == k.a.isice) ? -1 : 0);      // drv:426-432
   const bool water = (xland - 1.5f) >= 0.f;
   if (k.a.itimestep == 1) {                                                      // drv:399-419
@@ -85,7 +99,7 @@ NMP_DEV int column_classify_values(const KArgs& k, float xland, float xice, int 
 }
 
 // Classify column t (loads its XLAND, XICE, IVGTYP).  returns 0 land, 1 glacier, 2 skipped, 3 outside the tile
-NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij) {
+NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, nmp_ij_t& ij) {
   if (!column_index(k, t, ii, jj, ij)) return 3;
   const float xland = G2(xland), xice = G2(xice);
   const int ivg = G2(ivgtyp);
@@ -95,7 +109,7 @@ NMP_DEV int column_classify(const KArgs& k, long t, int& ii, int& jj, size_t& ij
 // Outputs that are final once the ENERGY phase is done (nothing in WATER / CARBON / the SFLX tail touches
 // them).  Land columns store them right after ENERGY so that their ~48 registers are free during the
 // water phase (fewer spills at 2 waves/SIMD); glacier columns store them with everything else.
-NMP_DEV void scatter_energy_outputs(const KArgs& k, const Col& s, size_t ij) {
+NMP_DEV void scatter_energy_outputs(const KArgs& k, const Col& s, nmp_ij_t ij) {
   G2(tsk) = s.trad; G2(hfx) = s.fsh; G2(grdflx) = s.ssoil;                             // drv:728-730
   if (s.albedo > -999) G2(albedo) = s.albedo;                                          // drv:741
   G2(snowc) = s.fsno; G2(emiss) = s.emissi;
@@ -113,7 +127,7 @@ NMP_DEV void scatter_energy_outputs(const KArgs& k, const Col& s, size_t ij) {
 }
 
 // The part of the gather (drv:449-545) that only WATER, CARBON and the final pass-through scatter read.
-NMP_DEV void gather_water_state(const KArgs& k, Col& s, size_t ij) {
+NMP_DEV void gather_water_state(const KArgs& k, Col& s, nmp_ij_t ij) {
   s.wslake = G2(wslakexy); s.zwt = G2(zwtxy); s.wt = G2(wtxy);
   s.lfmass = G2(lfmassxy); s.rtmass = G2(rtmassxy); s.stmass = G2(stmassxy); s.wood = G2(woodxy);
   s.stblcp = G2(stblcpxy); s.fastcp = G2(fastcpxy);
@@ -134,7 +148,7 @@ NMP_DEV void gather_water_state(const KArgs& k, Col& s, size_t ij) {
 // one memory round trip instead of two in a row at the start of every wave, and the class comes back through *cls_out -- a column
 // of another class than the range was declared to hold is left untouched (the caller raises NOAHMP_ERR_CLASS_RANGE).
 template <int STRIDE, int MODE = 0, bool EARLY = false, class Runner>
-NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, size_t ij, float* base, Runner& runner, int* cls_out = nullptr) {
+NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, float* base, Runner& runner, int* cls_out = nullptr) {
   Lay<LArr<STRIDE>> y = make_lay<STRIDE>(base);
   // value-initialise (NOT memset(): HIP's device memset is a byte loop through a pointer PHI, which
   // pins the whole struct in scratch and defeats scalar replacement -- 556 B/lane of scratch traffic)

@@ -36,7 +36,7 @@ __device__ __forceinline__ void column_kernel_body(const KArgs& k) {
   const long tl = (long)blockIdx.x * BLOCK + threadIdx.x;
   const long t = k.t_first + tl;
   int ii = 0, jj = 0;
-  size_t ij = 0;
+  nmp_ij_t ij = 0;
   int cls = 3, err = 0;
   if (MODE == 1 || MODE == 2) {
     // class range of a sorted layout: the gather does not wait for the classification (column_step<.., EARLY>)

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include "noahmp_hip.h"
+#define NMP_WIDE_INDEX 1     // this unit's kernels (run-time options; land ice; skipped cells) address arrays of any size (nmp_dev_column.hpp)
 #include "nmp_kernel.hpp"
 
 using namespace nmp;
@@ -249,6 +250,7 @@ static int fixed_level(const KArgs& k) {
 #else
   const Opt& o = k.c.O;
   if (!g.fixed_kernels) return 0;
+  if (noahmp_hip_index_width(k.ni, k.a.jme - k.a.jms + 1, k.nka) != 32) return 0;   // the specialised kernels use 32-bit byte offsets
   if (!(o.crs == 1 && o.btr == 1 && o.sfc == 1 && o.frz == 1 && o.inf == 1 && o.rad == 3 && o.alb == 2 &&
         o.snf == 1 && o.tbot == 2 && o.stc == 1)) return g.jit_kernels ? -1 : 0;
   for (int n = 0; n < (int)(sizeof(kFixed) / sizeof(kFixed[0])); n++)
@@ -862,6 +864,13 @@ const char* noahmp_hip_error_string(int code) {
 }
 
 const char* noahmp_hip_last_error(void) { return g.last_error.c_str(); }
+
+// 32: every array of a call with these memory extents (ni x nj cells, the widest one having max(7, nk_atm) levels) ends below 4 GiB, so
+// the option-specialised kernels (32-bit byte offsets, nmp_dev_column.hpp) can serve it; 64: the generic kernels do.
+int noahmp_hip_index_width(int ni_mem, int nj_mem, int nk_atm) {
+  const unsigned long long lev = nk_atm > 7 ? nk_atm : 7;
+  return ((unsigned long long)ni_mem * (unsigned long long)nj_mem * lev * 4ull < (1ull << 32)) ? 32 : 64;
+}
 
 #ifdef NMP_PHASE_TIMERS
 // profiling build only: read and clear the phase tick counters (summed over their 256 slots, over the generic and the

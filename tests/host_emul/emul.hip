@@ -43,7 +43,7 @@ extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
   for (long t = 0; t < n; t++) {
     float base[LAY_SLOTS];
     int ii = 0, jj = 0;
-    size_t ij = 0;
+    nmp_ij_t ij = 0;
     int cls = column_classify(k, t, ii, jj, ij);
     if (cls == 2) st->n_skipped++;
     if (cls > 1) continue;

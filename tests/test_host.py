@@ -65,6 +65,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.noahmp_hip_error_string(7).decode().startswith("Water budget")
 
 
+def test_index_width_gate():
+    """The option-specialised kernels address with 32-bit byte offsets: a call whose widest array (max(7, atmospheric levels) levels)
+    reaches 4 GiB is served by the generic kernels (host arithmetic only; no device call)."""
+    lib = abi.load_library()
+    w = lib.noahmp_hip_index_width
+    assert w(4608, 1536, 2) == 32 and w(3600, 1800, 2) == 32
+    assert w(153391689, 1, 2) == 32 and w(153391690, 1, 2) == 64          # 28 B per cell over 7 levels: 2^32 / 28
+    assert w(16384, 16384, 2) == 64
+    assert w(4608, 1536, 50) == 32 and w(21474836, 1, 50) == 32 and w(21474837, 1, 50) == 64   # 200 B per cell
+
+
 def test_engine_fails_loudly_without_gpu(tables):
     """No CPU fallback: without a device the engine refuses to run."""
     import torch

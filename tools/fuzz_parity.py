@@ -177,6 +177,8 @@ def one_seed(mode, seed, ncol, kw):
         import torch  # noqa: F401
         from noahmp_amd.driver import Engine
         other = Engine(T, device=0)
+        if os.environ.get("NMP_NO_JIT"):                    # debugging: option sets outside the ahead-of-time kernels take the generic kernel
+            other.lib.noahmp_hip_set_option(b"jit_option_kernels", 0)
         step = lambda x, it: other.noahmplsm(x, it, YR, JUL, check=False)
     nbad = 0
     a = s.copy()
