@@ -574,7 +574,8 @@ struct VegLoop {
   double r_rhocp, r_hcan, r_gammav;     // 1 / (RHOAIR*CPAIR), 1 / HCAN, 1 / GAMMAV: divisors of every iteration (div_rc)
   // carried from iteration to iteration / read after the loop
   MoState mo;
-  float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, wstar;
+  float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, wstar,
+        tv_in, csh, cev, ctr;        // the last iteration's TV on entry and conductances (flux corrections after the loop)
   int liter, err, iter, done;    // iter = the next iteration to run (2..21); done = loop1 has exited
 };
 constexpr int VEGLOOP_WORDS = sizeof(VegLoop) / 4;
@@ -681,10 +682,9 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   float b = L.sav - L.irc - L.shc - L.evc - L.tr;
   float a = fveg * (4.f * L.cir * powi3(L.tv) + csh + (cev + ctr) * destv);
   L.dtv = b / a;
-  L.irc = L.irc + fveg * 4.f * L.cir * powi3(L.tv) * L.dtv;
-  L.shc = L.shc + fveg * csh * L.dtv;
-  L.evc = L.evc + fveg * cev * destv * L.dtv;
-  L.tr = L.tr + fveg * ctr * destv * L.dtv;
+  // The flux corrections by DTV (lsm:3426-3429) are overwritten by the next iteration before anything reads them: what they need of the
+  // last iteration is carried out of the loop and they are applied once, after it (vege_flux)
+  L.tv_in = L.tv; L.csh = csh; L.cev = cev; L.ctr = ctr;
   L.tv = L.tv + L.dtv;
   L.h = div_rc(rhoair * CPAIR * (L.tah - sfctmp), r_rahc);
   L.hg = div_rc(rhoair * CPAIR * (tg - L.tah), r_rahg);
@@ -758,6 +758,13 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   if (NMP_TRUNC == 5) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch + L.mo.fv + L.mo.fh2; s.err = 99; return; }
   if (!canopy) return;
   if (L.err) raise(s, L.err);
+  {                                                   // lsm:3426-3429 of the last iteration
+    const float fveg = L.fveg, destv = L.destv;
+    L.irc = L.irc + fveg * 4.f * L.cir * powi3(L.tv_in) * L.dtv;
+    L.shc = L.shc + fveg * L.csh * L.dtv;
+    L.evc = L.evc + fveg * L.cev * destv * L.dtv;
+    L.tr = L.tr + fveg * L.ctr * destv * L.dtv;
+  }
   float& tv = s.tv; float& tg = s.tgv; float& tah = s.tah; float& eah = s.eah;
   const float rhoair = s.rhoair;
   tv = L.tv; tah = L.tah; eah = L.eah; cmv = L.cm;
