@@ -806,7 +806,8 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     }
   }
   // 2-m diagnostics lsm:3557-3571 (OPT_SFC 1/2; FH2 is 0 under OPT_SFC=2)
-  float cah2 = L.mo.fv * VKC / (nmp_logf((2.f + z0h) / z0h) - L.mo.fh2);
+  // LOG((2 + Z0H) / Z0H) with Z0H = Z0M: SFCDIF1 evaluated the same expression in its first iteration (tmpcm2)
+  float cah2 = L.mo.fv * VKC / ((c.O.sfc == 1 ? L.mo.tmpcm2 : nmp_logf((2.f + z0h) / z0h)) - L.mo.fh2);
   s.chv2 = cah2;
   if (cah2 < 1.E-5f) {
     s.t2mv = tah;
@@ -882,7 +883,7 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
       s.ghb = s.sag - (s.irb + s.shb + s.evb);
     }
   }
-  float ehb2 = mo.fv * VKC / (nmp_logf((2.f + z0h) / z0h) - mo.fh2);
+  float ehb2 = mo.fv * VKC / ((c.O.sfc == 1 ? mo.tmpcm2 : nmp_logf((2.f + z0h) / z0h)) - mo.fh2);   // as in VEGE_FLUX
   s.chb2 = ehb2;
   if (ehb2 < 1.E-5f) {
     s.t2mb = tgb;
