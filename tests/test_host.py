@@ -76,6 +76,52 @@ def test_index_width_gate():
     assert w(4608, 1536, 50) == 32 and w(21474836, 1, 50) == 32 and w(21474837, 1, 50) == 64   # 200 B per cell
 
 
+def _device_code_objects(path):
+    """The gfx950 ELF images inside a HIP fat binary (clang offload bundles, one per translation unit)."""
+    import struct
+    blob = open(path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], blob.find(magic)
+    while pos >= 0:
+        n, = struct.unpack_from("<Q", blob, pos + 24)
+        q = pos + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "gfx950" in triple and size:
+                out.append(blob[pos + off:pos + off + size])
+        pos = blob.find(magic, pos + 1)
+    return out
+
+
+def test_no_function_is_called_inside_our_kernels(tmp_path):
+    """Everything in the column / groundwater / forcing / init kernels is inline: a real call (s_swappc_b64 to a noinline routine)
+    inside the column kernel once corrupted a live value of its caller (profiles/r03_experiments.md section 3d).  Checked on the
+    ISA of the built library; rocprim's own sort kernels are not ours."""
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    from noahmp_amd import build as b
+    images = _device_code_objects(b.LIB)
+    assert len(images) >= 8, len(images)                    # one per translation unit with device code
+    kernels_seen = 0
+    for n, img in enumerate(images):
+        f = tmp_path / ("co%d.elf" % n)
+        f.write_bytes(img)
+        fn, calls = None, {}
+        for line in subprocess.run([objdump, "-d", str(f)], capture_output=True, text=True, check=True).stdout.splitlines():
+            if line.endswith(">:"):
+                fn = line.split("<", 1)[1][:-2]
+            elif "s_swappc_b64" in line or "s_call_b64" in line:
+                calls[fn] = calls.get(fn, 0) + 1
+            if fn and "noahmp_column_kernel" in fn:
+                kernels_seen += 1
+        ours = {k: v for k, v in calls.items() if "rocprim" not in k}
+        assert not ours, ours
+    assert kernels_seen > 0
+
+
 def test_engine_fails_loudly_without_gpu(tables):
     """No CPU fallback: without a device the engine refuses to run."""
     import torch
