@@ -871,6 +871,8 @@ def main():
                                   "halo_probe_per_rank": comm.probe_results,
                                   "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
+        if world > 1:
+            out["distributed"] = {"backend": comm.backend, "note": getattr(comm, "backend_note", None)}
         if scaling_ref is not None:
             out["scaling_reference"] = scaling_ref
         if config5_ref is not None:

@@ -24,6 +24,7 @@ class Comm:
         self.device_index = self.local_rank if device_index is None else int(device_index)
         self.dist = None
         self.backend = None
+        self.backend_note = None
         self.halo = halo
         self.halo_lib = None
         self._halo_plans = {}
@@ -46,13 +47,32 @@ class Comm:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = backend or os.environ.get("NMP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            kw = {}
-            if backend == "nccl":
-                torch.cuda.set_device(self.device_index)
-                kw["device_id"] = torch.device("cuda", self.device_index)
             import datetime
             # a collective that never completes ends the job after 5 minutes instead of hanging a GPU box
-            dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=5), **kw)
+            tmo = datetime.timedelta(minutes=5)
+            self.backend_note = None
+            try:
+                kw = {}
+                if backend == "nccl":
+                    torch.cuda.set_device(self.device_index)
+                    kw["device_id"] = torch.device("cuda", self.device_index)       # eager communicator: a broken RCCL shows here
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=tmo, **kw)
+            except Exception as e:                                   # noqa: BLE001
+                if backend != "nccl":
+                    raise
+                # RCCL could not be brought up (every rank sees the same node): the control plane and the ring move to gloo -- timing
+                # barrier, reductions and host-staged edges -- so that the run still completes and says so (`backend_note`)
+                self.backend_note = "nccl (RCCL) initialisation failed on rank %d: %s; running over gloo" % (self.rank, str(e).splitlines()[0][:200])
+                print("noahmp_amd.parallel: " + self.backend_note, flush=True)
+                try:
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                except Exception:                                    # noqa: BLE001
+                    pass
+                backend = "gloo"
+                port2 = int(os.environ.get("MASTER_PORT", "29500")) + 23       # a fresh store: the first one may be half alive
+                dist.init_process_group("gloo", init_method="tcp://%s:%d" % (os.environ["MASTER_ADDR"], port2), rank=self.rank,
+                                        world_size=self.world, timeout=tmo)
             self.dist = dist
             self.backend = backend
             # control-plane group on the host, created while every rank is still healthy: probe_halo() agrees over it, so a rank

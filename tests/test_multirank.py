@@ -80,6 +80,38 @@ def _worker(rank, world, port, gx, gy, q):
     comm.close()
 
 
+def _fallback_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from noahmp_amd.parallel import Comm
+    comm = Comm(backend="nccl")                  # no GPU here: RCCL cannot come up
+    comm.barrier()
+    s = comm.reduce_sum(rank + 1.0)
+    if rank == 0:
+        q.put((comm.backend, comm.backend_note, s, comm.probe_halo()))
+    else:
+        comm.probe_halo()
+    comm.close()
+
+
+def test_nccl_that_cannot_initialise_falls_back_to_gloo():
+    """A node whose RCCL does not come up (here: no GPU at all) still runs bench.py --gpus N: control plane and ring over gloo."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box where nccl cannot initialise")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, p, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    backend, note, s, mover = q.get(timeout=240)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert backend == "gloo" and "initialisation failed" in note and s == 3.0 and "gloo" in mover.lower()
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_ranks_cover_domain_and_match_single_process(world, port, tables):
     gx, gy = 48, 6
