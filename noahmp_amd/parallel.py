@@ -7,6 +7,7 @@ ring LATERALFLOW reads (gw:231-252): ``exchange_halo`` below, ZWTXY before every
 the static FDEPTH / TOPO / ISLTYP planes once.
 """
 import os
+import sys
 
 from .partition import partition, neighbours, tile_geometry
 
@@ -63,7 +64,7 @@ class Comm:
                 # RCCL could not be brought up (every rank sees the same node): the control plane and the ring move to gloo -- timing
                 # barrier, reductions and host-staged edges -- so that the run still completes and says so (`backend_note`)
                 self.backend_note = "nccl (RCCL) initialisation failed on rank %d: %s; running over gloo" % (self.rank, str(e).splitlines()[0][:200])
-                print("noahmp_amd.parallel: " + self.backend_note, flush=True)
+                print("noahmp_amd.parallel: " + self.backend_note, file=sys.stderr, flush=True)
                 try:
                     if dist.is_initialized():
                         dist.destroy_process_group()
@@ -136,7 +137,7 @@ class Comm:
                 if not bool((recv == float(prv)).all()):
                     bad = 1.0
             except Exception as e:                                   # noqa: BLE001  (any failure of the device mover)
-                print("noahmp_amd.parallel: device send/recv failed on rank %d (%s)" % (self.rank, e), flush=True)
+                print("noahmp_amd.parallel: device send/recv failed on rank %d (%s)" % (self.rank, e), file=sys.stderr, flush=True)
                 bad = 1.0
         ctrl = getattr(self, "ctrl_group", None)
         flag = torch.tensor([bad], dtype=torch.float32, device="cpu" if ctrl is not None else dev)
