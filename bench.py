@@ -346,7 +346,9 @@ class Run:
             self.wargs_col = d.wtable_args()                  # the per-column half works on the sorted store itself
         self.work = {k: d.a[k] for k in FKEYS}
         src0 = [self.work[k] for k in FKEYS] if self.block_forcing else [self.forcing[0][k] for k in FKEYS]   # (plan only; sources are set per step)
-        self.scat = eng.scatter([self.work[k] for k in FKEYS], src0, self.perm, self.ni, self.nj)
+        # T3D has two levels in memory (HRLDAS passes kms:kme = 1:2) and noahmplsm reads level 1: only that level is permuted
+        self.lvl1 = tuple(i for i, k in enumerate(FKEYS) if self.work[k].dim() == 3)
+        self.scat = eng.scatter([self.work[k] for k in FKEYS], src0, self.perm, self.ni, self.nj, first_level_only=self.lvl1)
         self.sarg = d.step_args(1, 2000, 180.0)
 
     def step(self, it):
@@ -359,7 +361,7 @@ class Run:
             # step's WTABLE call return to sorted order in the same launch
             srt = [self.work[k] for k in FKEYS]
             til = [self.forcing[h][k] for k in FKEYS]
-            self.scat.exchange(srt, til, False, self.gw.ni, self.i_off, self.j_off, self.sp)
+            self.scat.exchange(srt, til, False, self.gw.ni, self.i_off, self.j_off, self.sp, first_level_only=self.lvl1)
             self.sarg.itimestep = it
             self.eng.noahmplsm_async(self.sarg, self.sp)
         elif self.sorted:

@@ -106,10 +106,11 @@ __global__ void __launch_bounds__(256) noahmp_scatter_kernel(const ScatterArgs k
   }
   int phase = 0;
   for (int f = 0; f < k.n; f++) {
-    const int nk = k.nlev[f];
+    const int nk = k.nlev[f] < 0 ? -k.nlev[f] : k.nlev[f];      // nlev < 0: |nlev| levels in memory, only the first one is moved
+    const int nmove = k.nlev[f] < 0 ? 1 : nk;
     const uint32_t* s = (const uint32_t*)k.src[f];
     uint32_t* d = (uint32_t*)k.dst[f];
-    for (int l = 0; l < nk; l++, phase ^= 1) {
+    for (int l = 0; l < nmove; l++, phase ^= 1) {
       if (!k.reverse) {          // coalesced reads of consecutive tile cells, writes in ascending sorted position
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -155,11 +156,12 @@ __global__ void __launch_bounds__(1024) noahmp_scatter_big_kernel(const ScatterA
   const int sj0 = (int)(q0 / k.ni), si0 = (int)(q0 - (long)sj0 * k.ni);
 #pragma unroll 1
   for (int f = 0; f < k.n; f++) {
-    const int nk = k.nlev[f];
+    const int nk = k.nlev[f] < 0 ? -k.nlev[f] : k.nlev[f];      // nlev < 0: |nlev| levels in memory, only the first one is moved
+    const int nmove = k.nlev[f] < 0 ? 1 : nk;
     const uint32_t* s = (const uint32_t*)k.src[f];
     uint32_t* d = (uint32_t*)k.dst[f];
 #pragma unroll 1
-    for (int l = 0; l < nk; l++) {
+    for (int l = 0; l < nmove; l++) {
       int sj = sj0, si = si0;
       asm volatile("" : "+v"(sj), "+v"(si));
       // elements go in groups of G with a scheduling barrier between groups: left alone, the compiler batches all R loads of a thread

@@ -282,21 +282,30 @@ class Engine:
             if rc:
                 raise RuntimeError("noahmp_hip_scatter_fields: rc=%d" % rc)
 
-        def exchange(self, sorted_planes, tile_planes, to_tile, ni_mem=None, i_off=0, j_off=0, stream=None):
+        def exchange(self, sorted_planes, tile_planes, to_tile, ni_mem=None, i_off=0, j_off=0, stream=None, first_level_only=()):
             """Move planes between the sorted store and TILE-order planes (possibly the interior of a memory block that carries
             the LATERALFLOW ring: rows ni_mem long, tile origin at (i_off, j_off)) with this permutation's plan
-            (noahmp_hip_sorted_exchange).  to_tile: sorted -> tile order, else tile order -> sorted."""
+            (noahmp_hip_sorted_exchange).  to_tile: sorted -> tile order, else tile order -> sorted.  first_level_only: as in scatter()."""
             n = len(sorted_planes)
             sp = (C.c_void_p * n)(*[t.data_ptr() for t in sorted_planes])
             tp = (C.c_void_p * n)(*[t.data_ptr() for t in tile_planes])
             nl = (C.c_int * n)(*[(t.shape[1] if t.dim() == 3 else 1) for t in sorted_planes])
+            for i in first_level_only:
+                if nl[i] > 1:
+                    nl[i] = -nl[i]
             rc = self.lib.noahmp_hip_sorted_exchange(n, sp, tp, nl, self.order.data_ptr(), self.dpos.data_ptr(), self.ni, self.nj,
                                                      ni_mem or self.ni, i_off, j_off, 1 if to_tile else 0, stream)
             if rc:
                 raise RuntimeError("noahmp_hip_sorted_exchange: rc=%d" % rc)
 
-    def scatter(self, dst, src, perm, ni, nj):
-        return Engine.Scatter(self.lib, dst, src, perm, ni, nj)
+    def scatter(self, dst, src, perm, ni, nj, first_level_only=()):
+        """first_level_only: indices of level arrays of which only the first level is moved (the column kernel reads level 1 of the
+        atmospheric arrays only: the driver's level-2 copies, hdrv:336-344, need not travel)."""
+        sc = Engine.Scatter(self.lib, dst, src, perm, ni, nj)
+        for i in first_level_only:
+            if sc.nlev[i] > 1:
+                sc.nlev[i] = -sc.nlev[i]
+        return sc
 
     def groundwater_init(self, store, stream=None):
         """GROUNDWATER_INIT + EQSMOISTURE (reference drv:1286-1522): equilibrium soil moisture, deep-layer moisture

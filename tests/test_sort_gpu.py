@@ -88,6 +88,17 @@ def test_scatter_plan_on_device_equals_host_plan(engine, tables, ni, nj):
     engine.stream_sync()
     for t, u in zip(src, dst):
         np.testing.assert_array_equal(_cols(t.cpu().numpy(), p), _cols(u.cpu().numpy()))
+    # level arrays of which only the first level travels (nlev < 0 at the C-ABI): level 1 moved, level 2 of the destination untouched
+    dst2 = [torch.full_like(t, -7.0) for t in src]
+    sc2 = engine.scatter(dst2, src, perm, ni, nj, first_level_only=(1,))
+    sc2()
+    sc2.exchange([dst[1]], [src[1]], False, stream=None, first_level_only=(0,))     # the sorted_exchange entry, level 1 over the full result: no change
+    engine.stream_sync()
+    np.testing.assert_array_equal(_cols(src[0].cpu().numpy(), p), _cols(dst2[0].cpu().numpy()))
+    got = dst2[1].cpu().numpy()
+    np.testing.assert_array_equal(_cols(src[1].cpu().numpy()[:, :1, :], p), _cols(got[:, :1, :]))
+    assert (got[:, 1, :] == -7.0).all()
+    np.testing.assert_array_equal(_cols(src[1].cpu().numpy(), p), _cols(dst[1].cpu().numpy()))
 
 
 def test_sort_refuses_a_tile_with_a_halo(engine, tables):
