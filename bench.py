@@ -623,9 +623,10 @@ def main():
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-snow-key", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--halo", choices=("torch", "rccl", "tcp"), default=os.environ.get("NMP_HALO", "torch"),
-                    help="who moves the groundwater ring: torch.distributed send/recv (RCCL under the nccl backend), or the engine's "
-                         "C-ABI exchange noahmp_hip_exchange_halo with its RCCL or socket transport")
+    ap.add_argument("--halo", choices=("auto", "torch", "rccl", "tcp"), default=os.environ.get("NMP_HALO", "auto"),
+                    help="who moves the groundwater ring: the engine's C-ABI exchange noahmp_hip_exchange_halo with its RCCL or socket "
+                         "transport, or torch.distributed send/recv (RCCL under the nccl backend); auto = the C-ABI RCCL mover when it "
+                         "starts and passes a checked probe exchange on every rank, else torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="N = 1, default workload: skip the short config-4 run that gives the N = 1 point of the --gpus N curve")
@@ -845,8 +846,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "grid": [args.ni, args.nj], "columns_per_gpu": run.tile_cells,
                        "parallelism": ("1 GPU" if world == 1 else "%d tiles (mpp_land_partition_calc), one rank per GPU%s"
-                                       % (world, (", RCCL ZWTXY ring exchange (%s)" % {"torch": "torch.distributed send/recv", "rccl": "noahmp_hip_exchange_halo, RCCL transport",
-                                                                          "tcp": "noahmp_hip_exchange_halo, socket transport"}[args.halo])
+                                       % (world, (", one-phase ZWTXY ring exchange (%s)" % {"torch": "torch.distributed send/recv", "rccl": "noahmp_hip_exchange_halo, RCCL transport",
+                                                                          "tcp": "noahmp_hip_exchange_halo, socket transport"}[comm.halo])
                                           if run.lateral else ", no collective"))},
             "timed_region_s": dt, "setup_s": t_setup,
             "achieved_hbm_gbs": achieved,          # the second half of BASELINE.json's metric: algorithmic GB/s of the dominant kernel (= roofline.achieved)
@@ -874,7 +875,8 @@ def main():
                                   "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
         if world > 1:
-            out["distributed"] = {"backend": comm.backend, "note": getattr(comm, "backend_note", None)}
+            out["distributed"] = {"backend": comm.backend, "note": getattr(comm, "backend_note", None), "halo_requested": args.halo,
+                                  "halo": comm.halo, "halo_note": comm.halo_note}
         if scaling_ref is not None:
             out["scaling_reference"] = scaling_ref
         if config5_ref is not None:

@@ -195,15 +195,14 @@ struct Opt {   // the 12 option integers, uniform over the grid (drv:15-17)
 
 // Per-type constants that follow from the parameter tables alone: what every column of a soil type (x urban override, lsm:9294-9300)
 // or vegetation type would evaluate again and again -- THKS**(1-SMCMAX) (three powf, lsm:2076-2094), THKDRY, the dry-layer part of
-// RSURF (a powf, lsm:1655), KDT, FRZX, the leaf-orientation integrals of TWOSTREAM (a logf and two divisions, lsm:2891-2897) and
-// the float64 reciprocals of SMCMAX, SMCREF-SMCWLT, PSISAT (div_rc).  Filled once per noahmp_hip_set_tables on the HOST by
+// RSURF (a powf, lsm:1655), KDT, FRZX, the leaf-orientation integrals of TWOSTREAM (a logf and two divisions, lsm:2891-2897).
+// (The float64 reciprocals of SMCMAX, SMCREF-SMCWLT, PSISAT are formed from registers by rc64 instead.)  Filled once per noahmp_hip_set_tables on the HOST by
 // derive_tables() (nmp_dev_sflx.hpp) with the very functions and float32 operations the device code used to run per column
 // (nmp_libm is host + device and held to the reference libm bit for bit on both).
 constexpr int NSLT = 30, NVEGT = 27;
 struct Derived {
   float thks_pow[2][NSLT], thkdry[2][NSLT], d_rsurf[2][NSLT], frzx[2][NSLT];      // [urban override][soil type - 1]
-  float kdt[NSLT], neg_inv_bexp[NSLT];
-  double r_smcmax[2][NSLT], r_refwlt[2][NSLT], r_psisat[NSLT];
+  float kdt[NSLT];
   float chil[NVEGT], phi1[NVEGT], phi2[NVEGT], avmu[NVEGT];                       // [vegetation type - 1]
 };
 

@@ -77,7 +77,10 @@ NMP_DEV void redprm_water(const Ctx& c, Parm& P, int soiltyp, int vegtyp) {
 // HOST: the per-type constants of `Derived`, by the functions the device code ran per column before round 3
 inline void derive_tables(const noahmp_tables& T, Derived& D) {
   memset(&D, 0, sizeof D);
-  for (int st = 0; st < NSLT; st++) {
+  // only the rows the tables define (SLCATS / LUCATS of SOILPARM.TBL / MPTABLE.TBL): the rows behind them are zero, and evaluating
+  // them would raise FE_DIVBYZERO / FE_INVALID in the caller's process (a Fortran host built with FP traps)
+  const int nst = T.slcats < NSLT ? T.slcats : NSLT, nvt = T.lucats < NVEGT ? T.lucats : NVEGT;
+  for (int st = 0; st < nst; st++) {
     for (int u = 0; u < 2; u++) {
       Parm P = {};
       redprm_soil(&T, st, u == 1, P);
@@ -85,14 +88,10 @@ inline void derive_tables(const noahmp_tables& T, Derived& D) {
       D.thkdry[u][st] = tdfcnd_thkdry(P);
       D.d_rsurf[u][st] = rsurf_dry_layer(P);
       D.frzx[u][st] = redprm_frzx(&T, P);
-      D.r_smcmax[u][st] = 1.0 / (double)P.smcmax;
-      D.r_refwlt[u][st] = 1.0 / (double)(P.smcref - P.smcwlt);
     }
     D.kdt[st] = redprm_kdt(&T, T.satdk[st]);
-    D.neg_inv_bexp[st] = -1.f / T.bb[st];
-    D.r_psisat[st] = 1.0 / (double)T.satpsi[st];
   }
-  for (int v = 0; v < NVEGT; v++) leaf_orientation(T.xl[v], D.chil[v], D.phi1[v], D.phi2[v], D.avmu[v]);
+  for (int v = 0; v < nvt; v++) leaf_orientation(T.xl[v], D.chil[v], D.phi1[v], D.phi2[v], D.avmu[v]);
 }
 #endif
 

@@ -759,7 +759,7 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
   const int nsteps = g.async_pending;
   g.async_pending = 0;
   int code = 0;
-  if (st) {
+  {                                         // per-step / per-class times of THIS sync, whether or not the caller takes the tallies
     float ms = 0.f;
     for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f;
     g.sync_step_ms.assign(nsteps, 0.f);
@@ -779,10 +779,12 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
       }
     }
     g.sync_steps = nsteps;
-    st->kernel_ms = ms;
-    int cnt[4];
-    nmp_host::sum_counts(cnt);
-    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+    if (st) {
+      st->kernel_ms = ms;
+      int cnt[4];
+      nmp_host::sum_counts(cnt);
+      st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+    }
   }
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);

@@ -3,15 +3,16 @@
 // LATERALFLOW (gw:231-292) reads WTD, FDEPTH, TOPO and ISLTYP on the 1-cell ring around a rank's tile, corners included.  The
 // reference fills such rings with mpp_land_comlr_real followed by mpp_land_comub_real, flag 99 (mpp:344-369, 603-642): first
 // left/right over the tile's rows, then down/up over whole memory rows, which by then carry the columns received in the first
-// phase -- corners arrive without diagonal messages.  This file does the same for a caller with one rank per GPU
-// (mpp_land_get_nprocsxy's rank grid, mpp:124-141; neighbours as mpp:93-107) and needs neither MPI nor torch:
+// phase -- two DEPENDENT message phases.  This file delivers the same cells in ONE phase: the four tile edges go to the four edge
+// neighbours and the four corner cells to the four diagonal ranks, all at once (the exchange is latency-bound: ~25 KB per edge
+// at the config-4 grid on 8 ranks).  For a caller with one rank per GPU (mpp_land_get_nprocsxy's rank grid, mpp:124-141;
+// neighbours as mpp:93-107 plus the diagonals); needs neither MPI nor torch:
 //   * rendezvous over TCP (rank 0 listens on master_addr:master_port; every rank learns its neighbours' listeners);
-//   * transport NOAHMP_HALO_RCCL: ncclSend / ncclRecv of packed edges in one group per phase on the caller's stream
-//     (RCCL over xGMI, GPU-direct; librccl is loaded with dlopen at init, its unique id travels over the rendezvous);
+//   * transport NOAHMP_HALO_RCCL: ncclSend / ncclRecv of the packed edges to / from all <= 8 neighbours in ONE group on the caller's
+//     stream (RCCL over xGMI, GPU-direct; librccl is loaded with dlopen at init, its unique id travels over the rendezvous);
 //   * transport NOAHMP_HALO_TCP: the packed edges travel over the rendezvous sockets (host planes directly, device planes through a
 //     pinned staging buffer) -- the form the CPU tests and single-GPU checks use, and a fallback where RCCL is not available.
-// <= 4 messages of one tile edge per phase and plane set (~25 KB at the config-4 grid on 8 ranks): latency-bound, so all planes of a
-// call share the messages of a phase.
+// All planes of a call share the messages.
 #include <arpa/inet.h>
 #include <dlfcn.h>
 #include <errno.h>
@@ -54,8 +55,10 @@ constexpr int kNcclInt32 = 2;      // ncclInt32 / ncclInt (nccl.h ncclDataType_t
 struct Halo {
   bool up = false;
   int rank = 0, nranks = 1, npx = 1, npy = 1, transport = NOAHMP_HALO_TCP;
-  int nb[4] = {-1, -1, -1, -1};          // left, right, down, up
-  int sock[4] = {-1, -1, -1, -1};
+  // left, right, down, up, down-left, up-right, down-right, up-left: edge types first, inside a type the lower-ranked peer first, so
+  // that the blocking pairwise transfers of the socket transport follow ONE global order of the links (no cyclic wait)
+  int nb[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  int sock[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   Rccl rccl;
   NcclComm comm = nullptr;
   // staging
@@ -96,6 +99,13 @@ double halo_timeout_s() {
   const char* e = getenv("NMP_HALO_TIMEOUT_S");
   const double v = e ? atof(e) : 120.0;
   return v > 0.0 ? v : 120.0;
+}
+// the DATA path has its own, longer deadline (NMP_HALO_IO_TIMEOUT_S, default 1800 s): a neighbour that is late for a step -- its
+// first step compiles a kernel, it sorts again, it writes a restart file -- is not a dead neighbour
+double halo_io_timeout_s() {
+  const char* e = getenv("NMP_HALO_IO_TIMEOUT_S");
+  const double v = e ? atof(e) : 1800.0;
+  return v > 0.0 ? v : 1800.0;
 }
 void set_io_timeout(int fd, double sec) {
   timeval tv; tv.tv_sec = (long)sec; tv.tv_usec = (long)((sec - (double)tv.tv_sec) * 1e6);
@@ -166,18 +176,19 @@ struct Peer { uint32_t ip; int port; };
 
 // ---- edge packing.  An edge = `count` words of a plane starting at `first`, `stride` apart; n planes share a message.
 struct EdgeDesc { long first, stride; int count; long buf_off; };     // buf_off: word offset of plane 0's copy in the staging buffer
-constexpr int kMaxPlanes = 64;
-struct PackArgs { void* planes[kMaxPlanes]; int n; EdgeDesc e[2]; int nedge; };     // plane addresses travel as kernel arguments
+constexpr int kMaxPlanes = 64, kMaxEdges = 8;
+struct PackArgs { void* planes[kMaxPlanes]; int n; EdgeDesc e[kMaxEdges]; long start[kMaxEdges + 1]; int nedge; };   // by value: kernel argument
 
 __global__ void __launch_bounds__(256) halo_pack_kernel(const PackArgs k, uint32_t* buf, int unpack) {
-  const int per = k.e[0].count;                     // both edges of a phase have the same length
-  const long total = (long)k.nedge * k.n * per;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int q = (int)(t % per), p = (int)((t / per) % k.n), ed = (int)(t / ((long)per * k.n));
+  if (t >= k.start[k.nedge]) return;
+  int ed = 0;
+  while (ed + 1 < k.nedge && t >= k.start[ed + 1]) ed++;               // <= 8 edges
   const EdgeDesc& e = k.e[ed];
+  const long r = t - k.start[ed];
+  const int q = (int)(r % e.count), p = (int)(r / e.count);
   uint32_t* plane = (uint32_t*)k.planes[p];
-  uint32_t* slot = buf + e.buf_off + (long)p * per + q;
+  uint32_t* slot = buf + e.buf_off + (long)p * e.count + q;
   if (unpack) plane[e.first + (long)q * e.stride] = *slot;
   else *slot = plane[e.first + (long)q * e.stride];
 }
@@ -218,59 +229,62 @@ int ensure_staging(size_t words, bool device) {
   return 0;
 }
 
-// one phase: exchange edge `a` with neighbour slot na and edge `b` with slot nb_ (either may be absent)
-int phase(int n, void* const* planes, bool device, hipStream_t s, int slot_a, const EdgeDesc& send_a,
-          const EdgeDesc& recv_a, int slot_b, const EdgeDesc& send_b, const EdgeDesc& recv_b) {
-  const int per = send_a.count;
-  if (per <= 0) return 0;
-  const size_t words = (size_t)2 * n * per;
-  int rc = ensure_staging(words, device);
-  if (rc) return rc;
-  const int slots[2] = {slot_a, slot_b};
+// the one phase: send[d] goes to neighbour slot d, recv[d] comes from it (absent neighbours are skipped)
+int exchange_all(int n, void* const* planes, bool device, hipStream_t s, const EdgeDesc* send, const EdgeDesc* recv) {
   PackArgs pk; memset(&pk, 0, sizeof pk);
   PackArgs up; memset(&up, 0, sizeof up);
   for (int p = 0; p < n; p++) pk.planes[p] = up.planes[p] = planes[p];
   pk.n = up.n = n;
-  const EdgeDesc snd[2] = {send_a, send_b}, rcv[2] = {recv_a, recv_b};
-  long off[2] = {0, (long)n * per};
-  for (int i = 0; i < 2; i++) {
-    if (H.nb[slots[i]] < 0) continue;
-    pk.e[pk.nedge] = snd[i]; pk.e[pk.nedge].buf_off = off[i]; pk.nedge++;
-    up.e[up.nedge] = rcv[i]; up.e[up.nedge].buf_off = off[i]; up.nedge++;
+  long off[8]; int slot_of[8];
+  long words = 0;
+  for (int d = 0; d < 8; d++) {
+    off[d] = words;
+    if (H.nb[d] < 0 || send[d].count <= 0) continue;
+    const int e = pk.nedge;
+    slot_of[e] = d;
+    pk.e[e] = send[d]; pk.e[e].buf_off = words; pk.start[e] = words;
+    up.e[e] = recv[d]; up.e[e].buf_off = words; up.start[e] = words;
+    words += (long)n * send[d].count;
+    pk.nedge = up.nedge = e + 1;
   }
   if (!pk.nedge) return 0;
-  const unsigned nb = (unsigned)(((long)pk.nedge * n * per + 255) / 256);
-  if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, s, pk, H.d_send, 0);
+  pk.start[pk.nedge] = up.start[up.nedge] = words;
+  int rc = ensure_staging((size_t)words, device);
+  if (rc) return rc;
+  const unsigned nblk = (unsigned)((words + 255) / 256);
+  if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nblk), dim3(256), 0, s, pk, H.d_send, 0);
   else host_pack(pk, H.h_send, 0);
   if (H.transport == NOAHMP_HALO_RCCL) {
     if (!device) return fail("the RCCL transport exchanges device-resident planes");
     int e = H.rccl.GroupStart();
-    for (int i = 0; i < 2 && !e; i++) {
-      const int peer = H.nb[slots[i]];
-      if (peer < 0) continue;
-      e = H.rccl.Send(H.d_send + off[i], (size_t)n * per, kNcclInt32, peer, H.comm, s);
-      if (!e) e = H.rccl.Recv(H.d_recv + off[i], (size_t)n * per, kNcclInt32, peer, H.comm, s);
+    for (int i = 0; i < pk.nedge && !e; i++) {
+      const int peer = H.nb[slot_of[i]];
+      const size_t cnt = (size_t)n * pk.e[i].count;
+      e = H.rccl.Send(H.d_send + pk.e[i].buf_off, cnt, kNcclInt32, peer, H.comm, s);
+      if (!e) e = H.rccl.Recv(H.d_recv + pk.e[i].buf_off, cnt, kNcclInt32, peer, H.comm, s);
     }
     const int e2 = H.rccl.GroupEnd();
     if (e || e2) return fail(std::string("RCCL send/recv: ") + (H.rccl.GetErrorString ? H.rccl.GetErrorString(e ? e : e2) : "error"));
   } else {
     if (device) {
-      HIPCHK(hipMemcpyAsync(H.h_send, H.d_send, words * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(H.h_send, H.d_send, (size_t)words * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
     }
-    for (int i = 0; i < 2; i++) {                    // lower rank sends first: a total order, no deadlock with blocking sockets
-      const int peer = H.nb[slots[i]];
-      if (peer < 0) continue;
-      const int fd = H.sock[slots[i]];
-      const size_t bytes = (size_t)n * per * 4;
+    for (int i = 0; i < pk.nedge; i++) {              // links in their global order, on a link the lower rank sends first: no deadlock with blocking sockets
+      const int peer = H.nb[slot_of[i]];
+      const int fd = H.sock[slot_of[i]];
+      const size_t bytes = (size_t)n * pk.e[i].count * 4;
+      uint32_t* sb = H.h_send + pk.e[i].buf_off; uint32_t* rb = H.h_recv + pk.e[i].buf_off;
+      errno = 0;
       bool ok;
-      if (H.rank < peer) ok = send_all(fd, H.h_send + off[i], bytes) && recv_all(fd, H.h_recv + off[i], bytes);
-      else ok = recv_all(fd, H.h_recv + off[i], bytes) && send_all(fd, H.h_send + off[i], bytes);
-      if (!ok) return fail("socket transfer with rank " + std::to_string(peer) + " failed");
+      if (H.rank < peer) ok = send_all(fd, sb, bytes) && recv_all(fd, rb, bytes);
+      else ok = recv_all(fd, rb, bytes) && send_all(fd, sb, bytes);
+      if (!ok) return fail(std::string((errno == EAGAIN || errno == EWOULDBLOCK) ? "timeout (NMP_HALO_IO_TIMEOUT_S) in the" : "failed") +
+                           " socket transfer with rank " + std::to_string(peer));
     }
-    if (device) HIPCHK(hipMemcpyAsync(H.d_recv, H.h_recv, words * 4, hipMemcpyHostToDevice, s));
+    if (device) HIPCHK(hipMemcpyAsync(H.d_recv, H.h_recv, (size_t)words * 4, hipMemcpyHostToDevice, s));
   }
-  if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nb), dim3(256), 0, s, up, H.d_recv, 1);
+  if (device) hipLaunchKernelGGL(halo_pack_kernel, dim3(nblk), dim3(256), 0, s, up, H.d_recv, 1);
   else host_pack(up, H.h_recv, 1);
   return 0;
 }
@@ -299,8 +313,13 @@ int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int mast
   H.rank = rank; H.nranks = nranks; H.transport = transport;
   nprocs_xy(nranks, H.npx, H.npy);
   const int ipx = rank % H.npx, ipy = rank / H.npx;                               // rank = iprocy*nprocx + iprocx (mpp:93-107)
-  H.nb[0] = ipx > 0 ? rank - 1 : -1; H.nb[1] = ipx < H.npx - 1 ? rank + 1 : -1;
-  H.nb[2] = ipy > 0 ? rank - H.npx : -1; H.nb[3] = ipy < H.npy - 1 ? rank + H.npx : -1;
+  {
+    static const int dx[8] = {-1, 1, 0, 0, -1, 1, 1, -1}, dy[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    for (int d = 0; d < 8; d++) {
+      const int x = ipx + dx[d], y = ipy + dy[d];
+      H.nb[d] = (x >= 0 && x < H.npx && y >= 0 && y < H.npy) ? y * H.npx + x : -1;
+    }
+  }
   H.up = true;
   if (nranks == 1) return 0;
   const double timeout = halo_timeout_s(), deadline = now_s() + timeout;
@@ -352,8 +371,8 @@ int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int mast
   if (abort_all) return init_failed(my_abort ? my_reason : "another rank cannot use the requested transport (see its error): all ranks stop");
   // ---- neighbour links (TCP transport; also a liveness check for RCCL): connect to lower-ranked neighbours, accept the higher ones
   int expect = 0;
-  for (int d = 0; d < 4; d++) if (H.nb[d] > rank) expect++;
-  for (int d = 0; d < 4; d++) {
+  for (int d = 0; d < 8; d++) if (H.nb[d] > rank) expect++;
+  for (int d = 0; d < 8; d++) {
     if (H.nb[d] < 0 || H.nb[d] > rank) continue;
     const int fd = connect_to(table[H.nb[d]].ip, table[H.nb[d]].port, timeout);
     if (fd < 0) return init_failed("cannot connect to neighbour " + std::to_string(H.nb[d]));
@@ -367,9 +386,10 @@ int noahmp_hip_halo_init(int rank, int nranks, const char* master_addr, int mast
     if (!recv_all(fd, &who, sizeof who)) { close(fd); return init_failed("neighbour accept"); }
     int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
     bool placed = false;
-    for (int d = 0; d < 4; d++) if (H.nb[d] == who && H.sock[d] < 0) { H.sock[d] = fd; placed = true; break; }
+    for (int d = 0; d < 8; d++) if (H.nb[d] == who && H.sock[d] < 0) { H.sock[d] = fd; placed = true; break; }
     if (!placed) { close(fd); return init_failed("unexpected neighbour " + std::to_string(who)); }
   }
+  for (int d = 0; d < 8; d++) if (H.sock[d] >= 0) set_io_timeout(H.sock[d], halo_io_timeout_s());   // from here on: the data path's deadline
   if (transport == NOAHMP_HALO_RCCL) {
     int rc = nmp_host::ensure_init();
     if (rc) { const std::string m = g.last_error; noahmp_hip_halo_finalize(); g.last_error = m; return rc; }
@@ -396,16 +416,18 @@ int noahmp_hip_exchange_halo(int n, void* const* planes, const int32_t* index8, 
     if (rc) return rc;
     s = stream ? (hipStream_t)stream : g.own_stream;
   }
-  const int nrow = j1 - j0 + 1;
-  // phase 1 (mpp_land_comlr_real): columns its / ite of the tile rows -> the neighbour's ring column
-  EdgeDesc sl{(long)j0 * ni + i0, ni, nrow, 0}, rl{(long)j0 * ni + i0 - 1, ni, nrow, 0};
-  EdgeDesc sr{(long)j0 * ni + i1, ni, nrow, 0}, rr{(long)j0 * ni + i1 + 1, ni, nrow, 0};
-  int rc = phase(n, planes, device, s, 0, sl, rl, 1, sr, rr);
-  if (rc) return rc;
-  // phase 2 (mpp_land_comub_real, flag 99): whole memory rows jts / jte, including the columns just received
-  EdgeDesc sd{(long)j0 * ni, 1, (int)ni, 0}, rd{(long)(j0 - 1) * ni, 1, (int)ni, 0};
-  EdgeDesc su{(long)j1 * ni, 1, (int)ni, 0}, ru{(long)(j1 + 1) * ni, 1, (int)ni, 0};
-  rc = phase(n, planes, device, s, 2, sd, rd, 3, su, ru);
+  const int nrow = j1 - j0 + 1, ncol = i1 - i0 + 1;
+  // what goes out: the tile cells that touch a side; what comes in: the ring cells on that side (same slot order as H.nb)
+  EdgeDesc snd[8], rcv[8];
+  snd[0] = EdgeDesc{(long)j0 * ni + i0, ni, nrow, 0};        rcv[0] = EdgeDesc{(long)j0 * ni + i0 - 1, ni, nrow, 0};          // left
+  snd[1] = EdgeDesc{(long)j0 * ni + i1, ni, nrow, 0};        rcv[1] = EdgeDesc{(long)j0 * ni + i1 + 1, ni, nrow, 0};          // right
+  snd[2] = EdgeDesc{(long)j0 * ni + i0, 1, ncol, 0};         rcv[2] = EdgeDesc{(long)(j0 - 1) * ni + i0, 1, ncol, 0};         // down
+  snd[3] = EdgeDesc{(long)j1 * ni + i0, 1, ncol, 0};         rcv[3] = EdgeDesc{(long)(j1 + 1) * ni + i0, 1, ncol, 0};         // up
+  snd[4] = EdgeDesc{(long)j0 * ni + i0, 1, 1, 0};            rcv[4] = EdgeDesc{(long)(j0 - 1) * ni + i0 - 1, 1, 1, 0};        // down-left
+  snd[5] = EdgeDesc{(long)j1 * ni + i1, 1, 1, 0};            rcv[5] = EdgeDesc{(long)(j1 + 1) * ni + i1 + 1, 1, 1, 0};        // up-right
+  snd[6] = EdgeDesc{(long)j0 * ni + i1, 1, 1, 0};            rcv[6] = EdgeDesc{(long)(j0 - 1) * ni + i1 + 1, 1, 1, 0};        // down-right
+  snd[7] = EdgeDesc{(long)j1 * ni + i0, 1, 1, 0};            rcv[7] = EdgeDesc{(long)(j1 + 1) * ni + i0 - 1, 1, 1, 0};        // up-left
+  int rc = exchange_all(n, planes, device, s, snd, rcv);
   if (rc) return rc;
   if (device) HIPCHK(hipGetLastError());
   return 0;
@@ -444,7 +466,7 @@ int noahmp_hip_halo_selftest_rccl(int words) {
 }
 
 int noahmp_hip_halo_finalize(void) {
-  for (int d = 0; d < 4; d++) { if (H.sock[d] >= 0) close(H.sock[d]); H.sock[d] = -1; }
+  for (int d = 0; d < 8; d++) { if (H.sock[d] >= 0) close(H.sock[d]); H.sock[d] = -1; }
   if (H.comm && H.rccl.CommDestroy) H.rccl.CommDestroy(H.comm);
   H.comm = nullptr;
   if (H.d_send) { hipFree(H.d_send); hipFree(H.d_recv); }

@@ -299,8 +299,10 @@ class Engine:
                 raise RuntimeError("noahmp_hip_sorted_exchange: rc=%d" % rc)
 
     def scatter(self, dst, src, perm, ni, nj, first_level_only=()):
-        """first_level_only: indices of level arrays of which only the first level is moved (the column kernel reads level 1 of the
-        atmospheric arrays only: the driver's level-2 copies, hdrv:336-344, need not travel)."""
+        """first_level_only: indices of level arrays of which only the first level is moved -- T3D / QV3D / U_PHY / V_PHY / DZ8W only
+        (the column kernel reads their level 1, drv:451-459; the driver's level-2 copies, hdrv:336-344, need not travel).  Never
+        P8W3D: noahmplsm reads its levels 1 AND 2 (SFCPRS = (P8W3D(kts+1) + P8W3D(kts)) * 0.5, drv:463), so a P8W3D passed this way
+        would keep a stale level-2 pressure."""
         sc = Engine.Scatter(self.lib, dst, src, perm, ni, nj)
         for i in first_level_only:
             if sc.nlev[i] > 1:

@@ -1,24 +1,43 @@
 """One process per GPU (= one MPI rank per GPU, mpp/module_mpp_land.F90) over torch.distributed.
 
-Backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests.
-The column physics needs no data-path collective: these helpers only carry the tile
-assignment, the timing barrier and the metric reductions.  The one physics exchange is the 1-cell
-ring LATERALFLOW reads (gw:231-252): ``exchange_halo`` below, ZWTXY before every groundwater call and
-the static FDEPTH / TOPO / ISLTYP planes once.
+The column physics needs no data-path collective: these helpers carry the tile assignment, the timing barrier,
+the metric reductions and the one physics exchange -- the 1-cell ring LATERALFLOW reads (gw:231-252): ``exchange_halo``, ZWTXY
+before every groundwater call and the static FDEPTH / TOPO / ISLTYP planes once.
+
+Process groups.  The CONTROL plane (barrier, reductions, agreement between ranks) is always a gloo group: it comes up on any
+node, and every decision about the device transports below is agreed over it BEFORE any rank acts on it (a rank that decides
+alone to leave a process group strands the others in it).  The DATA plane for device tensors is RCCL ("nccl" on ROCm, xGMI inside a
+node), brought up second and tested with one all-reduce; when any rank fails, all ranks run the ring over gloo (host-staged edges).
+
+Ring movers (``halo``): "rccl" / "tcp" -- the engine's own C-ABI exchange noahmp_hip_exchange_halo (noahmp_halo.hip; what a
+Fortran / MPI caller binds) with its RCCL or socket transport; "torch" -- torch.distributed
+batch_isend_irecv (RCCL send/recv for device planes under nccl, host-staged under gloo); "auto" (default) -- the C-ABI RCCL mover
+when RCCL is up and its start + a checked probe exchange succeed on EVERY rank within a time limit, else "torch".
+All movers fill the ring in ONE phase: the four tile edges and the four corner cells travel to the eight neighbours at once --
+the cells mpp_land_comlr_real followed by mpp_land_comub_real (flag 99, mpp:344-369, 603-613) deliver in two dependent phases.
 """
 import os
 import sys
 
-from .partition import partition, neighbours, tile_geometry
+from .partition import partition, neighbours, neighbours8, tile_geometry, nprocs_xy, DIRS8
+
+
+def _edge_slices(geom, dx, dy):
+    """(send rows, send cols), (recv rows, recv cols) of the memory block for the neighbour at (dx, dy): the tile cells that
+    touch that side go out, the ring cells on that side come in."""
+    i0, i1 = geom["its"] - geom["ims"], geom["ite"] - geom["ims"]
+    j0, j1 = geom["jts"] - geom["jms"], geom["jte"] - geom["jms"]
+    srow = slice(j0, j1 + 1) if dy == 0 else (slice(j0, j0 + 1) if dy < 0 else slice(j1, j1 + 1))
+    scol = slice(i0, i1 + 1) if dx == 0 else (slice(i0, i0 + 1) if dx < 0 else slice(i1, i1 + 1))
+    rrow = slice(j0, j1 + 1) if dy == 0 else (slice(j0 - 1, j0) if dy < 0 else slice(j1 + 1, j1 + 2))
+    rcol = slice(i0, i1 + 1) if dx == 0 else (slice(i0 - 1, i0) if dx < 0 else slice(i1 + 1, i1 + 2))
+    return (srow, scol), (rrow, rcol)
 
 
 class Comm:
-    def __init__(self, backend=None, device_index=None, halo="torch", halo_port=None):
+    def __init__(self, backend=None, device_index=None, halo="auto", halo_port=None):
         """device_index: the GPU of this rank (default LOCAL_RANK); several ranks may share one GPU under gloo only
-        (a 1-GPU box exercising the N>1 code path).  halo: who moves the LATERALFLOW ring -- "torch" (torch.distributed
-        send/recv: RCCL for device planes under the nccl backend), or the engine's own C-ABI exchange noahmp_hip_exchange_halo
-        ("rccl": ncclSend / ncclRecv issued by the library; "tcp": its socket transport), which is what a Fortran / MPI caller
-        binds."""
+        (a 1-GPU box exercising the N>1 code path).  halo: who moves the LATERALFLOW ring (module docstring)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -26,62 +45,136 @@ class Comm:
         self.dist = None
         self.backend = None
         self.backend_note = None
-        self.halo = halo
+        self.dev_group = None          # RCCL group for device tensors (None: everything over the gloo control group)
+        self.halo_requested = halo
+        self.halo = halo if halo != "auto" else "torch"
+        self.halo_note = None
         self.halo_lib = None
         self._halo_plans = {}
-        if halo != "torch" and self.world > 1:
-            from . import abi
-            self.halo_lib = abi.load_library()
-            # bind the engine to THIS rank's GPU before anything of it touches a device: halo_init (RCCL transport) creates the
-            # engine's stream and the communicator on the current device, which would be GPU 0 for every rank otherwise
-            if halo == "rccl" or self.halo_lib.noahmp_hip_device_count() > 0:
-                rc = self.halo_lib.noahmp_hip_set_device(self.device_index)
-                if rc:
-                    raise RuntimeError("noahmp_hip_set_device(%d): %s" % (self.device_index, self.halo_lib.noahmp_hip_last_error().decode()))
-            port = halo_port or int(os.environ.get("NMP_HALO_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
-            rc = self.halo_lib.noahmp_hip_halo_init(self.rank, self.world, os.environ.get("MASTER_ADDR", "127.0.0.1").encode(), port,
-                                                    abi.HALO_RCCL if halo == "rccl" else abi.HALO_TCP)
-            if rc:
-                raise RuntimeError("noahmp_hip_halo_init: rc=%d %s" % (rc, self.halo_lib.noahmp_hip_last_error().decode()))
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            backend = backend or os.environ.get("NMP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            import datetime
-            # a collective that never completes ends the job after 5 minutes instead of hanging a GPU box
-            tmo = datetime.timedelta(minutes=5)
-            self.backend_note = None
-            try:
-                kw = {}
-                if backend == "nccl":
-                    torch.cuda.set_device(self.device_index)
-                    kw["device_id"] = torch.device("cuda", self.device_index)       # eager communicator: a broken RCCL shows here
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world, timeout=tmo, **kw)
-            except Exception as e:                                   # noqa: BLE001
-                if backend != "nccl":
-                    raise
-                # RCCL could not be brought up (every rank sees the same node): the control plane and the ring move to gloo -- timing
-                # barrier, reductions and host-staged edges -- so that the run still completes and says so (`backend_note`)
-                self.backend_note = "nccl (RCCL) initialisation failed on rank %d: %s; running over gloo" % (self.rank, str(e).splitlines()[0][:200])
-                print("noahmp_amd.parallel: " + self.backend_note, file=sys.stderr, flush=True)
-                try:
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                except Exception:                                    # noqa: BLE001
-                    pass
-                backend = "gloo"
-                port2 = int(os.environ.get("MASTER_PORT", "29500")) + 23       # a fresh store: the first one may be half alive
-                dist.init_process_group("gloo", init_method="tcp://%s:%d" % (os.environ["MASTER_ADDR"], port2), rank=self.rank,
-                                        world_size=self.world, timeout=tmo)
-            self.dist = dist
-            self.backend = backend
-            # control-plane group on the host, created while every rank is still healthy: probe_halo() agrees over it, so a rank
-            # whose device send/recv has just failed does not have to use the process group that failed
-            self.ctrl_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=5)) if backend == "nccl" else None
         self.probe_results = None
-        self.p2p_group = None          # set by probe_halo() when device send/recv does not work: host-staged edges over a gloo group
-        self.p2p_host = False
+        self.p2p_host = False          # device planes staged through the host (gloo data plane, or after a failed probe)
+        if self.world == 1:
+            return
+        import datetime
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        want = backend or os.environ.get("NMP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        self._tmo = datetime.timedelta(minutes=5)         # a collective that never completes ends the job instead of hanging a GPU box
+        dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=self._tmo)     # control plane
+        self.dist = dist
+        self.backend = "gloo"
+        if want == "nccl":
+            err = None
+            try:
+                torch.cuda.set_device(self.device_index)
+                pg = dist.new_group(backend="nccl", timeout=self._tmo)
+                t = torch.ones(1, device=torch.device("cuda", self.device_index))
+                dist.all_reduce(t, group=pg)                      # creates the communicator: a broken RCCL shows here
+                torch.cuda.synchronize()
+                if int(t.item()) != self.world:
+                    err = "all-reduce over RCCL returned %r" % t.item()
+            except Exception as e:                                # noqa: BLE001
+                err = str(e).splitlines()[0][:200] if str(e) else repr(e)
+                pg = None
+            bad = self._agree_any(err is not None)                # every rank learns whether ANY rank failed, then all act alike
+            if bad:
+                self.backend_note = ("nccl (RCCL) initialisation failed on %s: %s; running over gloo"
+                                     % ("rank %d" % self.rank if err else "another rank", err or "see its message"))
+                print("noahmp_amd.parallel: " + self.backend_note, file=sys.stderr, flush=True)
+            else:
+                self.backend, self.dev_group = "nccl", pg
+        self.p2p_host = self.backend == "gloo"
+        if halo in ("rccl", "tcp"):
+            self._start_cabi(halo, halo_port)                     # explicit request: a failure is an error
+        elif halo == "auto" and self.backend == "nccl" and os.environ.get("NMP_HALO_AUTO", "1") != "0":
+            self._try_cabi_rccl(halo_port)
+
+    # ---- agreement over the control plane
+    def _agree_any(self, flag):
+        import torch
+        t = torch.tensor([1.0 if flag else 0.0])
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return bool(t.item() > 0.0)
+
+    # ---- the engine's own exchange (C-ABI)
+    def _halo_port(self, halo_port):
+        return halo_port or int(os.environ.get("NMP_HALO_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+
+    def _start_cabi(self, halo, halo_port):
+        from . import abi
+        lib = abi.load_library()
+        # bind the engine to THIS rank's GPU before anything of it touches a device: halo_init (RCCL transport) creates the
+        # engine's stream and the communicator on the current device, which would be GPU 0 for every rank otherwise
+        if halo == "rccl" or lib.noahmp_hip_device_count() > 0:
+            rc = lib.noahmp_hip_set_device(self.device_index)
+            if rc:
+                raise RuntimeError("noahmp_hip_set_device(%d): %s" % (self.device_index, lib.noahmp_hip_last_error().decode()))
+        rc = lib.noahmp_hip_halo_init(self.rank, self.world, os.environ.get("MASTER_ADDR", "127.0.0.1").encode(), self._halo_port(halo_port),
+                                      abi.HALO_RCCL if halo == "rccl" else abi.HALO_TCP)
+        if rc:
+            raise RuntimeError("noahmp_hip_halo_init: rc=%d %s" % (rc, lib.noahmp_hip_last_error().decode()))
+        self.halo_lib, self.halo = lib, halo
+
+    def _probe_cabi(self, lib, device):
+        """One checked exchange with the C-ABI mover on a virtual 3 x 3-cells-per-rank grid whose values name their cell: every
+        ring cell (edges and corners, all eight directions) must come back as the neighbour's tile cell."""
+        import ctypes as C
+        import numpy as np
+        from . import abi
+        npx, npy = nprocs_xy(self.world)
+        gx, gy = 3 * npx, 3 * npy
+        geo = tile_geometry(gx, gy, self.world, self.rank, halo=1)
+        y, x = np.meshgrid(np.arange(gy), np.arange(gx), indexing="ij")
+        gf = (100.0 * y + x + 1.0).astype(np.float32)
+        sl = (slice(geo["jms"] - 1, geo["jme"]), slice(geo["ims"] - 1, geo["ime"]))
+        f = gf[sl].copy()
+        ring = np.ones(f.shape, dtype=bool)
+        ring[geo["jts"] - geo["jms"]:geo["jte"] - geo["jms"] + 1, geo["its"] - geo["ims"]:geo["ite"] - geo["ims"] + 1] = False
+        f[ring] = -1.0
+        idx = (C.c_int32 * 8)(*[geo[k] for k in ("ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")])
+        if device:
+            import torch
+            t = torch.from_numpy(f).to(torch.device("cuda", self.device_index))
+            ptrs = (C.c_void_p * 1)(t.data_ptr())
+            rc = lib.noahmp_hip_exchange_halo(1, ptrs, idx, abi.MEM_DEVICE, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            f = t.cpu().numpy()
+        else:
+            ptrs = (C.c_void_p * 1)(f.ctypes.data)
+            rc = lib.noahmp_hip_exchange_halo(1, ptrs, idx, abi.MEM_HOST, None)
+        if rc:
+            return "noahmp_hip_exchange_halo: rc=%d %s" % (rc, lib.noahmp_hip_last_error().decode())
+        return None if np.array_equal(f, gf[sl]) else "probe exchange returned wrong ring cells"
+
+    def _try_cabi_rccl(self, halo_port):
+        """halo="auto" with RCCL up: start the engine's RCCL mover and run one checked probe exchange in a helper thread with a time
+        limit (a communicator that never forms must not park the job), then AGREE: it is used only if every rank succeeded."""
+        import threading
+        limit = float(os.environ.get("NMP_HALO_AUTO_TIMEOUT_S", "90"))
+        os.environ.setdefault("NMP_HALO_TIMEOUT_S", str(int(max(limit - 30.0, 20.0))))     # the rendezvous' own deadlines end first
+        box = {}
+
+        def work():
+            try:
+                self._start_cabi("rccl", halo_port)
+                box["err"] = self._probe_cabi(self.halo_lib, device=True)
+            except Exception as e:                                # noqa: BLE001
+                box["err"] = str(e).splitlines()[0][:200] if str(e) else repr(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(limit)
+        err = "no answer within %g s" % limit if th.is_alive() else box.get("err")
+        if self._agree_any(err is not None):
+            self.halo_note = ("C-ABI RCCL mover not used (%s): torch.distributed send/recv moves the ring"
+                              % (("rank %d: %s" % (self.rank, err)) if err else "another rank failed"))
+            print("noahmp_amd.parallel: " + self.halo_note, file=sys.stderr, flush=True)
+            if self.halo_lib is not None and not th.is_alive():
+                self.halo_lib.noahmp_hip_halo_finalize()
+            self.halo_lib, self.halo = None, "torch"
+        else:
+            self.halo = "rccl"
 
     # ---- tile assignment (mpp_land_partition_calc, mpp:227-288)
     def my_tile(self, global_nx, global_ny):
@@ -95,15 +188,10 @@ class Comm:
 
     # ---- the one physics exchange
     def exchange_halo(self, planes, geom):
-        """Fill the 1-cell ring of 2-D planes shaped (jme-jms+1, ime-ims+1) from the neighbouring ranks.
-
-        Two phases, so that corners arrive without diagonal messages (the stencil has diagonal terms,
-        gw:264-286): (1) left/right over the tile's rows, (2) down/up over full memory rows, which by
-        then carry the columns received in (1) -- the order mpp_land_comlr_real / comub_real use
-        (mpp:344-369, 603-613).  Planes are torch tensors: HBM tensors travel over RCCL send/recv (xGMI,
-        GPU-direct), CPU tensors over gloo.  <= 4 messages of a tile edge each per plane: latency-bound, so
-        all planes of a phase go out as one batch.
-        """
+        """Fill the 1-cell ring of 2-D planes shaped (jme-jms+1, ime-ims+1) from the neighbouring ranks, corners included (the
+        stencil has diagonal terms, gw:264-286) -- one phase: <= 8 messages per call, all planes of a call sharing them
+        (~25 KB per edge neighbour at the config-4 grid on 8 ranks: latency-bound).  Planes are torch tensors: HBM tensors travel
+        over RCCL send/recv (xGMI, GPU-direct), CPU tensors over gloo."""
         if self.halo_lib is not None:
             return self._exchange_cabi(planes, geom)
         if not self.dist:
@@ -112,77 +200,73 @@ class Comm:
         plan = self._halo_plans.get(key)
         if plan is None:
             plan = self._halo_plans[key] = self._build_plan(planes, geom)
-        for legs in plan:                                    # phase 1: left / right, phase 2: down / up
-            self._run_phase(legs)
+        self._run_plan(plan)
 
     def probe_halo(self):
-        """One tiny send/recv round between ring neighbours with the mover exchange_halo will use, checked and AGREED on by all
-        ranks (one all_reduce) -- called once at set-up by bench.py.  If device send/recv raises or returns wrong data on any rank
-        (or NMP_HALO_FORCE_HOST=1), every rank switches to edges staged through the host over a gloo group: slower, but the run
-        completes and says so (`halo_mover`).  Returns the mover's name."""
-        if not self.dist or self.halo_lib is not None:
-            return "noahmp_hip_exchange_halo" if self.halo_lib is not None else "none"
+        """Once at set-up (bench.py): one tiny send/recv round between ring neighbours with the mover exchange_halo will use,
+        checked and AGREED on by all ranks.  If device send/recv raises or returns wrong data on any rank (or
+        NMP_HALO_FORCE_HOST=1), every rank switches to edges staged through the host over the gloo group: slower, but the run
+        completes and says so.  Returns the mover's name."""
+        if not self.dist:
+            return "none"
+        if self.halo_lib is not None:
+            return "noahmp_hip_exchange_halo (%s transport, one phase)" % ("RCCL" if self.halo == "rccl" else "socket")
         import torch
         dist = self.dist
-        dev = self._dev()
-        bad = 1.0 if os.environ.get("NMP_HALO_FORCE_HOST") == "1" else 0.0
-        if not bad and self.backend == "nccl":
+        bad = os.environ.get("NMP_HALO_FORCE_HOST") == "1"
+        if not bad and self.dev_group is not None:
             try:
+                dev = torch.device("cuda", self.device_index)
                 send = torch.full((256,), float(self.rank), device=dev)
                 recv = torch.full((256,), -1.0, device=dev)
                 nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
-                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt), dist.P2POp(dist.irecv, recv, prv)]):
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, nxt, group=self.dev_group),
+                                                 dist.P2POp(dist.irecv, recv, prv, group=self.dev_group)]):
                     w.wait()
                 torch.cuda.synchronize()
                 if not bool((recv == float(prv)).all()):
-                    bad = 1.0
+                    bad = True
             except Exception as e:                                   # noqa: BLE001  (any failure of the device mover)
                 print("noahmp_amd.parallel: device send/recv failed on rank %d (%s)" % (self.rank, e), file=sys.stderr, flush=True)
-                bad = 1.0
-        ctrl = getattr(self, "ctrl_group", None)
-        flag = torch.tensor([bad], dtype=torch.float32, device="cpu" if ctrl is not None else dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=ctrl)     # nccl runs: over the gloo control group (host tensor)
+                bad = True
+        mine = "ok" if not bad else "device send/recv failed or forced off"
+        any_bad = self._agree_any(bad)
         per_rank = [None] * self.world
-        dist.all_gather_object(per_rank, "ok" if not bad else "device send/recv failed or forced off", group=ctrl)
+        dist.all_gather_object(per_rank, mine)
         self.probe_results = per_rank
-        if float(flag.item()) > 0.0:
-            self.p2p_group = ctrl if ctrl is not None else dist.new_group(backend="gloo")    # (collective: every rank creates it)
+        if any_bad or self.dev_group is None:
             self.p2p_host = True
             self._halo_plans = {}
-            return "torch.distributed over gloo, edges staged through the host (device send/recv unavailable)"
-        return "torch.distributed send/recv (%s)" % ("RCCL" if self.backend == "nccl" else self.backend)
+            if self.backend == "nccl" or any_bad:
+                return "torch.distributed over gloo, edges staged through the host (device send/recv unavailable)"
+            return "torch.distributed send/recv (gloo, one phase)"
+        return "torch.distributed send/recv (RCCL, one phase)"
 
     def _build_plan(self, planes, geom):
-        """Views, persistent staging buffers and P2P descriptors of the two phases for these planes: the per-call work is then one
-        copy per edge, one batch_isend_irecv per phase and one copy per received edge (the exchange is latency-bound; at 8 ranks
-        a step of the config-4 run is under a millisecond, so the Python side must not rebuild anything per call)."""
+        """Views, persistent staging buffers and P2P descriptors for these planes: the per-call work is then one copy per outgoing
+        edge, ONE batch_isend_irecv and one copy per received edge (the exchange is latency-bound; at 8 ranks a step of the
+        config-4 run is about half a millisecond, so the Python side must not rebuild anything per call)."""
         dist = self.dist
-        nb = self.my_neighbours()
-        i0, i1 = geom["its"] - geom["ims"], geom["ite"] - geom["ims"]
-        j0, j1 = geom["jts"] - geom["jms"], geom["jte"] - geom["jms"]
-        rows = slice(j0, j1 + 1)
-        full = slice(None)
-        phases = [[(nb["left"], (rows, i0), (rows, i0 - 1)), (nb["right"], (rows, i1), (rows, i1 + 1))],
-                  [(nb["down"], (j0, full), (j0 - 1, full)), (nb["up"], (j1, full), (j1 + 1, full))]]
-        plan = []
-        for legs in phases:
-            edges, ops = [], []
-            for peer, send_ix, recv_ix in legs:
-                if peer < 0:
-                    continue
-                for p in planes:
-                    sview, rview = p[send_ix], p[recv_ix]
-                    host = (self.backend == "gloo" or self.p2p_host) and p.is_cuda   # gloo has no device send/recv: stage through the host
-                    sbuf = sview.new_empty(sview.shape, device="cpu" if host else p.device)
-                    rbuf = sbuf.new_empty(sbuf.shape)
-                    ops.append(dist.P2POp(dist.isend, sbuf, peer, group=self.p2p_group))
-                    ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=self.p2p_group))
-                    edges.append((sview, sbuf, rview, rbuf))
-            plan.append((edges, ops))
-        return plan
+        nb = neighbours8(self.rank, self.world)
+        group = None if self.p2p_host else self.dev_group
+        edges, ops = [], []
+        for name, dx, dy in DIRS8:
+            peer = nb[name]
+            if peer < 0:
+                continue
+            send_ix, recv_ix = _edge_slices(geom, dx, dy)
+            for p in planes:
+                sview, rview = p[send_ix], p[recv_ix]
+                host = self.p2p_host and p.is_cuda              # gloo has no device send/recv: stage through the host
+                sbuf = sview.new_empty(sview.shape, device="cpu" if host else p.device)
+                rbuf = sbuf.new_empty(sbuf.shape)
+                ops.append(dist.P2POp(dist.isend, sbuf, peer, group=group))
+                ops.append(dist.P2POp(dist.irecv, rbuf, peer, group=group))
+                edges.append((sview, sbuf, rview, rbuf))
+        return edges, ops
 
-    def _run_phase(self, phase):
-        edges, ops = phase
+    def _run_plan(self, plan):
+        edges, ops = plan
         if not ops:
             return
         for sview, sbuf, rview, rbuf in edges:
@@ -193,7 +277,7 @@ class Comm:
             rview.copy_(rbuf, non_blocking=True)
 
     def _exchange_cabi(self, planes, geom):
-        """The same two-phase exchange done by the engine library (noahmp_hip_exchange_halo): device planes on torch's current
+        """The same exchange done by the engine library (noahmp_hip_exchange_halo): device planes on torch's current
         stream, host planes (numpy arrays / CPU tensors) over its socket transport."""
         import ctypes as C
         import numpy as np
@@ -210,11 +294,7 @@ class Comm:
         if rc:
             raise RuntimeError("noahmp_hip_exchange_halo: rc=%d %s" % (rc, self.halo_lib.noahmp_hip_last_error().decode()))
 
-    # ---- timing / metric plumbing
-    def _dev(self):
-        import torch
-        return torch.device("cuda", self.device_index) if (self.dist and self.backend == "nccl") else torch.device("cpu")
-
+    # ---- timing / metric plumbing (control plane: host tensors over gloo)
     def barrier(self):
         if self.dist:
             self.dist.barrier()
@@ -223,7 +303,7 @@ class Comm:
         if not self.dist:
             return float(x)
         import torch
-        t = torch.tensor([float(x)], dtype=torch.float64, device=self._dev())
+        t = torch.tensor([float(x)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -231,7 +311,7 @@ class Comm:
         if not self.dist:
             return float(x)
         import torch
-        t = torch.tensor([float(x)], dtype=torch.float64, device=self._dev())
+        t = torch.tensor([float(x)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 

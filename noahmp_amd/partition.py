@@ -44,6 +44,24 @@ def neighbours(rank, nproc):
                 down=rank - npx if ipy > 0 else -1, up=rank + npx if ipy < npy - 1 else -1)
 
 
+# the eight ring neighbours in the order the one-phase exchange visits them (edge types first; inside a type the lower-ranked
+# peer first, so that blocking pairwise transfers follow one global order of the links and cannot wait in a cycle)
+DIRS8 = (("left", -1, 0), ("right", 1, 0), ("down", 0, -1), ("up", 0, 1),
+         ("down_left", -1, -1), ("up_right", 1, 1), ("down_right", 1, -1), ("up_left", -1, 1))
+
+
+def neighbours8(rank, nproc):
+    """The four edge neighbours of mpp:93-107 plus the four diagonal ranks whose corner cell the 9-point LATERALFLOW stencil reads
+    (gw:264-286): name -> rank id or -1, in DIRS8 order."""
+    npx, npy = nprocs_xy(nproc)
+    ipx, ipy = rank % npx, rank // npx
+    out = {}
+    for name, dx, dy in DIRS8:
+        x, y = ipx + dx, ipy + dy
+        out[name] = y * npx + x if (0 <= x < npx and 0 <= y < npy) else -1
+    return out
+
+
 def tile_geometry(global_nx, global_ny, nproc, rank, halo=1):
     """WRF-style index block of one rank: domain ids..jde = the global grid, tile its..jte = the rank's
     block, memory ims..jme = the tile plus `halo` cells towards every side that has a neighbour (so the

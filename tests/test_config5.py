@@ -65,3 +65,22 @@ def test_gpu_config5_chain_with_resorts_bit_identical():
     res = run(360, 180, nsteps=30, nsample=2048, verbose=False, checkpoints=(1, 7, 24), resort_every=6, resort_frac=-1.0)
     assert res["sample_bit_identical"], res
     assert res["resorts"] == 4 and res["checkpoints"] == [1, 7, 24, 30]
+
+
+@pytest.mark.gpu
+def test_gpu_config5_full_size_sample_bit_identical():
+    """BASELINE configs[4] at its full size (3600 x 1800 = 6 480 000 cells; the grid `bench.py --workload config5` and the default
+    line's `config5_reference` leg time): cold start on the device, 24 hourly steps of interpolate -> prepare -> step on the sorted
+    layout, every sync status 0 (the model's own SW / energy / water balance checks for every column, lsm:1185-1221,
+    gla:2939-2968) and every cell visited every step; a fixed random sample of 4096 columns is advanced by the oracle through the
+    same chain from the same raw state and compared bit for bit at steps 1, 12 and 24 -- the twin of
+    test_config3_full_size_sorted_sample_bit_identical."""
+    from tools.config5_run import run
+    res = run(3600, 1800, nsteps=24, nsample=4096, verbose=False, checkpoints=(1, 12))
+    assert res["device_status_max"] == 0, res
+    assert res["cells_stepped"] == 3600 * 1800 * 24, res
+    assert res["sample_bit_identical"], res
+    assert res["checkpoints"] == [1, 12, 24]
+    assert res["glacier_in_sample"] > 10 and res["water_in_sample"] > 10
+    assert set(res["isnow_states_in_sample"]) >= {0, -3}
+    assert res["land_columns"] > 6_000_000

@@ -329,6 +329,60 @@ def test_bench_two_ranks_equal_one_rank(workload, tmp_path, monkeypatch):
     assert seen == 96 * 130
 
 
+_ONE_RANK = {}
+
+
+def _one_rank_dump(workload, tmp_path_factory):
+    """the single-rank run of the global grid, once per workload and test session"""
+    if workload not in _ONE_RANK:
+        d = str(tmp_path_factory.mktemp("one_" + workload))
+        one, dump = _run_bench(["--gpus", "1", "--workload", workload], d, "one")
+        assert one["n_gpus"] == 1
+        _ONE_RANK[workload] = np.load(dump + ".rank0.npz")
+    return _ONE_RANK[workload]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,workload,halo", [(8, "config4", "torch"), (8, "config4", "tcp"), (9, "config4", "torch"), (9, "config4", "tcp"),
+                                                 (8, "config3", "torch"), (8, "config5", "torch")])
+def test_bench_north_star_tiling_equals_one_rank(world, workload, halo, tmp_path, tmp_path_factory):
+    """The north-star decomposition on the HIP path: `bench.py --gpus 8` = the 4 x 2 rank grid of mpp_land_get_nprocsxy
+    (mpp:124-141), `--gpus 9` = 3 x 3, whose centre rank has four edge neighbours and four diagonal ones (the corner cells of the
+    9-point LATERALFLOW stencil, gw:264-286, arrive through the two-phase order of mpp_land_comlr_real / comub_real, mpp:344-369,
+    603-613).  All ranks share the one GPU of the box (NMP_DIST_BACKEND=gloo: the ring is staged through the host, or moved by the
+    engine's own C-ABI exchange over its socket transport); every rank runs the device kernels on its own tile + ring.  Every INOUT /
+    OUT array of every tile equals the single-rank run of the same global grid bit for bit after 2 + 5 steps -- the config-4
+    groundwater step (ring exchange every step) included; config 3 / config 5: the collective-free split of the same rank grid."""
+    gx, gy = (96, 130) if workload != "config5" else (120, 66)
+    common = ["--workload", workload] + (["--ni", str(gx), "--nj", str(gy)] if workload == "config5" else [])
+    if workload == "config5":
+        one, d1 = _run_bench(["--gpus", "1"] + common, str(tmp_path), "one5")
+        whole = np.load(d1 + ".rank0.npz")
+    else:
+        whole = _one_rank_dump(workload, tmp_path_factory)
+    res, dn = _run_bench(["--gpus", str(world)] + common + (["--halo", halo] if workload == "config4" else []), str(tmp_path), "many")
+    assert res["n_gpus"] == world and res["scaling"] == "strong"
+    if workload == "config4":
+        assert res["groundwater"]["calls"] == 5 and "ring exchange" in res["config"]["parallelism"]
+        assert ("noahmp_hip_exchange_halo" in res["config"]["parallelism"]) == (halo == "tcp")
+    from noahmp_amd.partition import tile_geometry, neighbours
+    seen, most_nb = 0, 0
+    for r in range(world):
+        part = np.load(dn + ".rank%d.npz" % r)
+        its, ite, jts, jte = part["geom"]
+        g = tile_geometry(gx, gy, world, r, halo=0)
+        assert (its, ite, jts, jte) == (g["its"], g["ite"], g["jts"], g["jte"])
+        most_nb = max(most_nb, sum(1 for v in neighbours(r, world).values() if v >= 0))
+        for k in part.files:
+            if k == "geom":
+                continue
+            want = whole[k][jts - 1:jte, ..., its - 1:ite]
+            assert np.array_equal(want, part[k], equal_nan=True), "%s rank %d of %d" % (k, r, world)
+        seen += (ite - its + 1) * (jte - jts + 1)
+    assert seen == gx * gy
+    assert most_nb == (4 if world == 9 else 3)              # 4 x 2: an inner rank has three edge neighbours; 3 x 3: the centre has four
+
+
 # ------------------------------------------------------------------------------------------------
 # The C-ABI halo exchange (noahmp_hip_halo_init / noahmp_hip_exchange_halo, socket transport) on host planes: no torch.distributed,
 # no gloo, no GPU -- what a Fortran / MPI caller binds.  Parity target: the ring cells equal the neighbours' tile cells of ONE

@@ -92,6 +92,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     # ---- device run: record evaluation (torch) and the engine's kernels share one stream, so they are ordered
     snaps = {}
     resorts, stale_seen = 0, []
+    dev_codes, n_done = [], 0
     ts = torch.cuda.Stream(device=dev)
     sp = ts.cuda_stream
     torch.cuda.synchronize()
@@ -112,6 +113,8 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
             if n + 1 in checkpoints or (n + 1) % 24 == 0 or resort_due:
                 st, _ = eng.sync()
                 kernel_ms += st.kernel_ms
+                dev_codes.append(int(st.code))                           # 0 = every column passed the model's own balance checks
+                n_done += st.n_land + st.n_glacier + st.n_skipped
                 if n + 1 in checkpoints:
                     t_hold = time.perf_counter()
                     inv = torch.empty(ni * nj, dtype=torch.int64, device=dev)
@@ -163,7 +166,8 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     isn = sorted(set(np.unique(osamp.a["isnowxy"]).tolist()))
     res = dict(options=cfgkw or {}, grid=[ni, nj], steps=nsteps, land_columns=n_land, wall_s=round(wall, 3), ms_per_step=round(wall / nsteps * 1e3, 3),
                column_steps_per_s=n_land * nsteps / wall, column_kernel_ms_per_step=round(kernel_ms / nsteps, 3),
-               resorts=resorts, stale_columns_seen=stale_seen[-3:],
+               resorts=resorts, stale_columns_seen=stale_seen[-3:], device_status_max=max(dev_codes) if dev_codes else None,
+               cells_stepped=int(n_done),
                sample=nsample, sample_bit_identical=bool(ok_all), checkpoints=[c for c, _, _ in report],
                isnow_states_in_sample=isn, oracle_sample_s=round(t_or, 1),
                glacier_in_sample=int((osamp.a["ivgtyp"] == raw.cfg.isice).sum()),
