@@ -250,7 +250,7 @@ class Run:
         if workload == "config2":
             cfg = ModelConfig(idveg=1, dt=args.dt)
         else:
-            cfg = ModelConfig(iopt_run=5 if self.lateral else 1, idveg=args.dveg, dt=args.dt)
+            cfg = ModelConfig(**dict(dict(iopt_run=5 if self.lateral else 1, idveg=args.dveg, dt=args.dt), **(getattr(args, "opts", None) or {})))
         self.cfg = cfg
         geom = tile_geometry(gx, gy, comm.world, comm.rank, halo=1 if self.lateral else 0)
         self.geom = geom
@@ -598,6 +598,130 @@ WORKLOAD_TEXT = {
 }
 
 
+def timed_leg(run, steps, warmup, barrier):
+    """warm-up, then `steps` timed steps between two barriers; -> seconds of the timed region"""
+    it = 0
+    for _ in range(warmup):
+        it += 1
+        run.step(it)
+    run.collect()
+    run.reset_counters()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        it += 1
+        run.step(it)
+    run.collect()
+    barrier()
+    return time.perf_counter() - t0
+
+
+# Option sets of the `options_reference` legs: none of them has an ahead-of-time kernel, so they run through the kernels
+# noahmp_jit.hip specialises with hiprtc (loaded from the in-tree cache build() warms), the last leg through the generic kernel
+# (run-time options) that serves a call when hiprtc is not available
+OPTION_LEGS = (("DVEG=2 (dynamic vegetation + CARBON)", dict(idveg=2), True),
+               ("OPT_SFC=2 (Chen97 surface layer)", dict(iopt_sfc=2), True),
+               ("OPT_FRZ=2 x OPT_INF=2 (Koren99 supercooled water and frozen-soil permeability)", dict(iopt_frz=2, iopt_inf=2), True),
+               ("OPT_RUN=3 (Schaake96 free drainage)", dict(iopt_run=3), True),
+               ("namelist options through the GENERIC kernel (options as run-time values: fixed_option_kernels = jit_option_kernels = 0)", {}, False))
+
+
+def options_legs(args, comm, eng, tb, dev, barrier, torch):
+    """SURVEY 8d config 3 "full option sweep run as separate launches": the headline grid under other option sets."""
+    out = []
+    steps, warmup = min(args.steps, 24), min(args.warmup, 3)
+    for label, opts, specialised in OPTION_LEGS:
+        a = argparse.Namespace(**vars(args))
+        a.opts, a.dump = opts, None
+        prev = {}
+        if not specialised:
+            prev = {k: eng.set_option(k, 0) for k in ("fixed_option_kernels", "jit_option_kernels")}
+        try:
+            r = Run(a, "config3", comm, eng, tb, dev)
+            dt = timed_leg(r, steps, warmup, barrier)
+            K = steps
+            out.append({"options": label, "kernel": "run-time specialised (hiprtc)" if specialised else "generic",
+                        "value": r.n_adv / dt, "unit": "column-steps/s", "ms_per_step": dt / K * 1e3, "steps": K,
+                        "land_kernel_ms": r.class_ms[0] / K, "columns_per_launch": int(r.n_land / K),
+                        "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_land / K) / (r.class_ms[0] / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "first_forcing_hour": forcing_hour(warmup + 1, args.dt)})
+            del r
+        finally:
+            for k, v in prev.items():
+                eng.set_option(k, v)
+        torch.cuda.empty_cache()
+    return out
+
+
+def host_path_leg(args, eng, tb, torch):
+    """SURVEY 8d "end-to-end incl. H2D/D2H": the headline grid through noahmp_hip_step(NOAHMP_MEM_HOST) -- what the unedited call
+    site hdrv:386-415 gets, host arrays in, host arrays out.  (1) the plain path: every array staged up, INOUT + OUT staged back,
+    every call; (2) the resident path the Fortran shim can switch on (resident_state + lazy_download + static_inputs +
+    deferred_status, arrays page-locked): the state stays in the device mirrors, a call uploads the forcing and returns when the
+    caller may overwrite its forcing arrays; one fetch at the end (an output / restart time).  The loop writes the next hour's
+    forcing into the SAME host arrays between calls, as the driver's reader does (that host copy is inside the wall time).
+    Tile order, mixed-class kernel: the caller owns the column order on this path."""
+    import numpy as np
+    from noahmp_amd import synth
+    from noahmp_amd.state import ModelConfig
+    cfg = ModelConfig(idveg=args.dveg, dt=args.dt)
+    s = synth.config3_tile(tb, args.ni, args.nj, cfg=cfg)
+    synth.first_step_fixups(s)
+    hours = {}
+    for h in range(6, 18):
+        synth.diurnal_forcing(s, h, t_offset=s.t_offset)
+        hours[h] = {k: s.a[k].copy() for k in FKEYS}
+    res = {"workload": "the headline grid %dx%d through noahmp_hip_step(NOAHMP_MEM_HOST): host arrays in, host arrays out, tile order "
+                       "(mixed-class kernel), forcing rewritten in the caller's arrays between calls" % (args.ni, args.nj), "unit": "column-steps/s"}
+
+    def write_forcing(h):
+        for k in FKEYS:
+            np.copyto(s.a[k], hours[h][k])
+
+    def loop(n, first_it):
+        km, adv = 0.0, 0
+        t0 = time.perf_counter()
+        for i in range(n):
+            write_forcing(6 + (first_it + i - 1) % 12)
+            st = eng.noahmplsm(s, first_it + i, 2000, 180.0)
+            km += st.kernel_ms
+            adv += st.n_land + st.n_glacier
+        return time.perf_counter() - t0, km, adv
+
+    tw = time.perf_counter()
+    write_forcing(6)
+    res["host_forcing_write_ms"] = (time.perf_counter() - tw) * 1e3
+    # (1) plain: stage everything both ways (pageable arrays, single shot)
+    prev = {"host_chunks": eng.set_option("host_chunks", 0)}
+    eng.noahmplsm(s, 1, 2000, 180.0)
+    dt, km, adv = loop(2, 2)
+    res["stage_everything"] = {"value": adv / dt, "ms_per_step": dt / 2 * 1e3, "kernel_ms": km / 2, "steps": 2,
+                               "bytes_up_per_step": int(sum(v.nbytes for k, v in s.a.items() if k != "dzs")),
+                               "note": "pageable host arrays, every array H2D and INOUT + OUT D2H per call"}
+    # (2) resident state behind the same call
+    opts = dict(pin_host_arrays=1, resident_state=1, lazy_download=1, static_inputs=1, deferred_status=1)
+    for k, v in opts.items():
+        prev[k] = eng.set_option(k, v)
+    try:
+        for it in (4, 5, 6):                      # state rebuilt, arrays registered (second sighting), both IN buffers filled
+            eng.noahmplsm(s, it, 2000, 180.0)
+        n = 12
+        t0 = time.perf_counter()
+        dt, km, adv = loop(n, 7)
+        tf = time.perf_counter()
+        eng.fetch()                               # waits for the last step, brings INOUT + OUT arrays back
+        t1 = time.perf_counter()
+        res["resident"] = {"value": s.ncol * n / (t1 - t0), "ms_per_step": (tf - t0) / n * 1e3, "fetch_ms": (t1 - tf) * 1e3, "steps": n,
+                           "ms_per_step_with_one_fetch_per_%d_steps" % n: (t1 - t0) / n * 1e3,
+                           "options": sorted(opts), "note": "value = all cells of the tile x steps / wall time incl. the final fetch (the "
+                           "deferred status of a call reports the PREVIOUS step, so tallies lag by one)"}
+    finally:
+        for k in ("deferred_status", "static_inputs", "lazy_download", "resident_state", "pin_host_arrays", "host_chunks"):
+            if k in prev:
+                eng.set_option(k, prev[k])
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -628,6 +752,10 @@ def main():
                          "transport, or torch.distributed send/recv (RCCL under the nccl backend); auto = the C-ABI RCCL mover when it "
                          "starts and passes a checked probe exchange on every rank, else torch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-options-reference", action="store_true",
+                    help="N = 1, default workload: skip the legs under other option sets (run-time specialised kernels, generic kernel)")
+    ap.add_argument("--no-host-path-reference", action="store_true",
+                    help="N = 1, default workload: skip the PCIe-inclusive leg through noahmp_hip_step(NOAHMP_MEM_HOST)")
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="N = 1, default workload: skip the short config-4 run that gives the N = 1 point of the --gpus N curve")
     ap.add_argument("--dump", default=None, help="write every rank's tile (tile order, without the ring) to DUMP.rank<r>.npz after the run")
@@ -708,7 +836,7 @@ def main():
     # The default N > 1 workload is config 4 (the same grid with the groundwater exchange).  So that a scaling curve over
     # N = 1, 2, 4, 8 has its N = 1 point on the SAME workload, the default N = 1 run measures it too, after the headline (a second,
     # separately timed region of the same length; reported beside the headline, never as `value`).
-    scaling_ref = config5_ref = None
+    scaling_ref = config5_ref = options_ref = host_ref = None
     if world == 1 and workload == "config3" and args.workload is None and not args.no_scaling_reference:
         summary = dict(tsk_bin=run.tsk_bin, class_ms=list(run.class_ms), n_land=run.n_land, n_adv=run.n_adv, resorts=run.resorts, stale=list(run.stale_seen),
                        sorted=run.sorted, lateral=run.lateral, tile_cells=run.tile_cells, stepwtd=run.stepwtd, kernel_ms=run.kernel_ms,
@@ -716,20 +844,7 @@ def main():
         del run
         torch.cuda.empty_cache()
         r4 = Run(args, "config4", comm, eng, tb, dev)
-        it4 = 0
-        for _ in range(args.warmup):
-            it4 += 1
-            r4.step(it4)
-        r4.collect()
-        r4.reset_counters()
-        barrier()
-        t4 = time.perf_counter()
-        for _ in range(args.steps):
-            it4 += 1
-            r4.step(it4)
-        r4.collect()
-        barrier()
-        dt4 = time.perf_counter() - t4
+        dt4 = timed_leg(r4, args.steps, args.warmup, barrier)
         scaling_ref = {"workload": "BASELINE configs[3] on one GPU (`--workload config4`): the N = 1 point of the --gpus N strong-scaling curve",
                        "value": r4.n_adv / dt4, "unit": "column-steps/s", "ms_per_step": dt4 / args.steps * 1e3, "steps": args.steps,
                        "groundwater_calls": r4.gw_calls, "column_kernels_ms_per_step": r4.kernel_ms / args.steps}
@@ -740,26 +855,19 @@ def main():
             a5 = argparse.Namespace(**vars(args))
             a5.ni, a5.nj, a5.dump = 3600, 1800, None
             r5 = Run5(a5, comm, eng, tb, dev)
-            it5 = 0
-            for _ in range(args.warmup):
-                it5 += 1
-                r5.step(it5)
-            r5.collect()
-            r5.reset_counters()
-            barrier()
-            t5 = time.perf_counter()
-            for _ in range(args.steps):
-                it5 += 1
-                r5.step(it5)
-            r5.collect()
-            barrier()
-            dt5 = time.perf_counter() - t5
+            dt5 = timed_leg(r5, args.steps, args.warmup, barrier)
             config5_ref = {"workload": WORKLOAD_TEXT["config5"] % dict(cols=3600 * 1800, ni=3600, nj=1800, world=1, steps=args.steps) +
                            " (`--workload config5`)",
                            "value": r5.n_adv / dt5, "unit": "column-steps/s", "ms_per_step": dt5 / args.steps * 1e3, "steps": args.steps,
                            "columns_advanced_per_step": r5.n_adv // args.steps, "column_kernels_ms_per_step": r5.kernel_ms / args.steps,
+                           "land_kernel_ms": r5.class_ms[0] / args.steps, "land_ice_kernel_ms": r5.class_ms[1] / args.steps,
                            "cold_start_s": r5.cold_start_s}
             del r5
+            torch.cuda.empty_cache()
+        if not args.no_options_reference:
+            options_ref = options_legs(args, comm, eng, tb, dev, barrier, torch)
+        if not args.no_host_path_reference:
+            host_ref = host_path_leg(args, eng, tb, torch)
             torch.cuda.empty_cache()
 
         class _R:            # what the report below needs of the headline run
@@ -881,6 +989,10 @@ def main():
             out["scaling_reference"] = scaling_ref
         if config5_ref is not None:
             out["config5_reference"] = config5_ref
+        if options_ref is not None:
+            out["options_reference"] = options_ref
+        if host_ref is not None:
+            out["host_path_reference"] = host_ref
         if workload == "config5":
             out["cold_start_s"] = run.cold_start_s
         if cpu is not None:
