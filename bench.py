@@ -598,6 +598,41 @@ WORKLOAD_TEXT = {
 }
 
 
+# SIMD cycles a wave64 VALU instruction occupies the vector ALU with two or more waves per SIMD, measured on this chip
+# (tools/micro/valu_issue.hip, profiles/r04_valu_issue.txt): full-rate float32 / integer ~2.15, compares / selects / min / max / the
+# division helpers / lane moves / conversions / packed float32 ~4.1, float64 arithmetic ~4.4, v_rcp / v_sqrt float32 8.2
+VALU_CYCLES = {"full": 2.15, "half": 4.1, "f64": 4.4, "cvt": 4.1, "trans": 8.2}
+
+
+def valu_roofline(pm, dv, dom_ms, source):
+    """Share of the kernel's duration in which the SIMDs' vector ALUs are occupied, under three prices per instruction: the guide's
+    2 cycles for everything (lower bound), this chip's measured price list applied to the PMC instruction classes (float64, conversions,
+    transcendentals counted; the rest split full-rate / half-rate by the kernel's static mix, `half_rate_share_of_rest`), and 4
+    cycles for everything (upper bound = round 3's figure)."""
+    n = pm["SQ_INSTS_VALU"]
+    simd_cycles = SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3
+    f64 = sum(pm.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64"))
+    cvt, trans = pm.get("SQ_INSTS_VALU_CVT", 0.0), pm.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+    rest = max(n - f64 - cvt - trans, 0.0)
+    half_share = dv.get("half_rate_share_of_rest", 0.40)      # static mix of the land kernel (tools/isa_stats.py): selects, compares, division helpers, lane moves, packed, min / max
+    priced = (f64 * VALU_CYCLES["f64"] + cvt * VALU_CYCLES["cvt"] + trans * VALU_CYCLES["trans"] +
+              rest * (half_share * VALU_CYCLES["half"] + (1.0 - half_share) * VALU_CYCLES["full"]))
+    out = {"bound": "valu", "wave_insts_per_launch": n, "insts_per_column_step_wave": dv.get("valu_insts_per_column_step"),
+           "lane_utilisation": dv.get("lane_utilisation"), "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+           "frac": priced / simd_cycles, "frac_if_every_instruction_took_2_cycles": n * 2.0 / simd_cycles,
+           "frac_if_every_instruction_took_4_cycles": n * 4.0 / simd_cycles,
+           "cycles_per_instruction_class": VALU_CYCLES, "half_rate_share_of_rest": half_share,
+           "instruction_classes_per_launch": {"float64": f64, "conversions": cvt, "transcendental_f32": trans, "other": rest},
+           "source": source,
+           "note": "share of the kernel's duration in which the SIMDs' vector ALUs are occupied: instructions of the launch (PMC) priced by the "
+                   "measured SIMD cycles per instruction class (profiles/r04_valu_issue.txt) / (1024 SIMDs x 2.4 GHz x kernel time).  The "
+                   "kernel holds two waves per SIMD and a wave by itself issues at most one VALU instruction per ~4.2 cycles, so its waves are "
+                   "bound by their own serial instruction streams and s_waitcnt stalls, not by ALU throughput (profiles/r04_experiments.md)"}
+    if pm.get("SQ_ACTIVE_INST_VALU"):
+        out["wave_cadence_cycles_per_instruction"] = 4.0 * pm["SQ_ACTIVE_INST_VALU"] / n
+    return out
+
+
 def timed_leg(run, steps, warmup, barrier):
     """warm-up, then `steps` timed steps between two barriers; -> seconds of the timed region"""
     it = 0
@@ -898,7 +933,7 @@ def main():
         # PMC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this very command,
         # tools/run_profile.sh -> tools/collect_profile.py): the newest committed summary is quoted, and only when workload and
         # columns per launch are those of the profile
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
             if not os.path.exists(tpath):
                 continue
@@ -909,18 +944,8 @@ def main():
                     traffic_source = "profiles/%s_traffic.json (separate rocprofv3 --pmc passes of this command; not measured in this run)" % tag
                     pm = prof.get("pmc_mean_per_launch") or {}
                     dv = prof.get("derived") or {}
-                    if pm.get("SQ_ACTIVE_INST_VALU"):
-                        # VALU-busy roofline: SQ_ACTIVE_INST_VALU counts, per SIMD, the 4-cycle quads in which the VALU executes (a wave64
-                        # instruction occupies the 16-lane SIMD for 4 cycles; float64 / transcendental ones longer)
-                        busy = pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * CLOCK_GHZ * 1e9 * dom_ms * 1e-3)
-                        valu = {"bound": "valu_busy", "busy_quad_cycles_per_launch": pm["SQ_ACTIVE_INST_VALU"],
-                                "wave_insts_per_launch": pm.get("SQ_INSTS_VALU"),
-                                "insts_per_column_step_wave": dv.get("valu_insts_per_column_step"),
-                                "lane_utilisation": dv.get("lane_utilisation"), "simds": SIMDS, "clock_ghz": CLOCK_GHZ, "frac": busy,
-                                "source": traffic_source,
-                                "note": "share of the kernel's duration in which the SIMDs' vector ALUs execute (SQ_ACTIVE_INST_VALU x 4 cycles / "
-                                        "(1024 SIMDs x 2.4 GHz x kernel time)); the rest is both resident waves of a SIMD waiting at once "
-                                        "(LDS look-ups of the libm tables, layer arrays, memory) -- profiles/r03_experiments.md"}
+                    if pm.get("SQ_INSTS_VALU"):
+                        valu = valu_roofline(pm, dv, dom_ms, traffic_source)
                     break
             except Exception:
                 traffic, valu, traffic_source = None, None, None
@@ -969,8 +994,8 @@ def main():
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_COLSTEP * int(dom_cols), "valu": valu,
                          "note": "824 B/column-step x columns of the launch / HIP-event time of that kernel (its own event pair per step on the "
-                                 "stream it runs on, mean over the timed steps); the kernel is bound by VALU work and by the latency of its "
-                                 "dependent chains at two waves per SIMD, not by HBM (SURVEY 8d) -- see `valu`"},
+                                 "stream it runs on, mean over the timed steps); the kernel is bound by the serial instruction streams of its "
+                                 "two waves per SIMD and their stalls, not by HBM (SURVEY 8d) -- see `valu`"},
             "column_kernels_ms_per_step": {"land_or_mixed": run.class_ms[0] / K, "land_ice": run.class_ms[1] / K,
                                            "skipped": run.class_ms[2] / K, "all_max_over_ranks": kernel_ms_max / K},
             "kernel_only_column_steps_per_s": n_adv_all / (kernel_ms_max * 1e-3) if kernel_ms_max else None,
