@@ -503,9 +503,15 @@ class Run5:
         self.lon_t = torch.from_numpy(lon).to(dev).reshape(-1)
         self.static_t = {k: torch.from_numpy(v).to(dev).reshape(-1) for k, v in static.items()}
         self.perm = None
+        self.band = None
         if self.sorted:
             self.tsk_bin = args.tsk_bin if args.tsk_bin is not None else 1.0
             self.sort_kw = dict(tsk_bin=self.tsk_bin)
+            if args.lon_band > 0:
+                # sub-key of the column order: the longitude band (hours of local solar time), so that the columns of a wavefront are in
+                # day or in night together -- the class / vegetation / snow keys put columns of all longitudes side by side
+                d.a["lonband"] = ((torch.from_numpy(lon).to(dev) + 180.0) / float(args.lon_band)).floor().clamp_(0, 31).to(torch.int32).contiguous()
+                self.sort_kw["band"] = self.band = "lonband"
             self.perm = eng.sort_store(d, **self.sort_kw)
         self._bind()
         self.rain = torch.zeros((ny, nx), dtype=torch.float32, device=dev)
@@ -777,6 +783,8 @@ def main():
     ap.add_argument("--resort-frac", type=float, default=0.10,
                     help="re-sort when this share of the columns left their bucket (measured: 11 %% stale columns cost the land kernel 0.8 %%, "
                          "a re-sort 1.7 ms -- profiles/r02_experiments.md)")
+    ap.add_argument("--lon-band", type=float, default=15.0,
+                    help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
@@ -960,7 +968,8 @@ def main():
         desc = WORKLOAD_TEXT[workload] % dict(cols=args.ni * args.nj, ni=args.ni, nj=args.nj, dveg=args.dveg, world=world,
                                               stepwtd=run.stepwtd, steps=K)
         if workload == "config5":
-            desc += ("; sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature bin)" % run.tsk_bin
+            desc += ("; sorted on the device by (class, vegetation type, snow-layer count, %s%g-K skin-temperature bin)"
+                     % (("%g-degree longitude band, " % args.lon_band) if getattr(run, "band", None) else "", run.tsk_bin)
                      if run.sorted else "; tile order")
         elif run.sorted:
             desc += ("; state resident in HBM, sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature "

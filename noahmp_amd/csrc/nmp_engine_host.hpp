@@ -96,7 +96,7 @@ struct LaunchDesc {
   unsigned long long err_base;
   long t_offset, t_first, t_count;
 };
-// mode: 0 mixed tile, 1 land-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
+// mode: 0 mixed tile, 1 land-only range, 2 land-ice-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
 void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);
 #ifdef NMP_PHASE_TIMERS
 void prof_fixed_d1_r1(unsigned long long*, int); void prof_fixed_d3_r1(unsigned long long*, int); void prof_fixed_d3_r5(unsigned long long*, int);

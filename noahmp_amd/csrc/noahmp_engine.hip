@@ -281,7 +281,7 @@ template <int MODE>
 static void launch_range(KArgs k, long first, long count, hipStream_t s) {
   if (count <= 0) return;
   k.t_first = first; k.t_count = count;
-  const int fx = (MODE == 0 || MODE == 1) ? fixed_level(k) : 0;      // land ice / skipped cells hardly depend on the options
+  const int fx = (MODE != 3) ? fixed_level(k) : 0;      // skipped cells do not depend on the options
   if (fx && launch_fixed(k, fx, MODE, s)) return;
   hipLaunchKernelGGL((noahmp_column_kernel<256, true, MODE>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k);
 }

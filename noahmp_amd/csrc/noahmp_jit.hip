@@ -31,7 +31,7 @@ size_t pack_fixed_kargs(const LaunchDesc& d, void* buf, size_t cap);     // noah
 
 namespace {
 
-struct JitKernels { hipModule_t mod = nullptr; hipFunction_t fn[2] = {nullptr, nullptr}; bool failed = false; };
+struct JitKernels { hipModule_t mod = nullptr; hipFunction_t fn[3] = {nullptr, nullptr, nullptr}; bool failed = false; };
 std::map<std::string, JitKernels> cache;
 struct JitStats { int compiled = 0, disk_hits = 0, fallbacks = 0; } stats;
 
@@ -85,7 +85,9 @@ const char* kWrapper =
     "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m0(const nmp::KArgs k) {\n"
     "  column_kernel_body<256, true, 0>(k); }\n"
     "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m1(const nmp::KArgs k) {\n"
-    "  column_kernel_body<256, true, 1>(k); }\n";
+    "  column_kernel_body<256, true, 1>(k); }\n"
+    "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m2(const nmp::KArgs k) {\n"
+    "  column_kernel_body<256, true, 2>(k); }\n";
 const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
 
 uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -188,7 +190,8 @@ void store_code(const std::string& path, const std::vector<char>& code) {
 bool load_module(const std::vector<char>& code, JitKernels& out, std::string& log) {
   if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) { log = "hipModuleLoadData"; (void)hipGetLastError(); return false; }
   if (hipModuleGetFunction(&out.fn[0], out.mod, "nmp_jit_m0") != hipSuccess ||
-      hipModuleGetFunction(&out.fn[1], out.mod, "nmp_jit_m1") != hipSuccess) { log = "hipModuleGetFunction"; (void)hipGetLastError(); return false; }
+      hipModuleGetFunction(&out.fn[1], out.mod, "nmp_jit_m1") != hipSuccess ||
+      hipModuleGetFunction(&out.fn[2], out.mod, "nmp_jit_m2") != hipSuccess) { log = "hipModuleGetFunction"; (void)hipGetLastError(); return false; }
   return true;
 }
 
@@ -262,7 +265,7 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
   const long n = mode == 0 ? (long)d.nti * d.ntj : d.t_count;
   if (n <= 0) return true;
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const hipError_t e = hipModuleLaunchKernel(it->second.fn[mode == 1 ? 1 : 0], (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s,
+  const hipError_t e = hipModuleLaunchKernel(it->second.fn[(mode == 1 || mode == 2) ? mode : 0], (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s,
                                              nullptr, extra);
   if (e != hipSuccess) { (void)hipGetLastError(); it->second.failed = true; g.last_error = "launch of a run-time compiled kernel failed: generic kernel used"; return false; }
   return true;

@@ -19,31 +19,36 @@ struct KeyArgs {
   const float* xland; const float* xice; const float* tsk;   // tsk: the temperature plane of the key (TSK, or level 1 of T3D)
   int t_nk, t_k, ni;                                          // its levels per row, the level taken, the row length
   const int* ivgtyp; const int* isnow;
+  const int* band;                                            // optional caller-defined sub-key plane (noahmp_hip_sort_set_band), or NULL
   float xice_thres, inv_bin;
   int isice, flags;
   long n;
 };
 
-// key = class(2) | a(6) | b(6) | tsk bin(8): class 0 land, 1 land ice, 2 skipped (the classification of drv:426-441);
-// a/b = vegetation type and snow-layer count in the order the flags ask for; skipped columns carry no sub-key.
+// key = class(2) | vegetation type and snow-layer count (8, in the order the flags ask for) | band(5) | tsk bin(8): class 0 land, 1 land ice,
+// 2 skipped (the classification of drv:426-441); skipped columns carry no sub-key.  band: a caller-defined static sub-key, 0..31
+// (noahmp_hip_sort_set_band; e.g. the 15-degree longitude band of a lat/lon grid, so that a wavefront's columns share their local solar time).
+constexpr int kClsShift = 21, kHiShift = 13, kBandShift = 8;
 __device__ __forceinline__ unsigned column_key(const KeyArgs& k, long p) {
   const float xland = k.xland[p], xice = k.xice[p];
   const int ivg = k.ivgtyp[p];
   const unsigned cls = ((xland - 1.5f) >= 0.f || xice >= k.xice_thres) ? 2u : (ivg == k.isice ? 1u : 0u);
-  if (cls == 2u) return 2u << 20;
-  unsigned veg = 0, sn = 0, tb = 0;
+  if (cls == 2u) return 2u << kClsShift;
+  unsigned veg = 0, sn = 0, tb = 0, band = 0;
   if (cls == 0u && (k.flags & NOAHMP_SORT_VEG)) veg = (unsigned)min(max(ivg, 0), 63);
   if (k.flags & NOAHMP_SORT_SNOW) sn = (unsigned)min(max(-k.isnow[p], 0), 3);
+  if (k.band) band = (unsigned)min(max(k.band[p], 0), 31);
   if (k.inv_bin > 0.f) {
     float t = k.t_nk == 1 ? k.tsk[p] : k.tsk[((size_t)(p / k.ni) * k.t_nk + k.t_k) * k.ni + p % k.ni];
     if (!(t == t)) t = 250.f;
     tb = (unsigned)min(max((int)((t - 230.0f) * k.inv_bin), 0), 255);
   }
-  const unsigned hi = (k.flags & NOAHMP_SORT_SNOW_FIRST) ? (sn << 6 | veg) : (veg << 6 | sn);
-  return cls << 20 | hi << 8 | tb;
+  const unsigned hi = (k.flags & NOAHMP_SORT_SNOW_FIRST) ? (sn << 6 | veg) : (veg << 2 | sn);
+  return cls << kClsShift | hi << kHiShift | band << kBandShift | tb;
 }
 constexpr unsigned kTskMask = 0xFFu;
-constexpr int kKeyBits = 22;
+constexpr int kKeyBits = 23;
+const int* g_band_plane = nullptr;      // host-side: the plane the next sort / staleness call reads (device pointer, the store's column order)
 
 __global__ void __launch_bounds__(256) sort_key_kernel(const KeyArgs k, unsigned* keys, int* idx) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +69,7 @@ __global__ void __launch_bounds__(256) sort_stale_kernel(const KeyArgs k, const 
 // class boundaries of the sorted keys: out[0] = land columns, out[1] = land-ice columns
 __global__ void sort_bounds_kernel(const unsigned* keys, long n, long* out) {
   if (threadIdx.x > 1) return;
-  const unsigned want = (threadIdx.x + 1u) << 20;          // first key >= want
+  const unsigned want = (threadIdx.x + 1u) << kClsShift;          // first key >= want
   long lo = 0, hi = n;
   while (lo < hi) { const long mid = (lo + hi) >> 1; if (keys[mid] < want) lo = mid + 1; else hi = mid; }
   out[threadIdx.x] = lo;
@@ -118,6 +123,7 @@ int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_
   k.t_nk = 1; k.t_k = 0; k.ni = a->ime - a->ims + 1;
   if (flags & NOAHMP_SORT_TAIR) { k.tsk = a->t3d; k.t_nk = a->kme - a->kms + 1; k.t_k = 1 - a->kms; }   // the forcing air temperature (level 1)
   k.xice_thres = a->xice_thres; k.isice = a->isice; k.flags = flags;
+  k.band = g_band_plane;
   k.inv_bin = tsk_bin_mk > 0 ? 1000.0f / (float)tsk_bin_mk : 0.f;
   k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
   return 0;
@@ -145,6 +151,11 @@ void sort_finalize() {
 }  // namespace nmp_host
 
 extern "C" {
+
+int noahmp_hip_sort_set_band(const int32_t* band_plane) {
+  g_band_plane = band_plane;
+  return 0;
+}
 
 int noahmp_hip_sort_columns(const noahmp_step_args* a, int flags, int tsk_bin_mk, int32_t* perm_out, uint32_t* keys_out,
                             int64_t* class_counts, void* stream) {

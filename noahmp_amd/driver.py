@@ -190,7 +190,7 @@ class Engine:
         if rc:
             raise RuntimeError("noahmp_hip_stream_sync: " + self.lib.noahmp_hip_last_error().decode())
 
-    def sort_store(self, store, tsk_bin=1.0, veg=True, snow=True, snow_first=False, allow_lateral=False, tair=False):
+    def sort_store(self, store, tsk_bin=1.0, veg=True, snow=True, snow_first=False, allow_lateral=False, tair=False, band=None):
         """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, snow-layer count,
         skin-temperature bin) are adjacent, and return the permutation as an int32 device tensor: sorted position p holds the
         column that sits at linear tile index perm[p] of the ORIGINAL tile order (a second call on an already sorted
@@ -200,7 +200,9 @@ class Engine:
         then hold columns that take the same branches: class and vegetation type select code paths and are static, the
         snow-layer count bounds the layer loops and changes slowly (see sort_staleness), the skin temperature (`tsk_bin`
         K wide bins, 0 = off) is a cheap proxy for the stability / freezing regime a column is in.  Forcing that arrives
-        in tile order goes through `scatter`."""
+        in tile order goes through `scatter`.  band: name of an int32 device plane of the store (values 0..31, static; it is
+        permuted with the state) used as a sub-key between the snow-layer count and the temperature bin (noahmp_hip_sort_set_band),
+        e.g. the 15-degree longitude band of a lat/lon grid: a wavefront's columns then share their local solar time."""
         import numpy as np
         import torch
         assert isinstance(store, DeviceColumnStore)
@@ -215,6 +217,7 @@ class Engine:
         keys = torch.empty(n, dtype=torch.int32, device=store.device)
         counts = (C.c_int64 * 3)()
         torch.cuda.current_stream().synchronize()          # tensors written by torch kernels are read on the engine's stream
+        self.lib.noahmp_hip_sort_set_band(store.a[band].data_ptr() if band else None)
         rc = self.lib.noahmp_hip_sort_columns(C.byref(a), flags, int(round(tsk_bin * 1000)) if tsk_bin else 0,
                                               perm.data_ptr(), keys.data_ptr(), counts, None)
         if rc:
@@ -239,7 +242,8 @@ class Engine:
         self.stream_sync()
         # classes are contiguous now: land, land ice, skipped -- each range gets its own kernel (noahmp_engine.hip, launch_any)
         store.class_ranges = (int(counts[0]), int(counts[1]))
-        store.sort_perm, store.sort_keys, store.sort_flags = perm, keys, flags
+        store.sort_perm, store.sort_keys, store.sort_flags, store.sort_band = perm, keys, flags, band
+        self.lib.noahmp_hip_sort_set_band(None)
         return perm
 
     def sort_staleness(self, store):
@@ -247,7 +251,10 @@ class Engine:
         sorted by -- snow layers that appeared or vanished (lsm:7044, 7110, 7177, 7294-7343).  Waits for the engine's stream."""
         a = store.step_args(1, 2000, 1.0)
         changed = C.c_int64(0)
+        band = getattr(store, "sort_band", None)
+        self.lib.noahmp_hip_sort_set_band(store.a[band].data_ptr() if band else None)      # the key the store was sorted by
         rc = self.lib.noahmp_hip_sort_staleness(C.byref(a), store.sort_flags, store.sort_keys.data_ptr(), C.byref(changed), None)
+        self.lib.noahmp_hip_sort_set_band(None)
         if rc:
             raise RuntimeError("noahmp_hip_sort_staleness: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return int(changed.value)

@@ -24,7 +24,7 @@ def _cols(v, idx=None):
     return v if idx is None else v[idx]
 
 
-def _host_key(s, tsk_bin=1.0, veg=True, snow=True, snow_first=False):
+def _host_key(s, tsk_bin=1.0, veg=True, snow=True, snow_first=False, band=None):
     a = s.a
     ivg = a["ivgtyp"].ravel().astype(np.int64)
     cls = np.where((a["xland"].ravel() - np.float32(1.5) >= 0) | (a["xice"].ravel() >= np.float32(s.cfg.xice_thres)), 2,
@@ -36,20 +36,27 @@ def _host_key(s, tsk_bin=1.0, veg=True, snow=True, snow_first=False):
         t = a["tsk"].ravel().astype(np.float32)
         t = np.where(np.isnan(t), np.float32(250.0), t)
         tb = np.clip(((t - np.float32(230.0)) * np.float32(1000.0 / int(round(tsk_bin * 1000)))).astype(np.int64), 0, 255)
-    hi = (sk << 6 | vk) if snow_first else (vk << 6 | sk)
-    return np.where(cls == 2, 2 << 20, cls << 20 | hi << 8 | tb), cls
+    hi = (sk << 6 | vk) if snow_first else (vk << 2 | sk)
+    bd = np.clip(band.ravel().astype(np.int64), 0, 31) if band is not None else np.zeros_like(ivg)
+    return np.where(cls == 2, 2 << 21, cls << 21 | hi << 13 | bd << 8 | tb), cls     # class(2) | veg, snow(8) | band(5) | tsk bin(8)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(tsk_bin=0), dict(snow_first=True, tsk_bin=0.5), dict(veg=False), dict(snow=False)],
-                         ids=["default", "no_tsk", "snow_first", "no_veg", "no_snow"])
+@pytest.mark.parametrize("kw", [dict(), dict(tsk_bin=0), dict(snow_first=True, tsk_bin=0.5), dict(veg=False), dict(snow=False), dict(band="lonband")],
+                         ids=["default", "no_tsk", "snow_first", "no_veg", "no_snow", "band"])
 def test_device_sort_is_the_stable_sort_of_the_key(engine, tables, kw):
+    import torch
     s = synth.mixed_small(tables[1], ni=160, nj=48, glacier_frac=0.06, seed=71)
     s["xland"][3, :17] = 2.0
     s["xice"][5, 40:47] = 1.0
     s["tsk"][7, 3] = np.nan
     d = s.to_device("cuda:0")
+    band = None
+    if kw.get("band"):          # a caller-defined static sub-key plane (noahmp_hip_sort_set_band): here 24 "longitude bands" + out-of-range values
+        band = (np.arange(160)[None, :] * 24 // 160 + np.zeros((48, 1), np.int64)).astype(np.int32)
+        band[11, 5], band[12, 6] = -3, 77
+        d.a["lonband"] = torch.from_numpy(band).cuda()
     perm = engine.sort_store(d, **kw).cpu().numpy().astype(np.int64)
-    key, cls = _host_key(s, **{"tsk_bin": 1.0, **kw})
+    key, cls = _host_key(s, **{"tsk_bin": 1.0, **kw, "band": band})
     want = np.argsort(key, kind="stable")
     np.testing.assert_array_equal(perm, want)
     np.testing.assert_array_equal(d.sort_keys.cpu().numpy().view(np.uint32).astype(np.int64), key[want])
@@ -58,6 +65,8 @@ def test_device_sort_is_the_stable_sort_of_the_key(engine, tables, kw):
     for k, v in s.a.items():
         if k != "dzs":
             assert np.array_equal(_cols(v, perm), _cols(h.a[k]), equal_nan=True), k
+    if band is not None:        # the band plane travelled with the state
+        assert np.array_equal(band.reshape(-1)[perm], d.a["lonband"].cpu().numpy().reshape(-1))
     assert engine.sort_staleness(d) == 0
 
 

@@ -49,7 +49,7 @@ def extract(store, flat, n=None):
 
 
 def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240), restart_path=None, cfgkw=None,
-        resort_every=24, resort_frac=0.10):
+        resort_every=24, resort_frac=0.10, lon_band=15.0):
     T, tb = load_tables("usgs")
     port = PortLib(autobuild=not os.path.exists(os.path.join(ROOT, "oracle", "_build", "libnoahmp_oracle.so")))
     port.set_tables(T)
@@ -59,7 +59,11 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     dev = torch.device("cuda", 0)
     d = raw.to_device("cuda:0")
     eng.noahmp_init(d, fndsnowh=True)                                  # cold start on the device
-    perm = eng.sort_store(d)                                           # (class, vegetation type, snow layers, TSK bin) order
+    skw = {}
+    if lon_band:                                                       # longitude band (hours of local solar time) as a sub-key of the order
+        d.a["lonband"] = ((torch.from_numpy(lon).to(dev) + 180.0) / float(lon_band)).floor().clamp_(0, 31).to(torch.int32).contiguous()
+        skw["band"] = "lonband"
+    perm = eng.sort_store(d, **skw)                                    # (class, vegetation type, snow layers, [band,] TSK bin) order
     lon_t = torch.from_numpy(lon).to(dev).reshape(-1)
     static_t = {k: torch.from_numpy(v).to(dev).reshape(-1) for k, v in static.items()}
 
@@ -127,7 +131,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
                     stale = eng.sort_staleness(d)
                     stale_seen.append(stale)
                     if stale > resort_frac * ni * nj:
-                        perm = eng.sort_store(d)
+                        perm = eng.sort_store(d, **skw)
                         lon_d, recs = sorted_side(perm)
                         ri2, k2 = divmod(n + 1, synth5.RECORD_HOURS)       # records are in the store's column order: evaluate them again
                         rec_a, rec_b = (recs.at(ri2), recs.at(ri2 + 1)) if k2 else (None, None)
