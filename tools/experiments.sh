@@ -183,6 +183,11 @@ fuzz)
     timeout 1200 python tools/fuzz_parity.py gpu $seeds $cols $o 2>&1 | grep "^gpu\|DIFFER\|Error\|Traceback" | head -4 | tee -a $O/fuzz.log
   done
   timeout 900 python tools/config5_run.py 720 360 96 4096 2>&1 | tail -3 | cut -c1-400 | tee -a $O/fuzz.log
+  # the config-5 chain (cold start -> interpolate -> prepare -> step, sorted with the longitude band) under other option sets
+  for o in "idveg=2 iopt_run=3 iopt_stc=2 iopt_sfc=2 iopt_frz=2" "iopt_rad=1 iopt_alb=1 iopt_snf=3 iopt_tbot=1 idveg=5 iopt_crs=2 iopt_btr=2 iopt_inf=2" \
+           "iopt_run=2 iopt_btr=3 iopt_rad=2 iopt_snf=2" "idveg=4 iopt_run=4"; do
+    timeout 600 python tools/config5_run.py 720 360 96 8192 $o 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['options'], d['sample_bit_identical'], d['checkpoints'], '%.3g' % d['column_steps_per_s'])" | tee -a $O/fuzz.log
+  done
   ;;
 profile)
   TAG=${1:-r04}
