@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -63,10 +63,18 @@ out = {
         "lane_utilisation": pmc.get("SQ_THREAD_CYCLES_VALU", 0) / max(pmc.get("SQ_ACTIVE_INST_VALU", 1) * 64, 1),
         "valu_active_share_of_wave_cycles": pmc.get("SQ_ACTIVE_INST_VALU", 0) / max(pmc.get("SQ_WAVE_CYCLES", 1), 1),
         "wait_any_share_of_wave_cycles": pmc.get("SQ_WAIT_ANY", 0) / max(pmc.get("SQ_WAVE_CYCLES", 1), 1),
+        # share of the instructions that are neither float64 nor conversions nor transcendental and issue at half rate (compares, selects,
+        # min / max, the division helpers, lane moves, packed float32): the static mix of the land kernel (tools/isa_stats.py on a
+        # `hipcc -S` listing of noahmp_engine_d3_r1.hip: 4 470 of 11 150)
+        "half_rate_share_of_rest": 0.40,
+        "cycles_resident_per_wave": 4.0 * pmc.get("SQ_WAVE_CYCLES", 0) / waves,
     },
     "bench_line": bench,
 }
 json.dump(out, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
+sys.path.insert(0, ROOT)
+import bench as _bench  # noqa: E402
+VR = _bench.valu_roofline(pmc, out["derived"], float(krow["AverageNs"]) / 1e6, "this profile")
 L = ["# %s profile: `python3 bench.py` under rocprofv3 (MI355X, 1 GPU, %s: %d columns per launch of the dominant kernel)" % (tag, out["workload"], ncol), "",
      "## `rocprofv3 --kernel-trace --stats` (copied: %s_kernel_stats.csv)" % tag, "",
      "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
@@ -85,16 +93,17 @@ L += ["", "## Derived", "",
       "- VALU instructions per column-step (per wave) = %.0f; lane utilisation %.1f %%; VALU-active %.0f %% and waiting %.0f %% of wave cycles"
       % (out["derived"]["valu_insts_per_column_step"], 100 * out["derived"]["lane_utilisation"],
          100 * out["derived"]["valu_active_share_of_wave_cycles"], 100 * out["derived"]["wait_any_share_of_wave_cycles"]),
-      "- VALU-busy roofline: SQ_ACTIVE_INST_VALU = %.4g quad-cycles per launch x 4 cycles / (1024 SIMDs x 2.4 GHz x %.3f ms) = **%.1f %%** of the kernel's duration "
-      "(a wave64 instruction occupies the 16-lane SIMD for 4 cycles: %.3f quads per VALU instruction measured, float64 / transcendental ones longer)"
-      % (pmc.get("SQ_ACTIVE_INST_VALU", 0), float(krow["AverageNs"]) / 1e6, 100 * pmc.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * 2.4e9 * float(krow["AverageNs"]) * 1e-9),
-         pmc.get("SQ_ACTIVE_INST_VALU", 0) / max(pmc.get("SQ_INSTS_VALU", 1), 1)),
+      "- vector-ALU occupancy under the measured price list (profiles/r04_valu_issue.txt; `bench.py: valu_roofline`): **%.2f** of the kernel's duration "
+      "(every instruction at the guide's 2 cycles: %.2f; every instruction at 4 cycles: %.2f); a wave issues one VALU instruction per %.2f cycles on average "
+      "(4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU) and is resident %.0f cycles (4 x SQ_WAVE_CYCLES / waves)"
+      % (VR["frac"], VR["frac_if_every_instruction_took_2_cycles"], VR["frac_if_every_instruction_took_4_cycles"],
+         VR.get("wave_cadence_cycles_per_instruction", 0.0), out["derived"]["cycles_resident_per_wave"]),
       "- instruction cache: %.3g misses per %.3g requests (%.2f %%); LDS instructions per wave %.0f; float64 VALU instructions %.1f %% and conversions %.1f %% of all VALU instructions"
       % (pmc.get("SQC_ICACHE_MISSES", 0), pmc.get("SQC_ICACHE_REQ", 1), 100 * pmc.get("SQC_ICACHE_MISSES", 0) / max(pmc.get("SQC_ICACHE_REQ", 1), 1),
          pmc.get("SQ_INSTS_LDS", 0) / waves,
          100 * (pmc.get("SQ_INSTS_VALU_FMA_F64", 0) + pmc.get("SQ_INSTS_VALU_MUL_F64", 0) + pmc.get("SQ_INSTS_VALU_ADD_F64", 0)) / max(pmc.get("SQ_INSTS_VALU", 1), 1),
          100 * pmc.get("SQ_INSTS_VALU_CVT", 0) / max(pmc.get("SQ_INSTS_VALU", 1), 1)),
-      "- the kernel is bound by VALU work and by the latency of its dependent chains at two waves per SIMD (every wave waits ~%.0f %% of its cycles, mostly on LDS look-ups of the libm tables and the layer arrays), not by HBM (SURVEY.md 8d)"
+      "- the kernel is bound by the serial instruction streams of its two waves per SIMD (a wave alone issues at most one VALU instruction per ~4.2 cycles) and their stalls (every wave waits ~%.0f %% of its cycles, mostly on LDS look-ups of the libm tables and the layer arrays), not by HBM (SURVEY.md 8d) and not by vector-ALU throughput"
       % (100 * out["derived"]["wait_any_share_of_wave_cycles"]),
       "", "## bench.py line of the same build (un-profiled run)", "", "```", json.dumps(bench), "```", ""]
 # ---- the per-step forcing permutation of the bench (six 2-D planes of the whole tile: read + write + 6 B of plan per column)
@@ -114,6 +123,47 @@ for sub, name in (("trace4", "config 4"), ("trace5", "config 5")):
         for r in list(csv.DictReader(open(fs[0])))[:8]:
             L.append("| %s | %s | %.0f | %s |" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
         L.append("")
+# ---- config 5: traffic and SQ counters of its land kernel (separate passes of `bench.py --workload config5`)
+p5 = {}
+k5name = None
+for d in ("fetch5", "write5", "sq5"):
+    fs = glob.glob(os.path.join(src, d, "*_counter_collection.csv")) + glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+    if not fs:
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if KERN in r["Kernel_Name"] and "true, 1>" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            k5name = r["Kernel_Name"]
+    for k, v in acc.items():
+        p5[k] = sum(v) / len(v)
+if p5:
+    t5 = glob.glob(os.path.join(src, "trace5", "*_kernel_stats.csv")) + glob.glob(os.path.join(src, "trace5", "*", "*_kernel_stats.csv"))
+    k5 = [r for r in csv.DictReader(open(t5[0])) if r["Name"] == k5name] if t5 else []
+    w5 = p5.get("SQ_WAVES", 1)
+    ncol5 = None
+    try:
+        b5 = [json.loads(l) for l in open(os.path.join(src, "bench_trace5.log")) if l.startswith("{")][-1]
+        ncol5 = b5["roofline"]["columns_per_launch"]
+    except Exception:                                     # noqa: BLE001
+        b5 = None
+    o5 = {"round": tag, "workload": "config5", "kernel": k5name, "columns_per_launch": ncol5,
+          "avg_kernel_ns": float(k5[0]["AverageNs"]) if k5 else None, "calls": int(k5[0]["Calls"]) if k5 else None,
+          "algorithmic_bytes_per_launch": 824 * ncol5 if ncol5 else None,
+          "hbm_bytes_per_launch": p5.get("FETCH_SIZE", 0) * 1024 * 2 + p5.get("WRITE_SIZE", 0) * 1024,
+          "pmc_mean_per_launch": p5,
+          "derived": {"valu_insts_per_column_step": p5.get("SQ_INSTS_VALU", 0) / w5, "salu_insts_per_wave": p5.get("SQ_INSTS_SALU", 0) / w5,
+                      "lane_utilisation": p5.get("SQ_THREAD_CYCLES_VALU", 0) / max(p5.get("SQ_ACTIVE_INST_VALU", 1) * 64, 1),
+                      "wait_any_share_of_wave_cycles": p5.get("SQ_WAIT_ANY", 0) / max(p5.get("SQ_WAVE_CYCLES", 1), 1),
+                      "cycles_resident_per_wave": 4.0 * p5.get("SQ_WAVE_CYCLES", 0) / w5},
+          "bench_line": b5}
+    json.dump(o5, open(os.path.join(dst, "%s_traffic5.json" % tag), "w"), indent=1)
+    L += ["## config 5 land kernel: counters (copied: %s_traffic5.json)" % tag, "",
+          "- %s columns per launch, %.3f ms per launch; HBM traffic %.1f MB = %.2fx algorithmic; %.0f VALU instructions per wave, lane utilisation **%.3f** "
+          "(config 3: %.3f), waiting %.0f %% of wave cycles" % (ncol5, (o5["avg_kernel_ns"] or 0) / 1e6, o5["hbm_bytes_per_launch"] / 1e6,
+                                                            o5["hbm_bytes_per_launch"] / max(o5["algorithmic_bytes_per_launch"] or 1, 1),
+                                                            o5["derived"]["valu_insts_per_column_step"], o5["derived"]["lane_utilisation"],
+                                                            out["derived"]["lane_utilisation"], 100 * o5["derived"]["wait_any_share_of_wave_cycles"]), ""]
 # ---- MMF groundwater kernels (tools/gw_check.py perf, 4608 x 1536 cells)
 gws = glob.glob(os.path.join(src, "gw", "*_kernel_stats.csv"))
 if gws:
