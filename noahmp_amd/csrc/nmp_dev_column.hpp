@@ -132,6 +132,8 @@ NMP_DEV void gather_water_state(const KArgs& k, Col& s, nmp_ij_t ij) {
   s.lfmass = G2(lfmassxy); s.rtmass = G2(rtmassxy); s.stmass = G2(stmassxy); s.wood = G2(woodxy);
   s.stblcp = G2(stblcpxy); s.fastcp = G2(fastcpxy);
   s.smcwtd = G2(smcwtdxy);
+  s.acc_sfcrunoff = G2(sfcrunoff); s.acc_udrunoff = G2(udrunoff); s.acc_acsnow = G2(acsnow); s.acc_acsnom = G2(acsnom);
+  s.acc_rech = G2(rechxy); s.acc_deeprech = G2(deeprechxy);
 }
 
 // Gather -> REDPRM -> NOAHMP_SFLX | NOAHMP_GLACIER -> scatter for one land / glacier column.
@@ -220,7 +222,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   redprm(k.c, s, P, vegtyp, soiltyp);
   soiltyp_w = soiltyp;
   NMP_TIC(1);    // redprm
-  s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.T->lucats) ? vegtyp : 1;
+  s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.ts.lucats) ? vegtyp : 1;
   if (s.err) { failed = s.err; live = false; }                                     // REDPRM fatals, lsm:9266-9344
   if (NMP_TRUNC == 1) s.err = 99;
   }  // cls <= 1
@@ -282,8 +284,8 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   // ---- scatter of everything the water phase (or the glacier tail) produced, drv:728-835
   G2(qfx) = qfx_out; G2(lh) = lh_out;
   G2(smstav) = 0.0f; G2(smstot) = 0.0f;
-  G2(sfcrunoff) = G2(sfcrunoff) + s.runsrf * k.a.dt;
-  G2(udrunoff) = G2(udrunoff) + s.runsub * k.a.dt;
+  G2(sfcrunoff) = s.acc_sfcrunoff + s.runsrf * k.a.dt;
+  G2(udrunoff) = s.acc_udrunoff + s.runsub * k.a.dt;
 #pragma unroll
   for (int l = 1; l <= NSOIL; l++) {
     G3(smois, l - 1, NSOIL) = y.smc[L(l)]; G3(sh2o, l - 1, NSOIL) = y.sh2o[L(l)];
@@ -291,8 +293,8 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   }
   G2(snow) = s.sneqv; G2(snowh) = s.snowh;
   G2(canwat) = s.canliq + s.canice;
-  G2(acsnow) = G2(acsnow) + s.prcp * s.fpice;                                      // no *DT (drv:751)
-  G2(acsnom) = G2(acsnom) + s.qsnbot * k.a.dt + s.ponding + s.ponding1 + s.ponding2;
+  G2(acsnow) = s.acc_acsnow + s.prcp * s.fpice;                                    // no *DT (drv:751)
+  G2(acsnom) = s.acc_acsnom + s.qsnbot * k.a.dt + s.ponding + s.ponding1 + s.ponding2;
   G2(qsfc) = s.qsfc;
   G2(isnowxy) = s.isnow; G2(tvxy) = s.tv; G2(canliqxy) = s.canliq; G2(canicexy) = s.canice;
   G2(fwetxy) = s.fwet; G2(qsnowxy) = s.qsnow;
@@ -310,8 +312,8 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   G2(neexy) = s.nee; G2(gppxy) = s.gpp; G2(nppxy) = s.npp;
   G2(runsfxy) = s.runsrf; G2(runsbxy) = s.runsub; G2(ecanxy) = s.ecan;
   G2(edirxy) = s.edir; G2(etranxy) = s.etran;
-  G2(rechxy) = G2(rechxy) + s.rech * 1.E3f;
-  G2(deeprechxy) = G2(deeprechxy) + s.deeprech;
+  G2(rechxy) = s.acc_rech + s.rech * 1.E3f;
+  G2(deeprechxy) = s.acc_deeprech + s.deeprech;
   G2(smcwtdxy) = s.smcwtd;
   NMP_TIC(15);   // water tail + final scatter
   return 0;

@@ -266,6 +266,21 @@ struct Urc {
   double one_m_ea4;      // 1 / (1 - EXP(-4.)) (SOILWATER's FCR, lsm:7770)
 };
 
+// The scalars of the parameter tables (category indices and counts, the GENPARM values): uniform over the grid, so they travel as
+// kernel arguments (scalar registers).  Read through the table pointer they were VECTOR loads -- the compiler cannot prove that no
+// store of the kernel clobbers them -- and PHENOLOGY's `VEGTYP == ISWATER .OR. VEGTYP == ISBARREN .OR. ...` (lsm:1087) was a chain of
+// dependent memory round trips; REDPRM's range check of the soil / vegetation type (lsm:9266-9279) delayed its whole batch of gathers.
+struct TabScalars {
+  int iswater, isbarren, issnow, eblforest, lucats, slcats;
+  float csoil, zbot, czil, topt, rsmax, slope0;      // CSOIL_DATA, ZBOT_DATA, CZIL_DATA, TOPT_DATA, RSMAX_DATA, SLOPE_DATA(1) (SLOPETYP = 1, drv:525)
+};
+NMP_DEV TabScalars tab_scalars(const noahmp_tables& t) {
+  TabScalars r;
+  r.iswater = t.iswater; r.isbarren = t.isbarren; r.issnow = t.issnow; r.eblforest = t.eblforest; r.lucats = t.lucats; r.slcats = t.slcats;
+  r.csoil = t.csoil_data; r.zbot = t.zbot_data; r.czil = t.czil_data; r.topt = t.topt_data; r.rsmax = t.rsmax_data; r.slope0 = t.slope_data[0];
+  return r;
+}
+
 // launch-uniform context (kernel argument, lands in SGPRs)
 struct Ctx {
   const noahmp_tables* __restrict__ T;
@@ -274,6 +289,7 @@ struct Ctx {
   float dt;
   float zsoil[NL];   // zsoil[L(1..4)], drv:392-395
   int isurban;
+  TabScalars ts;     // host: tab_scalars(the tables passed to noahmp_hip_set_tables)
   Urc u;
 };
 
@@ -305,6 +321,10 @@ struct Col {
   int isnow;
   float snowh, sneqv, zwt, wa, wt, wslake, lfmass, rtmass, stmass, wood, stblcp, fastcp, lai, sai,
         cm, ch, tauss, smcwtd, deeprech, rech;
+  // the six accumulators the final scatter adds to (drv:731-732, 751-752, 833-834): their old values travel with the WATER phase's
+  // inputs (gather_water_state), so that the scatter is stores only -- read there, each one was a dependent memory round trip behind
+  // `s_waitcnt vmcnt(0)` at the very end of the wave (the compiler cannot move a load above earlier stores to other arrays)
+  float acc_sfcrunoff, acc_udrunoff, acc_acsnow, acc_acsnom, acc_rech, acc_deeprech;
   // out
   float fsa, fsr, fira, fsh, ssoil, fcev, fgev, fctr, ecan, etran, edir, trad, tgb, tgv, t2mv, t2mb,
         q2v, q2b, runsrf, runsub, apar, psn, sav, sag, fsno, nee, gpp, npp, fveg, albedo, qsnbot,

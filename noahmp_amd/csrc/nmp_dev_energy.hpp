@@ -430,8 +430,8 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   float zt = nmp_max(1.E-6f, nmp_expf(zilfc * sqrtf(ustar * z0)) * z0);
   float zslu = zlm + zu;
   float zslt = zlm + zt;
-  float rlogu = nmp_logf(zslu / zu);
-  float rlogt = nmp_logf(zslt / zt);
+  float rlogu, rlogt;
+  { const float la[2] = {zslu / zu, zslt / zt}; float lg[2]; nmp_logfN<2>(la, lg); rlogu = lg[0]; rlogt = lg[1]; }   // independent: one batch of look-ups
   float zetalt = nmp_max(zslt * rlmo, ZTMIN);
   rlmo = zetalt / zslt;
   float zetalu = zslu * rlmo;
@@ -441,10 +441,17 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   if (rlmo < 0.f) {
     float xlu = sqrtf(sqrtf(1.f - 16.f * zetalu)), xlt = sqrtf(sqrtf(1.f - 16.f * zetalt)),
           xu = sqrtf(sqrtf(1.f - 16.f * zetau)), xt = sqrtf(sqrtf(1.f - 16.f * zetat));
-    psmz = pspmu(xu);
-    simm = pspmu(xlu) - psmz + rlogu;
-    pshz = psphu(xt);
-    simh = psphu(xlt) - pshz + rlogt;
+    // PSPMU(xu), PSPMU(xlu), PSPHU(xt), PSPHU(xlt) (lsm:4290-4299 statement functions): their six LOGs are independent -- one batch of
+    // table look-ups instead of six dependent LDS round trips per iteration; the arithmetic of pspmu / psphu is unchanged
+    const float la[6] = {(xu + 1.f) * 0.5f, (xu * xu + 1.f) * 0.5f, (xlu + 1.f) * 0.5f, (xlu * xlu + 1.f) * 0.5f,
+                         (xt * xt + 1.f) * 0.5f, (xlt * xlt + 1.f) * 0.5f};
+    float lg[6];
+    nmp_logfN<6>(la, lg);
+    psmz = -2.f * lg[0] - lg[1] + 2.f * nmp_atanf(xu) - (3.14159265f / 2.f);
+    const float pspmu_xlu = -2.f * lg[2] - lg[3] + 2.f * nmp_atanf(xlu) - (3.14159265f / 2.f);
+    simm = pspmu_xlu - psmz + rlogu;
+    pshz = -2.f * lg[4];
+    simh = -2.f * lg[5] - pshz + rlogt;
   } else {
     zetalu = nmp_min(zetalu, ZTMAX);
     zetalt = nmp_min(zetalt, ZTMAX);

@@ -7,9 +7,9 @@
 namespace nmp {
 
 // the soil half of REDPRM (lsm:9282-9300) for soil type st+1 with or without the urban override
-NMP_DEV void redprm_soil(const noahmp_tables* T, int st, bool urban, Parm& P) {
+NMP_DEV void redprm_soil(const noahmp_tables* T, float csoil_data, int st, bool urban, Parm& P) {
   P.st = st; P.u = urban ? 1 : 0;
-  P.csoil = T->csoil_data;
+  P.csoil = csoil_data;
   P.bexp = T->bb[st];
   P.psisat = T->satpsi[st];
   P.quartz = T->qtz[st];
@@ -25,15 +25,15 @@ NMP_DEV float redprm_frzx(const noahmp_tables* T, const Parm& P) { return T->frz
 // REDPRM lsm:9202-9349: table gather into per-thread registers (the reference writes module globals)
 NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   const noahmp_tables* T = c.T;
-  if (soiltyp > T->slcats || soiltyp < 1) { raise(s, NOAHMP_ERR_SOILTYP_RANGE); soiltyp = 1; }
-  if (vegtyp > T->lucats || vegtyp < 1) { raise(s, NOAHMP_ERR_VEGTYP_RANGE); vegtyp = 1; }
+  if (soiltyp > c.ts.slcats || soiltyp < 1) { raise(s, NOAHMP_ERR_SOILTYP_RANGE); soiltyp = 1; }
+  if (vegtyp > c.ts.lucats || vegtyp < 1) { raise(s, NOAHMP_ERR_VEGTYP_RANGE); vegtyp = 1; }
   const int st = soiltyp - 1, vt = vegtyp - 1;
-  redprm_soil(T, st, vegtyp == c.isurban, P);
-  P.zbot = T->zbot_data;
-  P.czil = T->czil_data;
-  P.topt = T->topt_data;
+  redprm_soil(T, c.ts.csoil, st, vegtyp == c.isurban, P);
+  P.zbot = c.ts.zbot;
+  P.czil = c.ts.czil;
+  P.topt = c.ts.topt;
   P.rgl = T->rgltbl[vt];
-  P.rsmax = T->rsmax_data;
+  P.rsmax = c.ts.rsmax;
   P.rsmin = T->rstbl[vt];
   P.hs = T->hstbl[vt];
   P.nroot = T->nrotbl[vt];
@@ -64,12 +64,12 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
 NMP_DEV void redprm_water(const Ctx& c, Parm& P, int soiltyp, int vegtyp) {
   const noahmp_tables* T = c.T;
   P.ch2op = T->ch2op[vegtyp - 1];
-  if (soiltyp > T->slcats || soiltyp < 1) soiltyp = 1;
+  if (soiltyp > c.ts.slcats || soiltyp < 1) soiltyp = 1;
   const int st = soiltyp - 1;
   P.dksat = T->satdk[st];
   P.dwsat = T->satdw[st];
   P.kdt = c.D->kdt[st];                               // = redprm_kdt(T, DKSAT), evaluated per soil type by derive_tables
-  P.slope = T->slope_data[0];                         // SLOPETYP = 1 (drv:525)
+  P.slope = c.ts.slope0;                              // SLOPE_DATA(SLOPETYP = 1) (drv:525)
   P.frzx = c.D->frzx[P.u][st];                        // = redprm_frzx(T, P)
 }
 
@@ -83,7 +83,7 @@ inline void derive_tables(const noahmp_tables& T, Derived& D) {
   for (int st = 0; st < nst; st++) {
     for (int u = 0; u < 2; u++) {
       Parm P = {};
-      redprm_soil(&T, st, u == 1, P);
+      redprm_soil(&T, T.csoil_data, st, u == 1, P);
       D.thks_pow[u][st] = tdfcnd_thks_pow(P);
       D.thkdry[u][st] = tdfcnd_thkdry(P);
       D.d_rsurf[u][st] = rsurf_dry_layer(P);
@@ -106,7 +106,7 @@ NMP_DEV void phenology(const Ctx& c, const Parm& P, Col& s) {
   }
   if (s.sai < 0.01f) s.sai = 0.0f;
   if (s.lai < 0.05f || s.sai == 0.0f) s.lai = 0.0f;
-  if ((s.vegtyp == T->iswater) || (s.vegtyp == T->isbarren) || (s.vegtyp == T->issnow) ||
+  if ((s.vegtyp == c.ts.iswater) || (s.vegtyp == c.ts.isbarren) || (s.vegtyp == c.ts.issnow) ||
       (s.vegtyp == c.isurban)) {
     s.lai = 0.f; s.sai = 0.f;
   }
@@ -132,7 +132,7 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y);
 template <class A>
 NMP_DEV void carbon(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   const noahmp_tables* T = c.T;
-  const bool novegc = (s.vegtyp == T->iswater) || (s.vegtyp == T->isbarren) || (s.vegtyp == T->issnow) ||
+  const bool novegc = (s.vegtyp == c.ts.iswater) || (s.vegtyp == c.ts.isbarren) || (s.vegtyp == c.ts.issnow) ||
                       (s.vegtyp == c.isurban);
   if (novegc) {                                       // lsm:8792-8810
     s.lai = 0.f; s.sai = 0.f; s.gpp = 0.f; s.npp = 0.f; s.nee = 0.f;
@@ -169,7 +169,7 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float rswood = rswoodc * nmp_expf(0.08f * (tv - 298.16f)) * s.wood * T->wdpool[v];
   float carbfx = s.psn * 12.e-6f;
   float leafpt = nmp_expf(0.01f * (1.f - nmp_expf(0.75f * s.lai)) * s.lai);
-  if (s.vegtyp == T->eblforest) leafpt = nmp_expf(0.01f * (1.f - nmp_expf(0.50f * s.lai)) * s.lai);
+  if (s.vegtyp == c.ts.eblforest) leafpt = nmp_expf(0.01f * (1.f - nmp_expf(0.50f * s.lai)) * s.lai);
   float nonlef = 1.0f - leafpt;
   float stempt = s.lai / 10.0f;
   leafpt = leafpt - stempt;
@@ -270,7 +270,7 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
     raise(s, NOAHMP_ERR_DVEG_UNKNOWN);
     s.fveg = 0.01f;
   }
-  if (s.vegtyp == c.isurban || s.vegtyp == T->isbarren) s.fveg = 0.0f;
+  if (s.vegtyp == c.isurban || s.vegtyp == c.ts.isbarren) s.fveg = 0.0f;
   if (s.elai + s.esai == 0.0f) s.fveg = 0.0f;
   NMP_TRUNC_AT(2);
   }  // live

@@ -135,11 +135,12 @@ class Comm:
         idx = (C.c_int32 * 8)(*[geo[k] for k in ("ims", "ime", "jms", "jme", "its", "ite", "jts", "jte")])
         if device:
             import torch
-            t = torch.from_numpy(f).to(torch.device("cuda", self.device_index))
-            ptrs = (C.c_void_p * 1)(t.data_ptr())
-            rc = lib.noahmp_hip_exchange_halo(1, ptrs, idx, abi.MEM_DEVICE, torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            f = t.cpu().numpy()
+            with torch.cuda.device(self.device_index):        # (a helper thread starts with device 0 as its current device)
+                t = torch.from_numpy(f).to(torch.device("cuda", self.device_index))
+                ptrs = (C.c_void_p * 1)(t.data_ptr())
+                rc = lib.noahmp_hip_exchange_halo(1, ptrs, idx, abi.MEM_DEVICE, torch.cuda.current_stream(self.device_index).cuda_stream)
+                torch.cuda.synchronize(self.device_index)
+                f = t.cpu().numpy()
         else:
             ptrs = (C.c_void_p * 1)(f.ctypes.data)
             rc = lib.noahmp_hip_exchange_halo(1, ptrs, idx, abi.MEM_HOST, None)

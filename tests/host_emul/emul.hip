@@ -36,6 +36,7 @@ extern "C" int emul_step(const noahmp_step_args* a, noahmp_status* st) {
               a->iopt_rad, a->iopt_alb, a->iopt_snf, a->iopt_tbot, a->iopt_stc};
   k.c.dt = a->dt;
   k.c.isurban = a->isurban;
+  k.c.ts = tab_scalars(g_t);
   k.c.zsoil[L(1)] = -a->dzs[0];
   for (int l = 2; l <= NOAHMP_NSOIL; l++) k.c.zsoil[L(l)] = -a->dzs[l - 1] + k.c.zsoil[L(l - 1)];
   ctx_fill_uniform(k.c);

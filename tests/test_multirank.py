@@ -278,12 +278,15 @@ def test_config4_ranks_cut_one_global_grid(world, port, tables):
             assert np.array_equal(want, v, equal_nan=True), "%s tile its=%d jts=%d" % (k, geo["its"], geo["jts"])
 
 
-def _run_bench(extra, tmp, tag):
+def _run_bench(extra, tmp, tag, backend="gloo"):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NMP_DIST_BACKEND="gloo")          # two ranks on ONE GPU: host-staged ring exchange
+    env = dict(os.environ)
+    env.pop("NMP_DIST_BACKEND", None)
+    if backend:
+        env["NMP_DIST_BACKEND"] = backend                    # "gloo": several ranks on ONE GPU, host-staged ring exchange
     env.pop("WORLD_SIZE", None)
     dump = os.path.join(tmp, tag)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ni", "96", "--nj", "130", "--steps", "5", "--warmup", "2",
@@ -327,6 +330,28 @@ def test_bench_two_ranks_equal_one_rank(workload, tmp_path, monkeypatch):
             assert np.array_equal(want, part[k], equal_nan=True), "%s rank %d" % (k, r)
         seen += (ite - its + 1) * (jte - jts + 1)
     assert seen == 96 * 130
+
+
+@pytest.mark.gpu
+def test_bench_ranks_agree_when_rccl_refuses(tmp_path, tmp_path_factory):
+    """`bench.py --gpus 2` with the default backend (nccl = RCCL) on a box whose ranks share one GPU: RCCL refuses a communicator
+    with a duplicate device on every rank; the ranks learn of it over the gloo control plane, switch TOGETHER to host-staged edges
+    and the run completes, says so (`distributed.note`) and still equals the single-rank run bit for bit.  (On a box with two GPUs the
+    same command brings RCCL up and moves the ring with the engine's RCCL mover or torch's send/recv -- then that is what is checked.)"""
+    whole = _one_rank_dump("config4", tmp_path_factory)
+    res, dn = _run_bench(["--gpus", "2", "--workload", "config4"], str(tmp_path), "nccl2", backend=None)
+    d = res["distributed"]
+    assert d["halo_requested"] == "auto" and d["backend"] in ("gloo", "nccl")
+    if d["backend"] == "gloo":
+        assert "initialisation failed" in d["note"] and d["halo"] == "torch"
+    else:
+        assert d["halo"] in ("rccl", "torch")
+    for r in range(2):
+        part = np.load(dn + ".rank%d.npz" % r)
+        its, ite, jts, jte = part["geom"]
+        for k in part.files:
+            if k != "geom":
+                assert np.array_equal(whole[k][jts - 1:jte, ..., its - 1:ite], part[k], equal_nan=True), "%s rank %d" % (k, r)
 
 
 _ONE_RANK = {}
