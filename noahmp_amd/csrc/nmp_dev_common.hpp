@@ -273,11 +273,32 @@ struct Urc {
 struct TabScalars {
   int iswater, isbarren, issnow, eblforest, lucats, slcats;
   float csoil, zbot, czil, topt, rsmax, slope0;      // CSOIL_DATA, ZBOT_DATA, CZIL_DATA, TOPT_DATA, RSMAX_DATA, SLOPE_DATA(1) (SLOPETYP = 1, drv:525)
+  // NOAHMP_RAD_PARAMETERS (lsm:409-447) as the land path reads them: soil colour class ISC = 4 and surface type IST = 1 are fixed by the
+  // driver (drv:526-527), so ALBSAT / ALBDRY(ISC, band) and EG(IST) are grid-uniform too
+  float albsat4[2], albdry4[2], omegas[2], betads, betais, eg1;
 };
+constexpr int NMP_TS_INTS = 6, NMP_TS_FLOATS = 15;    // members of TabScalars as the type-free LaunchDesc carries them (nmp_engine_host.hpp)
 NMP_DEV TabScalars tab_scalars(const noahmp_tables& t) {
   TabScalars r;
   r.iswater = t.iswater; r.isbarren = t.isbarren; r.issnow = t.issnow; r.eblforest = t.eblforest; r.lucats = t.lucats; r.slcats = t.slcats;
   r.csoil = t.csoil_data; r.zbot = t.zbot_data; r.czil = t.czil_data; r.topt = t.topt_data; r.rsmax = t.rsmax_data; r.slope0 = t.slope_data[0];
+  for (int ib = 0; ib < 2; ib++) { r.albsat4[ib] = t.albsat[ib][3]; r.albdry4[ib] = t.albdry[ib][3]; r.omegas[ib] = t.omegas[ib]; }
+  r.betads = t.betads; r.betais = t.betais; r.eg1 = t.eg[0];
+  return r;
+}
+// TabScalars <-> the two plain arrays of LaunchDesc / Engine (host)
+NMP_DEV void tab_scalars_pack(const TabScalars& r, int* i, float* f) {
+  i[0] = r.iswater; i[1] = r.isbarren; i[2] = r.issnow; i[3] = r.eblforest; i[4] = r.lucats; i[5] = r.slcats;
+  f[0] = r.csoil; f[1] = r.zbot; f[2] = r.czil; f[3] = r.topt; f[4] = r.rsmax; f[5] = r.slope0;
+  f[6] = r.albsat4[0]; f[7] = r.albsat4[1]; f[8] = r.albdry4[0]; f[9] = r.albdry4[1]; f[10] = r.omegas[0]; f[11] = r.omegas[1];
+  f[12] = r.betads; f[13] = r.betais; f[14] = r.eg1;
+}
+NMP_DEV TabScalars tab_scalars_unpack(const int* i, const float* f) {
+  TabScalars r;
+  r.iswater = i[0]; r.isbarren = i[1]; r.issnow = i[2]; r.eblforest = i[3]; r.lucats = i[4]; r.slcats = i[5];
+  r.csoil = f[0]; r.zbot = f[1]; r.czil = f[2]; r.topt = f[3]; r.rsmax = f[4]; r.slope0 = f[5];
+  r.albsat4[0] = f[6]; r.albsat4[1] = f[7]; r.albdry4[0] = f[8]; r.albdry4[1] = f[9]; r.omegas[0] = f[10]; r.omegas[1] = f[11];
+  r.betads = f[12]; r.betais = f[13]; r.eg1 = f[14];
   return r;
 }
 
@@ -292,6 +313,33 @@ struct Ctx {
   TabScalars ts;     // host: tab_scalars(the tables passed to noahmp_hip_set_tables)
   Urc u;
 };
+
+// Element k (0..NSOIL: a root depth) of a grid-uniform array that lives in the kernel arguments, for a k that differs per lane: a chain of
+// selects on scalar operands.  Indexed directly, such an array is read by a vector load from the kernel-argument segment -- a dependent
+// memory round trip (~500 cycles exposed) for a word the scalar unit already holds.
+// uniform_value(x): x itself for a value that is uniform over the wavefront, as a VALUE the optimiser cannot trace back to its address
+// (v_readfirstlane): keeps select(load a, load b) from becoming load(select(&a, &b))
+#if defined(__HIP_DEVICE_COMPILE__)
+NMP_DEV float uniform_value(float x) { int i; memcpy(&i, &x, 4); i = __builtin_amdgcn_readfirstlane(i); memcpy(&x, &i, 4); return x; }
+NMP_DEV double uniform_value(double x) {
+  int i[2]; memcpy(i, &x, 8);
+  i[0] = __builtin_amdgcn_readfirstlane(i[0]); i[1] = __builtin_amdgcn_readfirstlane(i[1]);
+  memcpy(&x, i, 8); return x;
+}
+#else
+NMP_DEV float uniform_value(float x) { return x; }
+NMP_DEV double uniform_value(double x) { return x; }
+#endif
+template <class T> NMP_DEV T pick_layer(const T* a, int k) {
+  const T a0 = uniform_value(a[L(0)]), a1 = uniform_value(a[L(1)]), a2 = uniform_value(a[L(2)]), a3 = uniform_value(a[L(3)]),
+          a4 = uniform_value(a[L(4)]);
+  T r = a0;
+  r = (k == 1) ? a1 : r;
+  r = (k == 2) ? a2 : r;
+  r = (k == 3) ? a3 : r;
+  r = (k >= 4) ? a4 : r;
+  return r;
+}
 
 // soil-layer thickness as SOILWATER sees it (DZSNSO(1..4) after SNOWWATER rebuilt the layer geometry, lsm:6978-6994): uniform
 NMP_DEV float dz_soil(const Ctx& c, int k) { return k == 1 ? -c.zsoil[L(1)] : (c.zsoil[L(k - 1)] - c.zsoil[L(k)]); }

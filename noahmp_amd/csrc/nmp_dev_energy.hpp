@@ -168,8 +168,8 @@ NMP_DEV TwoStreamOut twostream(const Ctx& c, const Parm& P, int ic, int v, float
     tmp0 = omegal; tmp1 = betadl; tmp2 = betail;
   } else {
     tmp0 = (1.f - fwet) * omegal + fwet * omegas;
-    tmp1 = ((1.f - fwet) * omegal * betadl + fwet * omegas * T->betads) / tmp0;
-    tmp2 = ((1.f - fwet) * omegal * betail + fwet * omegas * T->betais) / tmp0;
+    tmp1 = ((1.f - fwet) * omegal * betadl + fwet * omegas * c.ts.betads) / tmp0;
+    tmp2 = ((1.f - fwet) * omegal * betail + fwet * omegas * c.ts.betais) / tmp0;
   }
   float omega = tmp0, betad = tmp1, betai = tmp2;
   float b = 1.f - omega + omega * betai;
@@ -274,7 +274,7 @@ NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1, const 
 #pragma unroll
     for (int ib = 0; ib < 2; ib++) {                    // GROUNDALB lsm:2703-2765 (IST=1 branch)
       float inc = nmp_max(0.11f - 0.40f * smc1, 0.f);
-      float albsod = nmp_min(T->albsat[ib][s.isc - 1] + inc, T->albdry[ib][s.isc - 1]);
+      float albsod = nmp_min(c.ts.albsat4[ib] + inc, c.ts.albdry4[ib]);          // ALBSAT / ALBDRY(ISC = 4, ib): drv:526 fixes ISC
       float albsoi = albsod;
       if (s.isc == 9) { albsod += 0.10f; albsoi += 0.10f; }
       albgrd[ib] = albsod * (1.f - s.fsno) + albsnd[ib] * s.fsno;
@@ -288,7 +288,7 @@ NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1, const 
 #pragma unroll
       for (int ic = 0; ic < 2; ic++) {
         TwoStreamOut o = twostream(c, P, ic, v, s.cosz, vai, s.fwet, s.tv, albgrd[ib], albgri[ib],
-                                   rho[ib], tau[ib], T->omegas[ib], s.fveg, gdir, s.bgap, s.wgap);
+                                   rho[ib], tau[ib], c.ts.omegas[ib], s.fveg, gdir, s.bgap, s.wgap);
         if (ic == 0) { fabd[ib] = o.fab; albd[ib] = o.fre; ftdd[ib] = o.ftd; ftid[ib] = o.fti;
                        frevd[ib] = o.frev; fregd[ib] = o.freg; }
         else { fabi[ib] = o.fab; albi[ib] = o.fre; ftii[ib] = o.fti; frevi[ib] = o.frev;
@@ -1225,11 +1225,11 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   NMP_TIC(4);    // radiation
   q.laisun = r.laisun; q.laisha = r.laisha; q.parsun = r.parsun; q.parsha = r.parsha;
   q.emv = 1.f - nmp_expf(-(s.elai + s.esai) / 1.0f);
-  q.emg = T->eg[s.ist - 1] * (1.f - s.fsno) + 1.0f * s.fsno;    // ICE is 0 on this path (drv:549)
+  q.emg = c.ts.eg1 * (1.f - s.fsno) + 1.0f * s.fsno;            // EG(IST = 1) (drv:527); ICE is 0 on this path (drv:549)
   // BTRAN lsm:1617-1640
   s.btran = 0.f;
-  const float zroot = -c.zsoil[L(P.nroot)];
-  const double r_zroot = c.u.zs[L(P.nroot)], r_smcmax = rc64(P.smcmax);
+  const float zroot = -pick_layer(c.zsoil, P.nroot);
+  const double r_zroot = pick_layer(c.u.zs, P.nroot), r_smcmax = rc64(P.smcmax);
   const double r_refwlt = (c.O.btr == 1) ? rc64(P.smcref - P.smcwlt) : 0.0;
 #pragma unroll
   for (int iz = 1; iz <= NSOIL; iz++) {

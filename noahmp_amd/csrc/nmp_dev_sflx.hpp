@@ -28,35 +28,42 @@ NMP_DEV void redprm(const Ctx& c, Col& s, Parm& P, int vegtyp, int soiltyp) {
   if (soiltyp > c.ts.slcats || soiltyp < 1) { raise(s, NOAHMP_ERR_SOILTYP_RANGE); soiltyp = 1; }
   if (vegtyp > c.ts.lucats || vegtyp < 1) { raise(s, NOAHMP_ERR_VEGTYP_RANGE); vegtyp = 1; }
   const int st = soiltyp - 1, vt = vegtyp - 1;
-  redprm_soil(T, c.ts.csoil, st, vegtyp == c.isurban, P);
-  P.zbot = c.ts.zbot;
-  P.czil = c.ts.czil;
-  P.topt = c.ts.topt;
-  P.rgl = T->rgltbl[vt];
-  P.rsmax = c.ts.rsmax;
-  P.rsmin = T->rstbl[vt];
-  P.hs = T->hstbl[vt];
-  P.nroot = T->nrotbl[vt];
-  if (vegtyp == c.isurban) P.rsmin = 400.0f;
-  const Derived* D = c.D;                                   // same batch of gathers as the table rows above
-  P.thks_pow = D->thks_pow[P.u][st]; P.thkdry = D->thkdry[P.u][st]; P.d_rsurf = D->d_rsurf[P.u][st];
-  P.chil = D->chil[vt]; P.phi1 = D->phi1[vt]; P.phi2 = D->phi2[vt]; P.avmu = D->avmu[vt];
-  {                                                         // PHENOLOGY's month interpolation (lsm:1054-1071): its table rows join the batch
+  // PHENOLOGY's month interpolation (lsm:1054-1071) first: its indices need no table, and the rows they select then join the ONE batch
+  // of gathers below (evaluated between the gathers, the division and the FMOD split the batch into dependent memory round trips)
+  int it1, it2;
+  {
     float day;
     if (s.lat >= 0.f) day = s.julian;
     else day = fmodf(s.julian + (0.5f * s.yearlen), (float)s.yearlen);
     float t = 12.f * day / (float)s.yearlen;
-    int it1 = (int)(t + 0.5f);                              // REAL -> INTEGER truncation (lsm:1063)
-    int it2 = it1 + 1;
+    it1 = (int)(t + 0.5f);                                  // REAL -> INTEGER truncation (lsm:1063)
+    it2 = it1 + 1;
     P.ph_wt1 = (it1 + 0.5f) - t;
     if (it1 < 1) it1 = 12;
     if (it2 > 12) it2 = 1;
-    P.lai1 = T->laim[it1 - 1][vt]; P.lai2 = T->laim[it2 - 1][vt];
-    P.sai1 = T->saim[it1 - 1][vt]; P.sai2 = T->saim[it2 - 1][vt];
   }
+  // ---- the gathers: table rows of the vegetation / soil type, per-type derived constants, the two months' LAI / SAI
+  redprm_soil(T, c.ts.csoil, st, vegtyp == c.isurban, P);
+  float rsmin = T->rstbl[vt];
+  P.rgl = T->rgltbl[vt];
+  P.hs = T->hstbl[vt];
+  int nroot = T->nrotbl[vt];
+  const Derived* D = c.D;
+  P.thks_pow = D->thks_pow[P.u][st]; P.thkdry = D->thkdry[P.u][st]; P.d_rsurf = D->d_rsurf[P.u][st];
+  P.chil = D->chil[vt]; P.phi1 = D->phi1[vt]; P.phi2 = D->phi2[vt]; P.avmu = D->avmu[vt];
+  P.lai1 = T->laim[it1 - 1][vt]; P.lai2 = T->laim[it2 - 1][vt];
+  P.sai1 = T->saim[it1 - 1][vt]; P.sai2 = T->saim[it2 - 1][vt];
   P.hvt = T->hvt[vt]; P.hvb = T->hvb[vt]; P.tmin = T->tmin[vt];
   P.z0mvt = T->z0mvt[vt]; P.cwpvt = T->cwpvt[vt]; P.dleaf = T->dleaf[vt];
-  if (P.nroot > NSOIL) { raise(s, NOAHMP_ERR_NROOT_GT_NSOIL); P.nroot = NSOIL; }
+  // ---- what depends on gathered values comes last
+  P.zbot = c.ts.zbot;
+  P.czil = c.ts.czil;
+  P.topt = c.ts.topt;
+  P.rsmax = c.ts.rsmax;
+  if (vegtyp == c.isurban) rsmin = 400.0f;
+  P.rsmin = rsmin;
+  if (nroot > NSOIL) { raise(s, NOAHMP_ERR_NROOT_GT_NSOIL); nroot = NSOIL; }
+  P.nroot = nroot;
 }
 
 // The REDPRM outputs only the WATER phase reads (DKSAT, DWSAT, KDT, SLOPE, FRZX; lsm:9286-9287, 9316-9322): looked up when
@@ -150,7 +157,7 @@ NMP_DEV void carbon_veg(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y) {
   float lapm = T->sla[v] / 1000.f;
   float wstres = 1.f - s.btran;
   float wroot = 0.f;
-  const float zroot = -c.zsoil[L(P.nroot)];
+  const float zroot = -pick_layer(c.zsoil, P.nroot);
 #pragma unroll
   for (int j = 1; j <= NSOIL; j++)
     if (j <= P.nroot) wroot = wroot + y.smc[L(j)] / P.smcmax * y.dzsnso[L(j)] / zroot;

@@ -20,7 +20,7 @@ struct Engine {
   int device = -1;
   bool have_tables = false;
   noahmp_tables* d_tables = nullptr;
-  int ts_i[6] = {0, 0, 0, 0, 0, 0}; float ts_f[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // scalars of the tables last passed to noahmp_hip_set_tables
+  int ts_i[6] = {0, 0, 0, 0, 0, 0}; float ts_f[15] = {};   // scalars of the tables last passed to noahmp_hip_set_tables
   unsigned long long* d_err = nullptr;
   int* d_counts = nullptr;
   int* d_gw_counts = nullptr;            // tallies of asynchronous groundwater calls (not reported)
@@ -90,7 +90,7 @@ extern Engine g;
 struct LaunchDesc {
   noahmp_step_args a;            // array members = device pointers
   const noahmp_tables* tables;
-  int ts_i[6]; float ts_f[6];    // the tables' scalars (TabScalars of the physics headers, member by member)
+  int ts_i[6]; float ts_f[15];   // the tables' scalars (TabScalars of the physics headers: tab_scalars_pack / _unpack)
   float dt, zsoil[8];
   int isurban, ni, nka, nti, ntj, k1, kp_lo, kp_hi, yearlen;
   unsigned long long* err;

@@ -141,12 +141,7 @@ int noahmp_hip_set_tables(const noahmp_tables* t) {
   nmp::derive_tables(img.t, img.d);
   if (!g.d_tables) HIPCHK(hipMalloc((void**)&g.d_tables, sizeof(nmp::TablesDev)));
   HIPCHK(hipMemcpy(g.d_tables, &img, sizeof(nmp::TablesDev), hipMemcpyHostToDevice));
-  {                                          // the tables' scalars travel as kernel arguments (Ctx::ts)
-    const nmp::TabScalars ts = nmp::tab_scalars(img.t);
-    const int i6[6] = {ts.iswater, ts.isbarren, ts.issnow, ts.eblforest, ts.lucats, ts.slcats};
-    const float f6[6] = {ts.csoil, ts.zbot, ts.czil, ts.topt, ts.rsmax, ts.slope0};
-    for (int n = 0; n < 6; n++) { g.ts_i[n] = i6[n]; g.ts_f[n] = f6[n]; }
-  }
+  nmp::tab_scalars_pack(nmp::tab_scalars(img.t), g.ts_i, g.ts_f);      // the tables' scalars travel as kernel arguments (Ctx::ts)
   g.have_tables = true;
   return 0;
 }
@@ -234,7 +229,7 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
               a->iopt_rad, a->iopt_alb, a->iopt_snf, a->iopt_tbot, a->iopt_stc};
   k.c.dt = a->dt;
   k.c.isurban = a->isurban;
-  k.c.ts = TabScalars{g.ts_i[0], g.ts_i[1], g.ts_i[2], g.ts_i[3], g.ts_i[4], g.ts_i[5], g.ts_f[0], g.ts_f[1], g.ts_f[2], g.ts_f[3], g.ts_f[4], g.ts_f[5]};
+  k.c.ts = tab_scalars_unpack(g.ts_i, g.ts_f);
   k.c.zsoil[L(1)] = -a->dzs[0];                                                    // drv:392-395
   for (int l = 2; l <= NOAHMP_NSOIL; l++) k.c.zsoil[L(l)] = -a->dzs[l - 1] + k.c.zsoil[L(l - 1)];
   ctx_fill_uniform(k.c);
@@ -274,7 +269,8 @@ static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
   nmp_host::LaunchDesc d;
   memset(&d, 0, sizeof(d));
   d.a = k.a; d.tables = k.c.T; d.dt = k.c.dt; d.isurban = k.c.isurban;
-  for (int n = 0; n < 6; n++) { d.ts_i[n] = g.ts_i[n]; d.ts_f[n] = g.ts_f[n]; }
+  for (int n = 0; n < 6; n++) d.ts_i[n] = g.ts_i[n];
+  for (int n = 0; n < 15; n++) d.ts_f[n] = g.ts_f[n];
   for (int l = 0; l < NL; l++) d.zsoil[l] = k.c.zsoil[l];
   d.ni = k.ni; d.nka = k.nka; d.nti = k.nti; d.ntj = k.ntj; d.k1 = k.k1; d.kp_lo = k.kp_lo; d.kp_hi = k.kp_hi; d.yearlen = k.yearlen;
   d.err = k.err; d.counts = k.counts; d.err_base = k.err_base; d.t_offset = k.t_offset; d.t_first = k.t_first; d.t_count = k.t_count;
