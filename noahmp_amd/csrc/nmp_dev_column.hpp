@@ -185,11 +185,14 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
     y.stc[L(l)] = G3(tslb, l - 1, NSOIL); y.smceq[L(l)] = G3(smoiseq, l - 1, NSOIL);
     y.sice[L(l)] = 0.f; y.btrani[L(l)] = 0.f;
   }
+  // Every load of the gather is issued before the first branch: FICEOLD's division (drv:516-518) is conditional per layer, and a branch
+  // between the layers' loads turned the gather into five dependent memory round trips (38 loads | layer -2 | layer -1 | layer 0 | the
+  // rest) -- the loads of a later block cannot be issued before the branch of an earlier one is resolved.  It is evaluated below.
+  float snice_in[3], snliq_in[3];
 #pragma unroll
   for (int l = -2; l <= 0; l++) {
-    float si = G3(snicexy, l + 2, 3), sl = G3(snliqxy, l + 2, 3);
-    y.stc[L(l)] = G3(tsnoxy, l + 2, 3); y.snice[L(l)] = si; y.snliq[L(l)] = sl;
-    y.ficeold[L(l)] = (l > s.isnow) ? si / (si + sl) : 0.f;                        // drv:516-518
+    snice_in[l + 2] = G3(snicexy, l + 2, 3); snliq_in[l + 2] = G3(snliqxy, l + 2, 3);
+    y.stc[L(l)] = G3(tsnoxy, l + 2, 3); y.snice[L(l)] = snice_in[l + 2]; y.snliq[L(l)] = snliq_in[l + 2];
   }
 #pragma unroll
   for (int l = -2; l <= NSOIL; l++) {
@@ -204,6 +207,9 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   // WSLAKE, ZWT, WT, SMCWTD and the carbon pools are first read by the WATER / CARBON phase: they are gathered there
   // (gather_water_state), not here, so that they do not occupy registers (or scratch) through the ENERGY phase
   s.rech = 0.f; s.deeprech = 0.f;
+#pragma unroll
+  for (int l = -2; l <= 0; l++)                                                    // drv:516-518 (after the last load of the gather)
+    y.ficeold[L(l)] = (l > s.isnow) ? snice_in[l + 2] / (snice_in[l + 2] + snliq_in[l + 2]) : 0.f;
   s.co2air = 395.e-06f * s.sfcprs;
   s.o2air = 0.209f * s.sfcprs;
   s.foln = 1.0f;
