@@ -164,55 +164,46 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   int c_ivg = 0;
   if (EARLY) { c_xland = G2(xland); c_xice = G2(xice); c_ivg = G2(ivgtyp); }
   if (EARLY || cls <= 1) {
-  // ---- gather, drv:449-545
-  s.cosz = G2(coszin); s.lat = G2(xlatin);
-  s.zlvl = 0.5f * G3(dz8w, k.k1, k.nka);
-  int vegtyp = G2(ivgtyp), soiltyp = G2(isltyp);
-  s.shdfac = div_rc(G2(vegfra), NMP_RCC(100.f));
-  s.shdmax = div_rc(G2(vegmax), NMP_RCC(100.f));
+  // ---- gather, drv:449-545.  Three parts, in this order, so that the wave pays ONE round trip to HBM and REDPRM's table gathers travel
+  // under it: (A) every load of the column's 87 words, nothing else (a branch or a store to LDS between two loads splits the batch: the
+  // loads behind it are not issued before the values in front of it have arrived); (B) classification, the type remaps and REDPRM, which
+  // need only the first words (vegetation / soil type, XLAND, XICE, latitude); (C) conversions and the layer arrays' way into LDS.
+  // (A)
+  int vegtyp = EARLY ? c_ivg : G2(ivgtyp), soiltyp = G2(isltyp);
+  const float xice_in = EARLY ? c_xice : G2(xice);
+  s.lat = G2(xlatin);
+  s.cosz = G2(coszin);
+  const float dz8w_in = G3(dz8w, k.k1, k.nka), vegfra_in = G2(vegfra), vegmax_in = G2(vegmax);
   s.tbot = G2(tmn);
   s.sfctmp = G3(t3d, k.k1, k.nka);
-  { float qv = G3(qv3d, k.k1, k.nka); s.q2 = qv / (1.0f + qv); }
+  const float qv_in = G3(qv3d, k.k1, k.nka);
   s.uu = G3(u_phy, k.k1, k.nka); s.vv = G3(v_phy, k.k1, k.nka);
   s.soldn = G2(swdown); s.lwdn = G2(glw);
-  s.sfcprs = (G3(p8w3d, k.kp_hi, k.nka) + G3(p8w3d, k.kp_lo, k.nka)) * 0.5f;
+  const float p8w_hi = G3(p8w3d, k.kp_hi, k.nka), p8w_lo = G3(p8w3d, k.kp_lo, k.nka);
   s.psfc = G3(p8w3d, k.k1, k.nka);
-  s.prcp = div_rc(G2(rainbl), k.c.u.dt);
+  const float rainbl_in = G2(rainbl);
   s.isnow = G2(isnowxy);
+  float smc_in[NSOIL], sh2o_in[NSOIL], tslb_in[NSOIL], smceq_in[NSOIL], tsno_in[3], snice_in[3], snliq_in[3], zsnso_in[NL];
 #pragma unroll
   for (int l = 1; l <= NSOIL; l++) {
-    y.smc[L(l)] = G3(smois, l - 1, NSOIL); y.sh2o[L(l)] = G3(sh2o, l - 1, NSOIL);
-    y.stc[L(l)] = G3(tslb, l - 1, NSOIL); y.smceq[L(l)] = G3(smoiseq, l - 1, NSOIL);
-    y.sice[L(l)] = 0.f; y.btrani[L(l)] = 0.f;
+    smc_in[l - 1] = G3(smois, l - 1, NSOIL); sh2o_in[l - 1] = G3(sh2o, l - 1, NSOIL);
+    tslb_in[l - 1] = G3(tslb, l - 1, NSOIL); smceq_in[l - 1] = G3(smoiseq, l - 1, NSOIL);
   }
-  // Every load of the gather is issued before the first branch: FICEOLD's division (drv:516-518) is conditional per layer, and a branch
-  // between the layers' loads turned the gather into five dependent memory round trips (38 loads | layer -2 | layer -1 | layer 0 | the
-  // rest) -- the loads of a later block cannot be issued before the branch of an earlier one is resolved.  It is evaluated below.
-  float snice_in[3], snliq_in[3];
 #pragma unroll
   for (int l = -2; l <= 0; l++) {
-    snice_in[l + 2] = G3(snicexy, l + 2, 3); snliq_in[l + 2] = G3(snliqxy, l + 2, 3);
-    y.stc[L(l)] = G3(tsnoxy, l + 2, 3); y.snice[L(l)] = snice_in[l + 2]; y.snliq[L(l)] = snliq_in[l + 2];
+    snice_in[l + 2] = G3(snicexy, l + 2, 3); snliq_in[l + 2] = G3(snliqxy, l + 2, 3); tsno_in[l + 2] = G3(tsnoxy, l + 2, 3);
   }
 #pragma unroll
-  for (int l = -2; l <= NSOIL; l++) {
-    y.zsnso[L(l)] = G3(zsnsoxy, l + 2, NSOIL + 3); y.dzsnso[L(l)] = 0.f; y.imelt[L(l)] = 0.f;
-  }
+  for (int l = -2; l <= NSOIL; l++) zsnso_in[L(l)] = G3(zsnsoxy, l + 2, NSOIL + 3);
   s.sneqv = G2(snow); s.snowh = G2(snowh); s.qsfc = G2(qsfc);
   s.tv = G2(tvxy); s.tg = G2(tgxy); s.canliq = G2(canliqxy); s.canice = G2(canicexy);
   s.eah = G2(eahxy); s.tah = G2(tahxy); s.cm = G2(cmxy); s.ch = G2(chxy); s.fwet = G2(fwetxy);
   s.sneqvo = G2(sneqvoxy); s.albold = G2(alboldxy); s.qsnow = G2(qsnowxy);
   s.lai = G2(xlaixy); s.sai = G2(xsaixy);
   s.tauss = G2(taussxy); s.wa = G2(waxy);                  // WA enters the water balance taken at the start (lsm:703)
-  // WSLAKE, ZWT, WT, SMCWTD and the carbon pools are first read by the WATER / CARBON phase: they are gathered there
-  // (gather_water_state), not here, so that they do not occupy registers (or scratch) through the ENERGY phase
-  s.rech = 0.f; s.deeprech = 0.f;
-#pragma unroll
-  for (int l = -2; l <= 0; l++)                                                    // drv:516-518 (after the last load of the gather)
-    y.ficeold[L(l)] = (l > s.isnow) ? snice_in[l + 2] / (snice_in[l + 2] + snliq_in[l + 2]) : 0.f;
-  s.co2air = 395.e-06f * s.sfcprs;
-  s.o2air = 0.209f * s.sfcprs;
-  s.foln = 1.0f;
+  // WSLAKE, ZWT, WT, SMCWTD, the carbon pools and the accumulators are first read by the WATER / CARBON phase: they are gathered there
+  // (gather_water_state), not here, so that they do not occupy registers through the ENERGY phase
+  // (B)
   if (EARLY) {                                   // everything above was loads: now the class
     cls = column_classify_values(k, c_xland, c_xice, c_ivg, ii, jj, ij);
     if (cls_out) *cls_out = cls;
@@ -221,13 +212,37 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   }
   s.ist = 1; s.isc = 4; s.ice = (cls == 1) ? -1 : 0;
   s.yearlen = k.yearlen; s.julian = k.a.julian;
-  if (soiltyp == 14 && G2(xice) == 0.f) soiltyp = 7;
+  if (soiltyp == 14 && xice_in == 0.f) soiltyp = 7;                                 // drv:530-534
   if (vegtyp == k.a.isurban || vegtyp == 31 || vegtyp == 32 || vegtyp == 33) vegtyp = k.a.isurban;
-  if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }
   NMP_TIC(0);    // gather
   redprm(k.c, s, P, vegtyp, soiltyp);
   soiltyp_w = soiltyp;
   NMP_TIC(1);    // redprm
+  // (C)
+  s.zlvl = 0.5f * dz8w_in;
+  s.shdfac = div_rc(vegfra_in, NMP_RCC(100.f));
+  s.shdmax = div_rc(vegmax_in, NMP_RCC(100.f));
+  s.q2 = qv_in / (1.0f + qv_in);
+  s.sfcprs = (p8w_hi + p8w_lo) * 0.5f;
+  s.prcp = div_rc(rainbl_in, k.c.u.dt);
+#pragma unroll
+  for (int l = 1; l <= NSOIL; l++) {
+    y.smc[L(l)] = smc_in[l - 1]; y.sh2o[L(l)] = sh2o_in[l - 1];
+    y.stc[L(l)] = tslb_in[l - 1]; y.smceq[L(l)] = smceq_in[l - 1];
+    y.sice[L(l)] = 0.f; y.btrani[L(l)] = 0.f;
+  }
+#pragma unroll
+  for (int l = -2; l <= 0; l++) {
+    y.stc[L(l)] = tsno_in[l + 2]; y.snice[L(l)] = snice_in[l + 2]; y.snliq[L(l)] = snliq_in[l + 2];
+    y.ficeold[L(l)] = (l > s.isnow) ? snice_in[l + 2] / (snice_in[l + 2] + snliq_in[l + 2]) : 0.f;     // drv:516-518
+  }
+#pragma unroll
+  for (int l = -2; l <= NSOIL; l++) { y.zsnso[L(l)] = zsnso_in[L(l)]; y.dzsnso[L(l)] = 0.f; y.imelt[L(l)] = 0.f; }
+  s.rech = 0.f; s.deeprech = 0.f;
+  s.co2air = 395.e-06f * s.sfcprs;
+  s.o2air = 0.209f * s.sfcprs;
+  s.foln = 1.0f;
+  if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }      // drv:540-545
   s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.ts.lucats) ? vegtyp : 1;
   if (s.err) { failed = s.err; live = false; }                                     // REDPRM fatals, lsm:9266-9344
   if (NMP_TRUNC == 1) s.err = 99;
