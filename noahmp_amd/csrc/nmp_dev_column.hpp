@@ -253,10 +253,13 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   if constexpr (MODE != 1)
   if (cls == 1 && !failed) {
     s.tbot = nmp_min(s.tbot, 263.15f);                                               // drv:555
-    gather_water_state(k, s, ij);              // passed through, or overwritten by glacier_fill_undefined (drv:571-625)
     glacier(k.c, s, y);
     if (s.err) failed = s.err;
     else {
+      // NOAHMP_GLACIER reads none of the WATER-phase words: SMCWTD and the accumulators are passed through, the rest is overwritten by
+      // glacier_fill_undefined (drv:571-625).  Gathered here, as one batch, they are not live across the glacier physics (the land-ice
+      // kernel needs all 256 registers; held from the start they were spilled one by one, each behind its own wait)
+      gather_water_state(k, s, ij);
       glacier_fill_undefined(s);                                                   // drv:571-625
       qfx_out = s.edir; lh_out = s.fgev;                                           // drv:627-628
       scatter_energy_outputs(k, s, ij);

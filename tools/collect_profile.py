@@ -106,13 +106,14 @@ L += ["", "## Derived", "",
       "- the kernel is bound by the serial instruction streams of its two waves per SIMD (a wave alone issues at most one VALU instruction per ~4.2 cycles) and their stalls (every wave waits ~%.0f %% of its cycles, mostly on LDS look-ups of the libm tables and the layer arrays), not by HBM (SURVEY.md 8d) and not by vector-ALU throughput"
       % (100 * out["derived"]["wait_any_share_of_wave_cycles"]),
       "", "## bench.py line of the same build (un-profiled run)", "", "```", json.dumps(bench), "```", ""]
-# ---- the per-step forcing permutation of the bench (six 2-D planes of the whole tile: read + write + 6 B of plan per column)
+# ---- the per-step forcing permutation of the bench (five 2-D planes of the whole tile -- of the two-level T3D only level 1 travels:
+# read + write + 6 B of plan per column)
 ntile = bench["config"]["columns_per_gpu"]
 for r in csv.DictReader(open(stats)):
     if "noahmp_scatter" in r["Name"]:
-        b = ntile * (6 * 8 + 6)
+        b = ntile * (5 * 8 + 6)
         L += ["## Forcing permutation (`%s`, %s calls)" % (r["Name"].split("(")[0].split("::")[-1][:40], r["Calls"]), "",
-              "six planes x %d columns x (4 B read + 4 B written) + 6 B of plan per column = %.0f MB in %.1f us = **%.2f TB/s = %.0f %% of 8 TB/s** (round 2: 203 us, 23 %%)"
+              "five planes x %d columns x (4 B read + 4 B written) + 6 B of plan per column = %.0f MB in %.1f us = **%.2f TB/s = %.0f %% of 8 TB/s** (round 2: six planes in 203 us, 23 %%)"
               % (ntile, b / 1e6, float(r["AverageNs"]) / 1e3, b / float(r["AverageNs"]) / 1e3, 100 * b / float(r["AverageNs"]) / 8000), ""]
 for sub, name in (("trace4", "config 4"), ("trace5", "config 5")):
     fs = glob.glob(os.path.join(src, sub, "*_kernel_stats.csv")) + glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
