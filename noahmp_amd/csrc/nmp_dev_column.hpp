@@ -183,6 +183,10 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   s.psfc = G3(p8w3d, k.k1, k.nka);
   const float rainbl_in = G2(rainbl);
   s.isnow = G2(isnowxy);
+  // ISNOWXY is -NSNOW .. 0 by construction of the model (lsm:7044-7343 keep it there; the reference indexes its (-2:4) arrays with it
+  // unchecked).  Told so, the compiler resolves every `layer > ISNOW` of a soil layer at compile time -- no branch, and the layer loops'
+  // LDS reads of the four soil layers become one batch -- and keeps the branches of the three snow layers only.
+  NMP_ASSUME(s.isnow >= -NSNOW && s.isnow <= 0);
   float smc_in[NSOIL], sh2o_in[NSOIL], tslb_in[NSOIL], smceq_in[NSOIL], tsno_in[3], snice_in[3], snliq_in[3], zsnso_in[NL];
 #pragma unroll
   for (int l = 1; l <= NSOIL; l++) {

@@ -18,6 +18,11 @@ namespace nmp {
 // __host__ too: tests/host_emul compiles the same source for the CPU to debug it without a GPU
 #define NMP_DEV __host__ __device__ __forceinline__
 #define L(i) ((i) + 2)   // layer -2..4 -> slot 0..6
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NMP_ASSUME(c) __builtin_assume(c)
+#else
+#define NMP_ASSUME(c) ((void)0)
+#endif
 constexpr int NL = 7;
 constexpr int NSOIL = NOAHMP_NSOIL;
 constexpr int NSNOW = NOAHMP_NSNOW;
