@@ -435,6 +435,7 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
     }
   }
   snowh2o<true>(c, s, y, qsnfro, qsnsub, qrain);
+  NMP_ASSUME(s.isnow >= -NSNOW && s.isnow <= 0);
   if (s.sneqv > 2000.f) {
     float bdsnow = y.snice[L(0)] / y.dzsnso[L(0)];
     snoflow = (s.sneqv - 2000.f);

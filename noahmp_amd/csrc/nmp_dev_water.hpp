@@ -264,6 +264,7 @@ NMP_DEV void divide(Col& s, const Lay<A>& y) {
     }
   }
   s.isnow = -msno;
+  NMP_ASSUME(s.isnow >= -NSNOW && s.isnow <= -1);         // DIVIDE runs on 1..3 layers and returns 1..3 (lsm:7263-7358)
   const int n = s.isnow;
   y.dzsnso[L(n + 1)] = dz1; y.snice[L(n + 1)] = wi1; y.snliq[L(n + 1)] = wl1; y.stc[L(n + 1)] = t1;
   if (msno >= 2) { y.dzsnso[L(n + 2)] = dz2; y.snice[L(n + 2)] = wi2; y.snliq[L(n + 2)] = wl2; y.stc[L(n + 2)] = t2; }
@@ -423,6 +424,7 @@ NMP_DEV void snowwater(const Ctx& c, Col& s, const Lay<A>& y, float snowhin, flo
   if (s.isnow < 0) combine<false>(s, y);
   if (s.isnow < 0) divide<false>(s, y);
   snowh2o<false>(c, s, y, qsnfro, qsnsub, qrain);
+  NMP_ASSUME(s.isnow >= -NSNOW && s.isnow <= 0);          // COMBINE only removes layers, DIVIDE returns 1..3, SNOWFALL creates the first
 #pragma unroll
   for (int iz = -2; iz <= 0; iz++) {
     if (iz <= s.isnow) {
