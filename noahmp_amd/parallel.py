@@ -86,8 +86,9 @@ class Comm:
                 self.backend, self.dev_group = "nccl", pg
         self.p2p_host = self.backend == "gloo"
         if halo in ("rccl", "tcp"):
-            self._start_cabi(halo, halo_port)                     # explicit request: a failure is an error
-        elif halo == "auto" and self.backend == "nccl" and os.environ.get("NMP_HALO_AUTO", "1") != "0":
+            self.halo_lib, self.halo = self._start_cabi(halo, halo_port), halo      # explicit request: a failure is an error
+        elif halo == "auto" and os.environ.get("NMP_HALO_AUTO", "1") != "0" and (
+                self.backend == "nccl" or os.environ.get("NMP_HALO_AUTO_TRANSPORT") == "tcp"):
             self._try_cabi_rccl(halo_port)
 
     # ---- agreement over the control plane
@@ -114,7 +115,7 @@ class Comm:
                                       abi.HALO_RCCL if halo == "rccl" else abi.HALO_TCP)
         if rc:
             raise RuntimeError("noahmp_hip_halo_init: rc=%d %s" % (rc, lib.noahmp_hip_last_error().decode()))
-        self.halo_lib, self.halo = lib, halo
+        return lib
 
     def _probe_cabi(self, lib, device):
         """One checked exchange with the C-ABI mover on a virtual 3 x 3-cells-per-rank grid whose values name their cell: every
@@ -152,30 +153,36 @@ class Comm:
         """halo="auto" with RCCL up: start the engine's RCCL mover and run one checked probe exchange in a helper thread with a time
         limit (a communicator that never forms must not park the job), then AGREE: it is used only if every rank succeeded."""
         import threading
+        # NMP_HALO_AUTO_TRANSPORT=tcp (tests): the same start / probe / agreement with the socket transport on host planes, so that the
+        # selection logic runs on a CPU-only box; NMP_HALO_AUTO_FAIL_RANK=r makes rank r report a failed probe
+        transport = "tcp" if os.environ.get("NMP_HALO_AUTO_TRANSPORT") == "tcp" else "rccl"
         limit = float(os.environ.get("NMP_HALO_AUTO_TIMEOUT_S", "90"))
         os.environ.setdefault("NMP_HALO_TIMEOUT_S", str(int(max(limit - 30.0, 20.0))))     # the rendezvous' own deadlines end first
         box = {}
 
-        def work():
+        def work():                      # touches only `box`: a helper that answers after the time limit must not change the mover
             try:
-                self._start_cabi("rccl", halo_port)
-                box["err"] = self._probe_cabi(self.halo_lib, device=True)
+                box["lib"] = self._start_cabi(transport, halo_port)
+                box["err"] = self._probe_cabi(box["lib"], device=(transport == "rccl"))
+                if os.environ.get("NMP_HALO_AUTO_FAIL_RANK") == str(self.rank):
+                    box["err"] = "forced failure (NMP_HALO_AUTO_FAIL_RANK)"
             except Exception as e:                                # noqa: BLE001
                 box["err"] = str(e).splitlines()[0][:200] if str(e) else repr(e)
 
         th = threading.Thread(target=work, daemon=True)
         th.start()
         th.join(limit)
-        err = "no answer within %g s" % limit if th.is_alive() else box.get("err")
+        late = th.is_alive()
+        err = "no answer within %g s" % limit if late else box.get("err")
         if self._agree_any(err is not None):
             self.halo_note = ("C-ABI RCCL mover not used (%s): torch.distributed send/recv moves the ring"
                               % (("rank %d: %s" % (self.rank, err)) if err else "another rank failed"))
             print("noahmp_amd.parallel: " + self.halo_note, file=sys.stderr, flush=True)
-            if self.halo_lib is not None and not th.is_alive():
-                self.halo_lib.noahmp_hip_halo_finalize()
+            if box.get("lib") is not None and not late:
+                box["lib"].noahmp_hip_halo_finalize()
             self.halo_lib, self.halo = None, "torch"
         else:
-            self.halo = "rccl"
+            self.halo_lib, self.halo = box["lib"], transport
 
     # ---- tile assignment (mpp_land_partition_calc, mpp:227-288)
     def my_tile(self, global_nx, global_ny):

@@ -93,6 +93,54 @@ def _fallback_worker(rank, world, port, q):
     comm.close()
 
 
+def _auto_worker(rank, world, port, fail_rank, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      NMP_HALO_AUTO_TRANSPORT="tcp", NMP_HALO_AUTO_TIMEOUT_S="60")
+    if fail_rank is not None:
+        os.environ["NMP_HALO_AUTO_FAIL_RANK"] = str(fail_rank)
+    import torch
+    from noahmp_amd.parallel import Comm
+    from noahmp_amd.partition import tile_geometry
+    comm = Comm(backend="gloo", halo="auto")
+    gx, gy = 23, 17
+    geo = tile_geometry(gx, gy, world, rank, halo=1)
+    y, x = np.meshgrid(np.arange(gy), np.arange(gx), indexing="ij")
+    gf = (1000.0 * y + x).astype(np.float32)
+    sl = (slice(geo["jms"] - 1, geo["jme"]), slice(geo["ims"] - 1, geo["ime"]))
+    f = gf[sl].copy()
+    ring = np.ones(f.shape, dtype=bool)
+    ring[geo["jts"] - geo["jms"]:geo["jte"] - geo["jms"] + 1, geo["its"] - geo["ims"]:geo["ite"] - geo["ims"] + 1] = False
+    f[ring] = np.nan
+    t = torch.from_numpy(f)
+    comm.exchange_halo([t], geo)                    # whichever mover was agreed on
+    q.put((rank, comm.halo, comm.halo_note, bool(np.array_equal(t.numpy(), gf[sl]))))
+    comm.close()
+
+
+@pytest.mark.parametrize("fail_rank", [None, 2])
+def test_auto_mover_is_agreed_on_by_all_ranks(fail_rank):
+    """`halo="auto"`: every rank starts the engine's own mover and runs the checked probe exchange (here with the socket transport on
+    host planes, so that it runs without a GPU); it is used only if EVERY rank succeeded -- one failing rank sends all of them to the
+    torch.distributed mover together -- and either way the ring arrives (4 ranks = 2 x 2: every rank has a diagonal neighbour)."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = _free_port()
+    procs = [ctx.Process(target=_auto_worker, args=(r, world, p, fail_rank, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert all(ok for _, _, _, ok in res), res
+    if fail_rank is None:
+        assert all(h == "tcp" and note is None for _, h, note, _ in res), res
+    else:
+        assert all(h == "torch" and note for _, h, note, _ in res), res
+        assert "forced failure" in res[fail_rank][2] and "another rank" in res[0][2]
+
+
 def test_nccl_that_cannot_initialise_falls_back_to_gloo():
     """A node whose RCCL does not come up (here: no GPU at all) still runs bench.py --gpus N: control plane and ring over gloo."""
     import torch
