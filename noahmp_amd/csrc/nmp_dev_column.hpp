@@ -182,11 +182,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   const float p8w_hi = G3(p8w3d, k.kp_hi, k.nka), p8w_lo = G3(p8w3d, k.kp_lo, k.nka);
   s.psfc = G3(p8w3d, k.k1, k.nka);
   const float rainbl_in = G2(rainbl);
-  s.isnow = G2(isnowxy);
-  // ISNOWXY is -NSNOW .. 0 by construction of the model (lsm:7044-7343 keep it there; the reference indexes its (-2:4) arrays with it
-  // unchecked).  Told so, the compiler resolves every `layer > ISNOW` of a soil layer at compile time -- no branch, and the layer loops'
-  // LDS reads of the four soil layers become one batch -- and keeps the branches of the three snow layers only.
-  NMP_ASSUME(s.isnow >= -NSNOW && s.isnow <= 0);
+  int isnow_in = G2(isnowxy);
   float smc_in[NSOIL], sh2o_in[NSOIL], tslb_in[NSOIL], smceq_in[NSOIL], tsno_in[3], snice_in[3], snliq_in[3], zsnso_in[NL];
 #pragma unroll
   for (int l = 1; l <= NSOIL; l++) {
@@ -216,6 +212,13 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   }
   s.ist = 1; s.isc = 4; s.ice = (cls == 1) ? -1 : 0;
   s.yearlen = k.yearlen; s.julian = k.a.julian;
+  // ISNOWXY is -NSNOW .. 0 by construction of the model (lsm:7044-7343 keep it there); the reference indexes its (-2:4) layer arrays
+  // with it unchecked, here another value is a reported error like REDPRM's type checks (the column is left untouched).  With the range
+  // stated, the compiler resolves every `layer > ISNOW` of a SOIL layer at compile time -- no branch, and the layer loops' LDS reads of
+  // the four soil layers become one batch -- and keeps the branches of the three snow layers only.
+  if (isnow_in < -NSNOW || isnow_in > 0) raise(s, NOAHMP_ERR_ISNOW_RANGE);
+  s.isnow = isnow_in < -NSNOW ? -NSNOW : (isnow_in > 0 ? 0 : isnow_in);
+  NMP_ASSUME(s.isnow >= -NSNOW && s.isnow <= 0);
   if (soiltyp == 14 && xice_in == 0.f) soiltyp = 7;                                 // drv:530-534
   if (vegtyp == k.a.isurban || vegtyp == 31 || vegtyp == 32 || vegtyp == 33) vegtyp = k.a.isurban;
   NMP_TIC(0);    // gather

@@ -865,6 +865,8 @@ const char* noahmp_hip_error_string(int code) {
     case NOAHMP_ERR_GLACIER_WATER_BALANCE: return "glacier: water budget (gla:2968)";
     case NOAHMP_ERR_GLACIER_FIRE_NONPOSITIVE: return "glacier: emitted longwave <0 (gla:541)";
     case NOAHMP_ERR_NSOIL_UNSUPPORTED: return "engine is compiled for NSOIL=4, NSNOW=3";
+    case NOAHMP_ERR_CLASS_RANGE: return "a column is not of the class its range was declared to hold (sorted_land_columns / sorted_glacier_columns)";
+    case NOAHMP_ERR_ISNOW_RANGE: return "ISNOWXY outside -NSNOW..0";
   }
   return "unknown";
 }

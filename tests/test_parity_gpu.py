@@ -271,6 +271,24 @@ def test_error_channel_first_column_wins(engine, tables):
     assert (s["tsk"][0] != before["tsk"][0]).all()          # the rest advanced
 
 
+def test_isnow_out_of_range_is_reported(engine, tables):
+    """ISNOWXY outside -NSNOW..0 (the reference would index its layer arrays out of bounds) is a reported error at that column,
+    which is left untouched; the other columns advance."""
+    from noahmp_amd.driver import NoahMPFatal
+    s = synth.mixed_small(tables[1], ni=32, nj=4)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+    s["isnowxy"][1, 5] = -7
+    s["isnowxy"][3, 9] = 2
+    before = s.copy()
+    with pytest.raises(NoahMPFatal) as e:
+        engine.noahmplsm(s, 1, 2000, 180.0)
+    assert (e.value.code, e.value.i, e.value.j) == (18, 6, 2)
+    assert engine.lib.noahmp_hip_error_string(18).decode().startswith("ISNOWXY")
+    assert s["tsk"][1, 5] == before["tsk"][1, 5] and s["isnowxy"][1, 5] == -7
+    assert (s["tsk"][0] != before["tsk"][0]).all()
+
+
 def test_water_and_seaice_points(engine, port, tables):
     s = synth.mixed_small(tables[1], ni=16, nj=2)
     synth.first_step_fixups(s)
