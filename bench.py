@@ -384,12 +384,13 @@ class Run:
         halo_store = self.gw if self.gw is not None else self.d
         if self.gw is not None:                                                      # ZWTXY: sorted -> (i,j) order, into the ring-carrying block
             self.scat.exchange([self.d.a["zwtxy"]], [self.gw.a["zwtxy"]], True, self.gw.ni, self.i_off, self.j_off, self.sp)
-        with torch.cuda.stream(self.ts):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self.comm.exchange_halo([halo_store.a["zwtxy"]], self.geom)              # ZWTXY ring before every call
-            e1.record()
-        self.halo_events.append((e0, e1))
+        if self.comm.world > 1:                # (one rank: nothing to exchange -- and two events are ~10 us between two kernels)
+            with torch.cuda.stream(self.ts):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.comm.exchange_halo([halo_store.a["zwtxy"]], self.geom)          # ZWTXY ring before every call
+                e1.record()
+            self.halo_events.append((e0, e1))
         if self.gw is not None:
             self.eng.wtable_lateral_async(self.wargs, self.gw.a["qlat"], self.sp)     # KCELL / HEAD + QLAT stencil, (i,j) order
             self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order

@@ -50,8 +50,8 @@ struct Engine {
   float sync_class_ms[3] = {0.f, 0.f, 0.f};   // noahmp_hip_sync_timing
   int sync_steps = 0;
   std::vector<float> sync_step_ms;            // noahmp_hip_sync_step_timing: land (or mixed) kernel of each step of the last sync
-  std::vector<char> async_forked;             // per pending step: did launch_any run the land-ice / skipped kernels on the second stream?
-  bool last_launch_forked = false;
+  std::vector<char> async_kind;               // per pending step: launch_any's kind (0 one kernel, 1 class kernels in a row, 2 forked)
+  int last_launch_kind = 0;
   int deferred_code = 0;                      // fatal code of a deferred step that no call has returned yet
   // host-memory path: row-chunk pipeline H2D | kernel | D2H on three streams, optional pinning of the caller's arrays
   hipStream_t s_up = nullptr, s_dn = nullptr;

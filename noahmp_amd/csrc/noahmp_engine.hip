@@ -291,11 +291,13 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
 }
 
 // class_ranges: the call is a whole device-resident tile, the only kind of call the declared class ranges can describe
-// mid: two events recorded after the land range and after the land-ice range (per-class kernel times of noahmp_hip_sync_timing)
-static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false, hipEvent_t* mid = nullptr) {
+// ev: the step's three timing events (noahmp_hip_sync_timing): start | end of the land (or only) kernel | end of the land-ice + skipped
+// kernels.  Every event is one more packet between two kernels of the caller's stream (~5 us each on this chip), so they double as the
+// fork / join events of the second stream and nothing else is recorded; g.last_launch_kind tells noahmp_hip_sync which of them exist.
+static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false, hipEvent_t* ev = nullptr) {
   const long ncol = (long)k.nti * k.ntj;
-  g.last_launch_forked = false;
-  if (ncol <= 0) return;
+  g.last_launch_kind = 0;
+  if (ncol <= 0) { if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); } return; }
   // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
   if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
       g.block == 256 && g.use_lds) {
@@ -303,29 +305,26 @@ static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false,
     // launch size): they run on a second stream beside the land kernel -- disjoint columns -- and join before anything else follows.
     const long n_rest = ncol - g.sorted_land;
     const bool fork = g.overlap_class_kernels && g.sorted_land > 0 && n_rest > 0;
-    g.last_launch_forked = fork;
-    if (fork) {
-      if (!g.aux_stream) {
-        hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);
-        hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming);
-        hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming);
-      }
-      hipEventRecord(g.ev_fork, s);
-      hipStreamWaitEvent(g.aux_stream, g.ev_fork, 0);
+    g.last_launch_kind = fork ? 2 : 1;
+    if (fork && !g.aux_stream) {
+      hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);
+      hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming);
+      hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming);
     }
+    hipEvent_t e_fork = ev ? ev[0] : g.ev_fork, e_join = ev ? ev[2] : g.ev_join;
+    if (fork || ev) hipEventRecord(e_fork, s);
+    if (fork) hipStreamWaitEvent(g.aux_stream, e_fork, 0);
     hipStream_t s2 = fork ? g.aux_stream : s;
     launch_range<1>(k, 0, g.sorted_land, s);
-    if (mid) hipEventRecord(mid[0], s);
+    if (ev) hipEventRecord(ev[1], s);
     launch_range<2>(k, g.sorted_land, g.sorted_glacier, s2);
     launch_range<3>(k, g.sorted_land + g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s2);
-    if (mid) hipEventRecord(mid[1], s2);        // with the fork: start of the step .. end of the land-ice + skipped kernels
-    if (fork) {
-      hipEventRecord(g.ev_join, s2);
-      hipStreamWaitEvent(s, g.ev_join, 0);
-    }
+    if (fork || ev) hipEventRecord(e_join, s2);
+    if (fork) hipStreamWaitEvent(s, e_join, 0);
     return;
   }
-  struct MidAtEnd { hipEvent_t* m; hipStream_t s; ~MidAtEnd() { if (m) { hipEventRecord(m[0], s); hipEventRecord(m[1], s); } } } at_end{mid, s};
+  if (ev) hipEventRecord(ev[0], s);
+  struct EndEvent { hipEvent_t* e; hipStream_t s; ~EndEvent() { if (e) hipEventRecord(e[1], s); } } at_end{ev, s};
   if (g.block == 256 && g.use_lds && fixed_level(k)) { launch_range<0>(k, 0, ncol, s); return; }
   if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
   else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
@@ -725,20 +724,17 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   KArgs k;
   fill_kargs(k, a);
   k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
-  // one event pair per step: kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
+  // three events per step (launch_any): kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
   // else the caller puts on the stream between them
-  while ((int)g.async_events.size() < 4 * (g.async_pending + 1)) {
+  while ((int)g.async_events.size() < 3 * (g.async_pending + 1)) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
     g.async_events.push_back(e);
   }
-  // events of a step: start | after the land (or mixed) kernel | after the land-ice kernel | end
-  HIPCHK(hipEventRecord(g.async_events[4 * g.async_pending], s));
-  launch_any(k, s, true, &g.async_events[4 * g.async_pending + 1]);
+  launch_any(k, s, true, &g.async_events[3 * g.async_pending]);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.async_events[4 * g.async_pending + 3], s));
-  if ((int)g.async_forked.size() <= g.async_pending) g.async_forked.resize(g.async_pending + 1);
-  g.async_forked[g.async_pending] = g.last_launch_forked ? 1 : 0;
+  if ((int)g.async_kind.size() <= g.async_pending) g.async_kind.resize(g.async_pending + 1);
+  g.async_kind[g.async_pending] = (char)g.last_launch_kind;
   g.async_pending++;
   g.async_stream = s;
   bool known = false;
@@ -768,19 +764,18 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
     for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f;
     g.sync_step_ms.assign(nsteps, 0.f);
     for (int i = 0; i < nsteps; i++) {
-      float one = 0.f;
-      hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 3]);
-      ms += one;
-      // land: start .. end of the land kernel.  land ice (+ skipped): they ran beside the land kernel when THIS step forked
-      // (their end is then measured from the start of the step), behind it otherwise
-      const bool forked = i < (int)g.async_forked.size() && g.async_forked[i];
-      one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i], g.async_events[4 * i + 1]); g.sync_class_ms[0] += one;
-      g.sync_step_ms[i] = one;
-      one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + (forked ? 0 : 1)], g.async_events[4 * i + 2]);
-      g.sync_class_ms[1] += one > 0.f ? one : 0.f;
-      if (!forked) {
-        one = 0.f; hipEventElapsedTime(&one, g.async_events[4 * i + 2], g.async_events[4 * i + 3]); g.sync_class_ms[2] += one;
-      }
+      // kind 0: one kernel (events 0, 1).  1: class kernels one after the other (0 | land | 1 | land ice + skipped | 2).
+      // 2: land ice + skipped on the second stream beside the land kernel (both measured from the start of the step).
+      hipEvent_t* e = &g.async_events[3 * i];
+      const int kind = i < (int)g.async_kind.size() ? g.async_kind[i] : 0;
+      float land = 0.f, rest = 0.f;
+      hipEventElapsedTime(&land, e[0], e[1]);
+      if (kind) hipEventElapsedTime(&rest, e[kind == 2 ? 0 : 1], e[2]);
+      if (rest < 0.f) rest = 0.f;
+      ms += kind == 2 ? (land > rest ? land : rest) : land + rest;
+      g.sync_class_ms[0] += land;
+      g.sync_class_ms[1] += rest;
+      g.sync_step_ms[i] = land;
     }
     g.sync_steps = nsteps;
     if (st) {
