@@ -75,6 +75,17 @@ __global__ void sort_bounds_kernel(const unsigned* keys, long n, long* out) {
   out[threadIdx.x] = lo;
 }
 
+// the 256 counters summed into ONE word of mapped host memory: a D2H copy command would make the host wait for the stream to reach it
+__global__ void __launch_bounds__(256) stale_sum_kernel(unsigned long long* slots, volatile long* host_word) {
+  __shared__ unsigned long long part[4];
+  unsigned long long v = slots[threadIdx.x];
+  slots[threadIdx.x] = 0;                      // ready for the next count
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { *host_word = (long)(part[0] + part[1] + part[2] + part[3]); __threadfence_system(); }
+}
+
 __global__ void __launch_bounds__(256) invert_perm_kernel(const int* perm, int* inv, long n) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) inv[perm[p]] = (int)p;
@@ -136,6 +147,7 @@ struct SortScratch {
   void* seg_tmp = nullptr; size_t seg_tmp_b = 0;
   unsigned long long* slots = nullptr;      // 256 staleness counters
   long* h_bounds = nullptr;                 // pinned: 2 class boundaries + 256 staleness slots
+  unsigned long long* slots_async = nullptr; long* h_async = nullptr; long* d_async_word = nullptr; hipEvent_t ev_async = nullptr; bool async_pending = false;   // noahmp_hip_sort_staleness_async
   long* d_bounds = nullptr;
 } sc;
 
@@ -146,6 +158,8 @@ void sort_finalize() {
   hipFree(sc.slot_in); hipFree(sc.seg_tmp);
   hipFree(sc.keys_in); hipFree(sc.idx_in); hipFree(sc.keys_out); hipFree(sc.tmp); hipFree(sc.inv); hipFree(sc.slots); hipFree(sc.d_bounds);
   if (sc.h_bounds) hipHostFree(sc.h_bounds);
+  hipFree(sc.slots_async); if (sc.h_async) hipHostFree(sc.h_async); if (sc.ev_async) hipEventDestroy(sc.ev_async);
+  sc.async_pending = false;
   sc = SortScratch();
 }
 }  // namespace nmp_host
@@ -154,6 +168,17 @@ extern "C" {
 
 int noahmp_hip_sort_set_band(const int32_t* band_plane) {
   g_band_plane = band_plane;
+  return 0;
+}
+
+// buffers of noahmp_hip_sort_staleness_async: allocated when a layout is sorted (allocations synchronise the device -- not inside a run)
+static int ensure_async_count() {
+  if (sc.slots_async) return 0;
+  HIPCHK(hipMalloc(&sc.slots_async, 256 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(sc.slots_async, 0, 256 * sizeof(unsigned long long)));
+  HIPCHK(hipHostMalloc((void**)&sc.h_async, sizeof(long), hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&sc.d_async_word, sc.h_async, 0));
+  HIPCHK(hipEventCreateWithFlags(&sc.ev_async, hipEventDisableTiming));
   return 0;
 }
 
@@ -174,6 +199,7 @@ int noahmp_hip_sort_columns(const noahmp_step_args* a, int flags, int tsk_bin_mk
   unsigned* kout = keys_out;
   if (!kout) { if ((rc = nmp_host::ensure_bytes((void**)&sc.keys_out, &sc.keys_out_b, n * 4))) return rc; kout = sc.keys_out; }
   if (!sc.d_bounds) { HIPCHK(hipMalloc(&sc.d_bounds, 2 * sizeof(long))); HIPCHK(hipHostMalloc((void**)&sc.h_bounds, 258 * sizeof(long), hipHostMallocDefault)); }
+  if ((rc = ensure_async_count())) return rc;
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(sort_key_kernel, dim3(nb), dim3(256), 0, s, k, sc.keys_in, sc.idx_in);
   size_t need = 0;
@@ -211,6 +237,39 @@ int noahmp_hip_sort_staleness(const noahmp_step_args* a, int flags, const uint32
   long tot = 0;
   for (int i = 0; i < 256; i++) tot += sc.h_bounds[2 + i];
   *changed = tot;
+  return 0;
+}
+
+// The same count without a wait: a check every K steps that drains the stream costs a run ~0.4 ms of idle GPU each time (the host has to
+// refill the queue); enqueued here, the count is read K steps later, when it has long arrived.
+int noahmp_hip_sort_staleness_async(const noahmp_step_args* a, int flags, const uint32_t* sorted_keys, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  KeyArgs k;
+  rc = fill_key_args(k, a, flags, 0);
+  if (rc) return rc;
+  if (!sorted_keys) { g.last_error = "noahmp_hip_sort_staleness_async: sorted_keys is required"; return -105; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  if ((rc = ensure_async_count())) return rc;
+  if (sc.async_pending) HIPCHK(hipEventSynchronize(sc.ev_async));      // an unread earlier count is overwritten, never raced
+  if (k.n > 0) hipLaunchKernelGGL(sort_stale_kernel, dim3((unsigned)((k.n + 255) / 256)), dim3(256), 0, s, k, sorted_keys, sc.slots_async);
+  hipLaunchKernelGGL(stale_sum_kernel, dim3(1), dim3(256), 0, s, sc.slots_async, (volatile long*)sc.d_async_word);
+  HIPCHK(hipEventRecord(sc.ev_async, s));
+  sc.async_pending = true;
+  return 0;
+}
+
+// 0: *changed = the count of the last noahmp_hip_sort_staleness_async; 1: not there yet (wait == 0); -105: nothing was asked for.
+int noahmp_hip_sort_staleness_result(int64_t* changed, int wait) {
+  if (!sc.async_pending || !changed) { g.last_error = "noahmp_hip_sort_staleness_result: no pending count"; return -105; }
+  if (wait) HIPCHK(hipEventSynchronize(sc.ev_async));
+  else {
+    hipError_t q = hipEventQuery(sc.ev_async);
+    if (q == hipErrorNotReady) return 1;
+    HIPCHK(q);
+  }
+  *changed = *(volatile long*)sc.h_async;
+  sc.async_pending = false;
   return 0;
 }
 

@@ -259,6 +259,27 @@ class Engine:
             raise RuntimeError("noahmp_hip_sort_staleness: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return int(changed.value)
 
+    def sort_staleness_async(self, store, stream=None):
+        """sort_staleness without the wait: enqueued on `stream`, read later with sort_staleness_result (a check that drains the
+        stream idles the GPU while the host refills its queue)."""
+        a = store.step_args(1, 2000, 1.0)
+        band = getattr(store, "sort_band", None)
+        self.lib.noahmp_hip_sort_set_band(store.a[band].data_ptr() if band else None)
+        rc = self.lib.noahmp_hip_sort_staleness_async(C.byref(a), store.sort_flags, store.sort_keys.data_ptr(), stream)
+        self.lib.noahmp_hip_sort_set_band(None)
+        if rc:
+            raise RuntimeError("noahmp_hip_sort_staleness_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+
+    def sort_staleness_result(self, wait=True):
+        """The count sort_staleness_async asked for; None if it has not arrived and wait is False."""
+        changed = C.c_int64(0)
+        rc = self.lib.noahmp_hip_sort_staleness_result(C.byref(changed), 1 if wait else 0)
+        if rc == 1:
+            return None
+        if rc:
+            raise RuntimeError("noahmp_hip_sort_staleness_result: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        return int(changed.value)
+
     def gather(self, dst, src, perm, ni, nj):
         return Engine.Gather(self.lib, dst, src, perm, ni, nj)
 

@@ -151,7 +151,9 @@ def test_resorted_run_over_snow_accumulation_equals_tile_order(engine, tables):
         if it % 4 == 0:
             st, _ = engine.sync()
             assert st.code == 0
+            engine.sort_staleness_async(srt)                       # the count without a wait: enqueued, read later
             stale.append(engine.sort_staleness(srt))
+            assert engine.sort_staleness_result(wait=True) == stale[-1]
             if stale[-1] > 0:
                 perm = engine.sort_store(srt)
                 assert engine.sort_staleness(srt) == 0
