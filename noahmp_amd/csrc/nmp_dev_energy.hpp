@@ -641,7 +641,8 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   if (FIRST) {
     StomataT st = {0.f, 0.f, 0.f};
     float avcmx_pow = 0.f;
-    if (c.O.crs == 1 && (f->parsun > 0.0f || f->parsha > 0.0f)) {   // STOMATA returns early for APAR <= 0
+    // STOMATA returns early for APAR <= 0 -- and only then: a NaN APAR (OPT_RAD = 1 on a type without crown geometry) goes on
+    if (c.O.crs == 1 && (!(f->parsun <= 0.0f) || !(f->parsha <= 0.0f))) {
       st = stomata_temperature(f->sp, L.tv, f->o2air);
       avcmx_pow = nmp_powf(f->sp.avcmx, div_rc((L.tv - TFRZ) - 25.0f, NMP_RCC(10.0f)));
     }

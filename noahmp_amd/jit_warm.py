@@ -21,7 +21,7 @@ MIXES = [dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_sfc=2, iopt_frz=2),
          dict(idveg=2, iopt_run=3, iopt_stc=2), dict(iopt_sfc=2, iopt_crs=2, iopt_btr=2, iopt_frz=2, iopt_inf=2),
          dict(iopt_rad=1, iopt_alb=1, iopt_snf=3, iopt_tbot=1, idveg=5), dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_frz=2),
          dict(iopt_btr=2, iopt_crs=2, idveg=5), dict(idveg=2, iopt_run=5), dict(idveg=1, iopt_run=5),
-         dict(iopt_frz=2, iopt_inf=2)]        # bench.py's options_reference legs: DVEG 2, SFC 2, RUN 3 (above) and this mix
+         dict(iopt_frz=2, iopt_inf=2), dict(idveg=5, iopt_crs=1, iopt_btr=3, iopt_run=3, iopt_frz=2, iopt_rad=1, iopt_alb=1)]        # bench.py's options_reference legs: DVEG 2, SFC 2, RUN 3 (above) and this mix
 
 
 def options12(cfg):

@@ -6,7 +6,10 @@ import pytest
 from tools import fuzz_parity
 
 OPTS = [dict(), dict(idveg=2, iopt_run=3, iopt_stc=2, iopt_sfc=2, iopt_frz=2), dict(iopt_run=5, idveg=3),
-        dict(iopt_rad=1, iopt_alb=1, iopt_snf=3, iopt_tbot=1, idveg=5, iopt_crs=2, iopt_btr=2, iopt_inf=2)]
+        dict(iopt_rad=1, iopt_alb=1, iopt_snf=3, iopt_tbot=1, idveg=5, iopt_crs=2, iopt_btr=2, iopt_inf=2),
+        # found by `experiments.sh fuzzopts` (random option sets): OPT_RAD = 1 gives a type without crown geometry a NaN APAR, dynamic
+        # vegetation gives it leaves, and Ball-Berry STOMATA (OPT_CRS = 1) returns early for APAR <= 0 only -- PSN is NaN in the reference
+        dict(idveg=5, iopt_crs=1, iopt_btr=3, iopt_run=3, iopt_frz=2, iopt_rad=1, iopt_alb=1)]
 # scalars=1: DT / DZS / YR / JULIAN / DZ8W drawn per seed (fuzz_parity.draw_scalars) instead of the namelist defaults
 SCALARS = [dict(scalars=1), dict(scalars=1, idveg=4, iopt_run=3, iopt_inf=1, iopt_frz=2), dict(scalars=1, iopt_run=5)]
 SEEDS = (1, 14, 27, 32)           # dt 600 / 900 / 1800 / 3600, three DZS sets, YR 2004 / 2100 / 2001, julian 60 ... 296

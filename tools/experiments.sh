@@ -20,6 +20,7 @@
 #   phase [LIB...]                 phase shares of the profiling build (-DNMP_PHASE_TIMERS: variants/lib_prof.so), after an optional A/B
 #   micro NAME                     run tools/micro/NAME.bin (built in the dev container: hipcc --offload-arch=gfx950 -O3 NAME.hip -o NAME.bin)
 #   fuzz [SEEDS [COLUMNS]]         randomised GPU-vs-oracle runs over option sets (tools/fuzz_parity.py) + a config-5 chain
+#   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
 #   profile TAG                    the evidence for profiles/: plain bench, kernel traces (config 3 / 4 / 5, groundwater), FETCH / WRITE /
 #                                  SQ passes; then in the dev container: python tools/collect_profile.py TAG
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -188,6 +189,21 @@ fuzz)
            "iopt_run=2 iopt_btr=3 iopt_rad=2 iopt_snf=2" "idveg=4 iopt_run=4"; do
     timeout 600 python tools/config5_run.py 720 360 96 8192 $o 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['options'], d['sample_bit_identical'], d['checkpoints'], '%.3g' % d['column_steps_per_s'])" | tee -a $O/fuzz.log
   done
+  ;;
+fuzzopts)         # fuzzopts [NSETS [SEED [SEEDS COLUMNS]]]: random OPTION SETS (every OPT_* drawn from its supported range), each through hiprtc
+  nsets=${1:-16}; seed=${2:-404}; seeds=${3:-3}; cols=${4:-8192}; : > $O/fuzzopts.log
+  python3 - $nsets $seed > $O/sets.txt <<'PY'
+import sys
+import numpy as np
+r = np.random.Generator(np.random.Philox(int(sys.argv[2])))
+rng = dict(idveg=(1, 5), iopt_crs=(1, 2), iopt_btr=(1, 3), iopt_run=(1, 5), iopt_sfc=(1, 2), iopt_frz=(1, 2), iopt_inf=(1, 2), iopt_rad=(1, 3),
+           iopt_alb=(1, 2), iopt_snf=(1, 3), iopt_tbot=(1, 2), iopt_stc=(1, 2))
+for n in range(int(sys.argv[1])):
+    print(" ".join("%s=%d" % (k, r.integers(lo, hi + 1)) for k, (lo, hi) in rng.items()))
+PY
+  while read o; do
+    timeout 900 python tools/fuzz_parity.py gpu $seeds $cols $o scalars=1 2>&1 | grep "^gpu\|DIFFER\|Error\|Traceback" | head -4 | tee -a $O/fuzzopts.log
+  done < $O/sets.txt
   ;;
 profile)
   TAG=${1:-r04}
