@@ -190,8 +190,9 @@ fuzz)
     timeout 600 python tools/config5_run.py 720 360 96 8192 $o 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['options'], d['sample_bit_identical'], d['checkpoints'], '%.3g' % d['column_steps_per_s'])" | tee -a $O/fuzz.log
   done
   ;;
-fuzzopts)         # fuzzopts [NSETS [SEED [SEEDS COLUMNS]]]: random OPTION SETS (every OPT_* drawn from its supported range), each through hiprtc
-  nsets=${1:-16}; seed=${2:-404}; seeds=${3:-3}; cols=${4:-8192}; : > $O/fuzzopts.log
+fuzzopts)         # fuzzopts [NSETS [SEED [SEEDS COLUMNS [key=value ...]]]]: random OPTION SETS (every OPT_* drawn from its supported range), each
+                  # through hiprtc; further keys go to fuzz_parity.py (modis=1, steps=48)
+  nsets=${1:-16}; seed=${2:-404}; seeds=${3:-3}; cols=${4:-8192}; shift 4 2>/dev/null; extra="$*"; : > $O/fuzzopts.log
   python3 - $nsets $seed > $O/sets.txt <<'PY'
 import sys
 import numpy as np
@@ -202,7 +203,7 @@ for n in range(int(sys.argv[1])):
     print(" ".join("%s=%d" % (k, r.integers(lo, hi + 1)) for k, (lo, hi) in rng.items()))
 PY
   while read o; do
-    timeout 900 python tools/fuzz_parity.py gpu $seeds $cols $o scalars=1 2>&1 | grep "^gpu\|DIFFER\|Error\|Traceback" | head -4 | tee -a $O/fuzzopts.log
+    timeout 900 python tools/fuzz_parity.py gpu $seeds $cols $o scalars=1 $extra 2>&1 | grep "^gpu\|DIFFER\|Error\|Traceback" | head -4 | tee -a $O/fuzzopts.log
   done < $O/sets.txt
   ;;
 profile)

@@ -6,6 +6,7 @@ a few steps, every output compared bit for bit after every step.
                                                      seed because the reference STOPs the process on a fatal column)
   fuzz_parity.py emul [nseeds ncol] [opt=val ...]   device source compiled for the host vs the restatement (no GPU needed)
   fuzz_parity.py gpu  [nseeds ncol] [opt=val ...]   HIP engine vs the restatement (GPU box)
+  further keys: scalars=1 (DT / DZS / YR / JULIAN / ZLVL drawn per seed), modis=1 (MODIS tables and categories), steps=N (default 3)
 
 Columns on which the restatement reports a fatal code (energy / water balance stops of the reference) are replaced by a benign
 column before the comparison and counted.
@@ -36,7 +37,7 @@ def random_tile(tb, ncol, seed, cfg):
     s = synth._base_store(ni, nj, cfg)
     a = s.a
     shp = (nj, ni)
-    a["ivgtyp"][...] = r.integers(1, 28, size=shp)
+    a["ivgtyp"][...] = r.integers(1, int(tb.get("lucats", 27)) + 1, size=shp)
     a["isltyp"][...] = r.integers(1, 13, size=shp)
     ice = a["ivgtyp"] == cfg.isice
     water = a["ivgtyp"] == cfg.iswater
@@ -122,14 +123,18 @@ def draw_scalars(seed):
 
 
 def one_seed(mode, seed, ncol, kw):
-    global YR, JUL
+    global YR, JUL, NSTEPS
     kw = dict(kw)
     YR, JUL = 2000, 180.0
+    NSTEPS = kw.pop("steps", 3)                   # steps=N: a longer free run under the same (constant) forcing
     if kw.pop("scalars", 0):
         sc, YR, JUL = draw_scalars(seed)
         kw.update(sc)
         print("seed %d scalars: dt %g dzs %s zlvl %g yr %d julian %.3f" % (seed, sc["dt"], sc["dzs"], sc["zlvl"], YR, JUL))
-    T, tb = load_tables("usgs")
+    modis = kw.pop("modis", 0)                    # modis=1: the MODIFIED_IGBP_MODIS_NOAH tables and category indices (hdrv:130-143)
+    T, tb = load_tables("modis" if modis else "usgs")
+    if modis:
+        kw.update(isurban=tb["isurban"], isice=tb["issnow"], iswater=tb["iswater"])
     from oracle.portlib import PortLib
     port = PortLib(autobuild=False)
     port.set_tables(T)
