@@ -21,6 +21,7 @@
 #   micro NAME                     run tools/micro/NAME.bin (built in the dev container: hipcc --offload-arch=gfx950 -O3 NAME.hip -o NAME.bin)
 #   fuzz [SEEDS [COLUMNS]]         randomised GPU-vs-oracle runs over option sets (tools/fuzz_parity.py) + a config-5 chain
 #   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
+#   fuzzopts5 [NSETS [SEED]]       the sorted config-5 chain (class-range kernels) under random option sets, sample vs the oracle
 #   profile TAG                    the evidence for profiles/: plain bench, kernel traces (config 3 / 4 / 5, groundwater), FETCH / WRITE /
 #                                  SQ passes; then in the dev container: python tools/collect_profile.py TAG
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -204,6 +205,25 @@ for n in range(int(sys.argv[1])):
 PY
   while read o; do
     timeout 900 python tools/fuzz_parity.py gpu $seeds $cols $o scalars=1 $extra 2>&1 | grep "^gpu\|DIFFER\|Error\|Traceback" | head -4 | tee -a $O/fuzzopts.log
+  done < $O/sets.txt
+  ;;
+fuzzopts5)        # fuzzopts5 [NSETS [SEED]]: the config-5 chain (cold start -> interpolate -> prepare -> step; sorted, class-range kernels through
+                  # hiprtc) under random option sets (OPT_RUN 1..4: the global grid carries no MMF planes), sample vs the oracle
+  nsets=${1:-8}; seed=${2:-515}; : > $O/fuzzopts5.log
+  python3 - $nsets $seed > $O/sets.txt <<'PY'
+import sys
+import numpy as np
+r = np.random.Generator(np.random.Philox(int(sys.argv[2])))
+rng = dict(idveg=(1, 5), iopt_crs=(1, 2), iopt_btr=(1, 3), iopt_run=(1, 4), iopt_sfc=(1, 2), iopt_frz=(1, 2), iopt_inf=(1, 2), iopt_rad=(1, 3),
+           iopt_alb=(1, 2), iopt_snf=(1, 3), iopt_tbot=(1, 2), iopt_stc=(1, 2))
+for n in range(int(sys.argv[1])):
+    print(" ".join("%s=%d" % (k, r.integers(lo, hi + 1)) for k, (lo, hi) in rng.items()))
+PY
+  while read o; do
+    timeout 900 python tools/config5_run.py 720 360 72 8192 $o 2>&1 | tail -1 | python3 -c "import sys,json
+try:
+    d=json.loads(sys.stdin.read()); print(d['options'], 'sample_bit_identical', d['sample_bit_identical'], d['checkpoints'], 'status_max', d.get('device_status_max'))
+except Exception as e: print('FAILED', '$o', e)" | tee -a $O/fuzzopts5.log
   done < $O/sets.txt
   ;;
 profile)
