@@ -179,6 +179,45 @@ def test_tile_split_invariance(engine, tables):
         np.testing.assert_array_equal(whole.a[k], parts.a[k], err_msg=k)
 
 
+def test_empty_and_one_cell_tiles(engine, tables):
+    """A rank whose tile is empty (ite < its or jte < jts: more ranks than rows) advances nothing and touches nothing; a one-cell tile
+    in a corner of the memory block advances exactly that column -- host and device arrays, synchronous and asynchronous call."""
+    import ctypes as C
+    from noahmp_amd import abi
+    s = synth.mixed_small(tables[1], ni=48, nj=6)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 12, t_offset=s.t_offset)
+    whole = s.copy()
+    engine.noahmplsm(whole, 2, 2000, 180.0)
+    for mem in (abi.MEM_HOST, abi.MEM_DEVICE):
+        work = s.copy()
+        blk = work if mem == abi.MEM_HOST else work.to_device("cuda:0")
+        for (i0, i1, j0, j1) in ((5, 4, 1, 6), (1, 48, 3, 2)):                  # empty in i, empty in j
+            a = blk.step_args(2, 2000, 180.0)
+            a.its, a.ite, a.jts, a.jte = i0, i1, j0, j1
+            st = abi.Status()
+            assert engine.lib.noahmp_hip_step(C.byref(a), mem, None, C.byref(st)) == 0
+            assert (st.n_land, st.n_glacier, st.n_skipped, st.code) == (0, 0, 0, 0)
+            assert engine.lib.noahmp_hip_step_async(C.byref(a), None) == 0
+            st2, _ = engine.sync()
+            assert (st2.n_land, st2.n_glacier, st2.code) == (0, 0, 0)
+        got = work if mem == abi.MEM_HOST else blk.to_host()
+        for k in _outs(whole):
+            np.testing.assert_array_equal(got.a[k], s.a[k], err_msg=k)          # nothing was touched
+        a = blk.step_args(2, 2000, 180.0)
+        a.its, a.ite, a.jts, a.jte = 48, 48, 6, 6                               # the last cell of the block
+        st = abi.Status()
+        assert engine.lib.noahmp_hip_step(C.byref(a), mem, None, C.byref(st)) == 0
+        assert st.n_land + st.n_glacier + st.n_skipped == 1
+        got = work if mem == abi.MEM_HOST else blk.to_host()
+        for k in _outs(whole):
+            x, y, z = got.a[k], whole.a[k], s.a[k]
+            np.testing.assert_array_equal(x[-1, ..., -1], y[-1, ..., -1], err_msg=k)
+            m = np.ones(x.shape, bool)
+            m[-1, ..., -1] = False
+            np.testing.assert_array_equal(x[m], z[m], err_msg=k)
+
+
 def test_permutation_invariance_large(engine, tables):
     """Size-independent property at 262 144 columns: columns are independent, so permuting them
     permutes the results bit-for-bit (catches any cross-column / indexing / race error)."""
