@@ -27,6 +27,7 @@ struct Engine {
   unsigned long long* h_err = nullptr;   // pinned
   int* h_counts = nullptr;               // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_timed = false;                    // ev0 / ev1 were recorded by the resident-path call now pending (not for an empty tile)
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;      // land-ice / skipped class kernels beside the land kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;

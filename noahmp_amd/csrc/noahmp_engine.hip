@@ -293,11 +293,12 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
 // class_ranges: the call is a whole device-resident tile, the only kind of call the declared class ranges can describe
 // ev: the step's three timing events (noahmp_hip_sync_timing): start | end of the land (or only) kernel | end of the land-ice + skipped
 // kernels.  Every event is one more packet between two kernels of the caller's stream (~5 us each on this chip), so they double as the
-// fork / join events of the second stream and nothing else is recorded; g.last_launch_kind tells noahmp_hip_sync which of them exist.
+// fork / join events of the second stream and nothing else is recorded; g.last_launch_kind tells noahmp_hip_sync which of them exist
+// (-1: an empty tile, none).
 static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false, hipEvent_t* ev = nullptr) {
   const long ncol = (long)k.nti * k.ntj;
   g.last_launch_kind = 0;
-  if (ncol <= 0) { if (ev) { hipEventRecord(ev[0], s); hipEventRecord(ev[1], s); } return; }
+  if (ncol <= 0) { g.last_launch_kind = -1; return; }          // an empty tile: nothing is enqueued, no event is recorded (kind -1: no times)
   // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
   if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
       g.block == 256 && g.use_lds) {
@@ -468,7 +469,7 @@ static bool level1_only(const FieldDesc& fd) {
 
 static void fill_status(const noahmp_step_args* a, int nti, noahmp_status* st, int* code_out) {
   float ms = 0.f;
-  hipEventElapsedTime(&ms, g.ev0, g.ev1);
+  if (g.ev_timed) hipEventElapsedTime(&ms, g.ev0, g.ev1);
   int code = 0;
   if (st) {
     st->kernel_ms = ms;
@@ -566,10 +567,11 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
   HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
-  HIPCHK(hipEventRecord(g.ev0, s));
+  g.ev_timed = (long)k.nti * k.ntj > 0;                // (an empty tile records no events: see noahmp_hip_step)
+  if (g.ev_timed) HIPCHK(hipEventRecord(g.ev0, s));
   launch_any(k, s);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.ev1, s));
+  if (g.ev_timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
   g.resident_calls++;
@@ -674,10 +676,11 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
   HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
-  HIPCHK(hipEventRecord(g.ev0, s));
+  const bool timed = (long)k.nti * k.ntj > 0;          // an empty tile: no kernel, no events (two records with nothing between them
+  if (timed) HIPCHK(hipEventRecord(g.ev0, s));         // send hipEventElapsedTime down a marker-inserting path of the runtime)
   launch_any(k, s, mem == NOAHMP_MEM_DEVICE);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.ev1, s));
+  if (timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
 
@@ -691,7 +694,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   }
   HIPCHK(hipStreamSynchronize(s));
   float ms = 0.f;
-  hipEventElapsedTime(&ms, g.ev0, g.ev1);
+  if (timed) hipEventElapsedTime(&ms, g.ev0, g.ev1);
   int code = 0;
   if (st) {
     st->kernel_ms = ms;
@@ -769,6 +772,7 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
       hipEvent_t* e = &g.async_events[3 * i];
       const int kind = i < (int)g.async_kind.size() ? g.async_kind[i] : 0;
       float land = 0.f, rest = 0.f;
+      if (kind < 0) continue;                            // an empty tile: no kernel, no events
       hipEventElapsedTime(&land, e[0], e[1]);
       if (kind) hipEventElapsedTime(&rest, e[kind == 2 ? 0 : 1], e[2]);
       if (rest < 0.f) rest = 0.f;

@@ -208,12 +208,11 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     }
   }
 
-  if (!enqueue_only) {
-    HIPCHK(hipMemsetAsync(g.d_counts, 0, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), s));
-    HIPCHK(hipEventRecord(g.ev0, s));
-  }
   const int hni = k.hi1 - k.hi0 + 1, hnj = k.hj1 - k.hj0 + 1;
   const int tni = a->ite - a->its + 1, tnj = a->jte - a->jts + 1;
+  const bool timed = !enqueue_only && tni > 0 && tnj > 0;       // an empty tile: no kernel, no events
+  if (!enqueue_only) HIPCHK(hipMemsetAsync(g.d_counts, 0, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), s));
+  if (timed) HIPCHK(hipEventRecord(g.ev0, s));
   if (hni > 0 && hnj > 0 && part != 2)
     hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX * HEAD_ILP - 1) / (BX * HEAD_ILP), (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
   if (init) {
@@ -230,7 +229,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   }
   HIPCHK(hipGetLastError());
   if (enqueue_only) return 0;
-  HIPCHK(hipEventRecord(g.ev1, s));
+  if (timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
   if (mem == NOAHMP_MEM_HOST) {
     for (int f = 0; f < kNW; f++) {
@@ -243,7 +242,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   HIPCHK(hipStreamSynchronize(s));
   if (st) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    if (timed) hipEventElapsedTime(&ms, g.ev0, g.ev1);
     st->kernel_ms = ms;
     int cnt[4];
     nmp_host::sum_counts(cnt);

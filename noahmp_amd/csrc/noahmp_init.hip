@@ -78,13 +78,14 @@ extern "C" int noahmp_hip_init(const noahmp_step_args* a, int iswater, int fndsn
   }
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
-  HIPCHK(hipEventRecord(g.ev0, s));
+  const bool timed = nti > 0 && ntj > 0;               // an empty tile: no kernel, no events
+  if (timed) HIPCHK(hipEventRecord(g.ev0, s));
   if (nti > 0 && ntj > 0) {
     const long n = (long)nti * ntj;
     hipLaunchKernelGGL(noahmp_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
   }
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(g.ev1, s));
+  if (timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   if (mem == NOAHMP_MEM_HOST) {
     for (int f = 0; f < kNI; f++) {
@@ -98,7 +99,7 @@ extern "C" int noahmp_hip_init(const noahmp_step_args* a, int iswater, int fndsn
   int code = 0;
   if (st) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, g.ev0, g.ev1);
+    if (timed) hipEventElapsedTime(&ms, g.ev0, g.ev1);
     st->kernel_ms = ms;
     st->n_land = nti > 0 && ntj > 0 ? nti * ntj : 0;
   }
