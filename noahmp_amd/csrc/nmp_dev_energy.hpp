@@ -246,7 +246,7 @@ NMP_DEV RadOut radiation(const Ctx& c, const Parm& P, Col& s, float smc1, const 
   float fsun = 0.f;
   s.bgap = 0.f; s.wgap = 0.f;
   const float vai = s.elai + s.esai;
-  if (s.cosz > 0.f) {                                   // lsm:2356: whole block skipped at night
+  if (!(s.cosz <= 0.f)) {                               // lsm:2356 IF(COSZ <= 0) GOTO 100: skipped at night -- a NaN COSZ is not
     float wl = s.elai / nmp_max(vai, MPE);
     float ws = s.esai / nmp_max(vai, MPE);
     float rho[2], tau[2], albsnd[2], albsni[2];
@@ -1219,7 +1219,7 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   q.cwp = P.cwpvt;
   NMP_TIC(2);    // energy: preamble
   RadP rp = {};
-  if (s.cosz > 0.f) rp = radiation_rows(T, v);          // their round trip runs under THERMOPROP
+  if (!(s.cosz <= 0.f)) rp = radiation_rows(T, v);      // their round trip runs under THERMOPROP
   thermoprop(c, P, s, y, df, hcpct, fact);
   NMP_TIC(3);    // thermoprop
   r = radiation(c, P, s, y.smc[L(1)], rp);

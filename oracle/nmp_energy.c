@@ -230,7 +230,7 @@ static void radiation(const nmp_ctx* c, int ist, int isc, int ice, real sneqvo, 
   real fage, vai, wl, ws, gdir = 0.f, ext;
   *bgap = 0.f; *wgap = 0.f; *fsun = 0.f;
   (void)ice;
-  if (cosz > 0.f) {
+  if (!(cosz <= 0.f)) {                          /* lsm:2356 IF(COSZ <= 0) GOTO 100: a NaN COSZ is not skipped */
     for (int ib = 0; ib < 2; ib++) {
       vai = elai + esai;
       wl = elai / MAXF(vai, MPE);

@@ -6,7 +6,8 @@ a few steps, every output compared bit for bit after every step.
                                                      seed because the reference STOPs the process on a fatal column)
   fuzz_parity.py emul [nseeds ncol] [opt=val ...]   device source compiled for the host vs the restatement (no GPU needed)
   fuzz_parity.py gpu  [nseeds ncol] [opt=val ...]   HIP engine vs the restatement (GPU box)
-  further keys: scalars=1 (DT / DZS / YR / JULIAN / ZLVL drawn per seed), modis=1 (MODIS tables and categories), steps=N (default 3)
+  further keys: scalars=1 (DT / DZS / YR / JULIAN / ZLVL drawn per seed), modis=1 (MODIS tables and categories), steps=N (default 3),
+  nan=1 (NaN / Inf / huge / denormal forcing words on 3 % of the columns; nan=2: state words too)
 
 Columns on which the restatement reports a fatal code (energy / water balance stops of the reference) are replaced by a benign
 column before the comparison and counted.
@@ -126,7 +127,8 @@ def one_seed(mode, seed, ncol, kw):
     global YR, JUL, NSTEPS
     kw = dict(kw)
     YR, JUL = 2000, 180.0
-    NSTEPS = kw.pop("steps", 3)                   # steps=N: a longer free run under the same (constant) forcing
+    NSTEPS = kw.pop("steps", 3)
+    poison = kw.pop("nan", 0)                   # steps=N: a longer free run under the same (constant) forcing
     if kw.pop("scalars", 0):
         sc, YR, JUL = draw_scalars(seed)
         kw.update(sc)
@@ -166,6 +168,21 @@ def one_seed(mode, seed, ncol, kw):
         for k in ("waxy", "wtxy", "deeprechxy", "rechxy"):
             s[k] = 0.0
     synth.first_step_fixups(s)
+    if poison:                                    # nan=1: 3 % of the columns get one forcing word no model run should see
+        r = np.random.Generator(np.random.Philox(seed + 104729))
+        cols = np.flatnonzero(r.random(ncol) < 0.03)
+        cols = cols[cols != 0]
+        keys = ("t3d", "qv3d", "u_phy", "v_phy", "p8w3d", "swdown", "glw", "rainbl", "coszin")
+        if poison >= 2:                           # nan=2: any float INOUT word of the state as well
+            from noahmp_amd.abi import FIELD_INFO
+            keys = keys + tuple(k for k in s.a if k in FIELD_INFO and FIELD_INFO[k][2] == "inout" and s.a[k].dtype == np.float32)
+        vals = (np.nan, np.inf, -np.inf, 0.0, -1.0e30, 1.0e30, 1.0e-42, -0.0)
+        for c in cols:
+            k = keys[r.integers(len(keys))]
+            if s.a[k].ndim == 3 and poison >= 2:
+                s.a[k][0, r.integers(s.a[k].shape[1]), c] = F(vals[r.integers(len(vals))])      # one level
+            else:
+                s.a[k][0, ..., c] = F(vals[r.integers(len(vals))])
     nrep = clean(port, s, 1)
     skip = SFC2_UNDEF if kw.get("iopt_sfc") == 2 else ()
     if mode == "ref":
