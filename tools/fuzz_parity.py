@@ -7,7 +7,7 @@ a few steps, every output compared bit for bit after every step.
   fuzz_parity.py emul [nseeds ncol] [opt=val ...]   device source compiled for the host vs the restatement (no GPU needed)
   fuzz_parity.py gpu  [nseeds ncol] [opt=val ...]   HIP engine vs the restatement (GPU box)
   further keys: scalars=1 (DT / DZS / YR / JULIAN / ZLVL drawn per seed), modis=1 (MODIS tables and categories), steps=N (default 3),
-  nan=1 (NaN / Inf / huge / denormal forcing words on 3 % of the columns; nan=2: state words too)
+  nan=1 (NaN / Inf / huge / denormal forcing words on 3 % of the columns; nan=2: state words too), soil=1 (soil classes 13, 15-19 on land as well)
 
 Columns on which the restatement reports a fatal code (energy / water balance stops of the reference) are replaced by a benign
 column before the comparison and counted.
@@ -28,6 +28,7 @@ from tools.compare import exact_check  # noqa: E402
 
 F = np.float32
 NSTEPS = 3
+WIDE_SOIL = 0
 YR, JUL = 2000, 180.0
 SFC2_UNDEF = ("t2mvxy", "t2mbxy", "q2mvxy", "q2mbxy", "chv2xy", "chb2xy")
 
@@ -40,6 +41,8 @@ def random_tile(tb, ncol, seed, cfg):
     shp = (nj, ni)
     a["ivgtyp"][...] = r.integers(1, int(tb.get("lucats", 27)) + 1, size=shp)
     a["isltyp"][...] = r.integers(1, 13, size=shp)
+    if WIDE_SOIL:                                 # soil=1: every class of the table except water (14: FRZX of soil 14 is the documented difference)
+        a["isltyp"][...] = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 19])[r.integers(0, 18, size=shp)]
     ice = a["ivgtyp"] == cfg.isice
     water = a["ivgtyp"] == cfg.iswater
     a["isltyp"][ice] = 16
@@ -124,11 +127,12 @@ def draw_scalars(seed):
 
 
 def one_seed(mode, seed, ncol, kw):
-    global YR, JUL, NSTEPS
+    global YR, JUL, NSTEPS, WIDE_SOIL
     kw = dict(kw)
     YR, JUL = 2000, 180.0
     NSTEPS = kw.pop("steps", 3)
-    poison = kw.pop("nan", 0)                   # steps=N: a longer free run under the same (constant) forcing
+    poison = kw.pop("nan", 0)
+    WIDE_SOIL = kw.pop("soil", 0)                   # steps=N: a longer free run under the same (constant) forcing
     if kw.pop("scalars", 0):
         sc, YR, JUL = draw_scalars(seed)
         kw.update(sc)
