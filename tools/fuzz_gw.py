@@ -28,6 +28,17 @@ for seed in range(1, 25):
     a0["eqwtd"][...] = -(10 ** r.uniform(-1, 1.7, size=shp)).astype(F)
     a0["riverbed"][...] = a0["eqwtd"] - r.uniform(0, 3, size=shp).astype(F)
     a0["xice"][...] = np.where(r.random(shp) < 0.02, 1.0, 0.0).astype(F)
+    if os.environ.get("NMP_FUZZ_POISON"):         # NaN / Inf / huge / denormal in one word of 2 % of the cells
+        vals = (np.nan, np.inf, -np.inf, 0.0, -1.0e30, 1.0e30, 1.0e-42, -0.0)
+        keys = ("zwtxy", "eqwtd", "riverbed", "fdepth", "pexp", "rivercond", "smois", "sh2o", "smoiseq", "deeprechxy", "rechxy", "smcwtdxy")
+        keys = [k for k in keys if k in a0]
+        for cidx in np.argwhere(r.random(shp) < 0.02):
+            k = keys[r.integers(len(keys))]
+            v = F(vals[r.integers(len(vals))])
+            if a0[k].ndim == 3:
+                a0[k][cidx[0], r.integers(a0[k].shape[1]), cidx[1]] = v
+            else:
+                a0[k][cidx[0], cidx[1]] = v
     a, b, c = s0.copy(), s0.copy(), s0.copy()
     for it in range(3):
         ref.wtable_mmf(a); port.wtable_mmf(b); em.wtable_mmf(c)

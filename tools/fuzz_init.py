@@ -22,6 +22,15 @@ for seed in range(1, 13):
     s["isltyp"] = r.integers(1, 20, size=s["isltyp"].shape).astype(np.int32)      # every soil class incl. 14 water, 15 bedrock, 16 ice
     s["isltyp"][s["ivgtyp"] == cfg.isice] = 16
     s["xice"] = np.where(r.random(s["xice"].shape) < 0.03, 1.0, 0.0).astype(F)
+    if os.environ.get("NMP_FUZZ_POISON"):         # NaN / Inf / huge / denormal in one input word of 3 % of the columns
+        vals = (np.nan, np.inf, -np.inf, 0.0, -1.0e30, 1.0e30, 1.0e-42, -0.0)
+        keys = ("tsk", "tmn", "canwat", "tslb", "smois")          # (a NaN snow depth is a fatal of the reference: SNOW_INIT stops the process)
+        for c in np.flatnonzero(r.random(8192) < 0.03):
+            k = keys[r.integers(len(keys))]
+            if s.a[k].ndim == 3:
+                s.a[k][0, r.integers(s.a[k].shape[1]), c] = F(vals[r.integers(len(vals))])
+            else:
+                s.a[k][0, c] = F(vals[r.integers(len(vals))])
     for fnd in (True, False):
         a, b, c = s.copy(), s.copy(), s.copy()
         ref.noahmp_init(a, fndsnowh=fnd); ref.set_tables(T)
