@@ -76,3 +76,20 @@ def test_poisoned_inputs_device_source_on_host_vs_oracle(port):
 def test_gpu_vs_oracle_poisoned_inputs(engine, port):
     assert fuzz_parity.one_seed("gpu", 3, 4096, dict(nan=1, scalars=1)) == 0
     assert fuzz_parity.one_seed("gpu", 2, 4096, dict(nan=2, scalars=1)) == 0
+
+
+# further dimensions of tools/fuzz_parity.py, one cheap case each on the CPU (the wide runs are in profiles/r04_parity.md)
+WIDE = [dict(modis=1, scalars=1, idveg=2, iopt_crs=2), dict(soil=1, scalars=1, iopt_run=3, iopt_frz=2), dict(steps=12, idveg=5, iopt_btr=2)]
+
+
+@pytest.mark.parametrize("kw", WIDE, ids=[repr(k) for k in WIDE])
+def test_device_source_on_host_vs_oracle_wide(port, kw):
+    assert fuzz_parity.one_seed("emul", 77, 2048, kw) == 0
+
+
+def test_oracle_vs_compiled_reference_wide(reflib, port):
+    import subprocess
+    import sys
+    for kw in WIDE[:2]:
+        rc = subprocess.call([sys.executable, fuzz_parity.__file__, "ref", "1", "2048"] + ["%s=%d" % kv for kv in kw.items()] + ["--seed:78"])
+        assert rc == 0, kw

@@ -212,3 +212,14 @@ def test_runtime_specialisation_compiles_without_gpu_and_fills_the_disk_cache(tm
     files = os.listdir(str(tmp_path))
     assert len(files) == 1 and files[0].startswith("nmp_gfx950_o2_2_2_3_1_2_2_1_1_3_1_2_") and files[0].endswith(".hsaco")
     assert str(tmp_path) in outs[0]
+
+
+def test_staleness_result_without_a_pending_count_is_an_error():
+    """noahmp_hip_sort_staleness_result before any noahmp_hip_sort_staleness_async: -105, no GPU touched."""
+    import ctypes as C
+    from noahmp_amd import abi
+    lib = abi.load_library()
+    changed = C.c_int64(7)
+    assert lib.noahmp_hip_sort_staleness_result(C.byref(changed), 0) == -105
+    assert lib.noahmp_hip_sort_staleness_result(None, 1) == -105
+    assert b"no pending count" in lib.noahmp_hip_last_error()
