@@ -412,8 +412,9 @@ class Run:
         per_step = self.eng.sync_step_timing()            # land (or mixed) kernel of every step since the last sync, by forcing hour
         for h, ms in zip(self.step_hours[len(self.step_hours) - len(per_step):], per_step):
             self.hour_ms.setdefault(h, []).append(ms)
-        self.n_adv += st.n_land + st.n_glacier
-        self.n_land += st.n_land
+        n_land, n_glacier, _ = self.eng.sync_counts()    # 64-bit: a sync over hundreds of steps of 7 M columns passes 2^31 (Status is int32)
+        self.n_adv += n_land + n_glacier
+        self.n_land += n_land
         return st
 
     def maybe_resort(self):

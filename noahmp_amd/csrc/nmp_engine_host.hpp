@@ -51,8 +51,9 @@ struct Engine {
   float sync_class_ms[3] = {0.f, 0.f, 0.f};   // noahmp_hip_sync_timing
   int sync_steps = 0;
   std::vector<float> sync_step_ms;            // noahmp_hip_sync_step_timing: land (or mixed) kernel of each step of the last sync
-  std::vector<char> async_kind;               // per pending step: launch_any's kind (0 one kernel, 1 class kernels in a row, 2 forked)
+  std::vector<signed char> async_kind;              // per pending step: launch_any's kind (0 one kernel, 1 class kernels in a row, 2 forked)
   int last_launch_kind = 0;
+  long long last_counts[3] = {0, 0, 0};       // 64-bit tallies behind the last status (noahmp_hip_sync_counts)
   int deferred_code = 0;                      // fatal code of a deferred step that no call has returned yet
   // host-memory path: row-chunk pipeline H2D | kernel | D2H on three streams, optional pinning of the caller's arrays
   hipStream_t s_up = nullptr, s_dn = nullptr;
@@ -123,7 +124,8 @@ void sort_finalize();     // noahmp_sort.hip
 
 int ensure_init();
 // sum the slots of h_counts into out[0..3]
-void sum_counts(int* out);
+void sum_counts(long long* out);
+void status_counts(noahmp_status* st);     // ... into the int32 members of a status (saturated)
 // grow-only device buffer
 int ensure_bytes(void** p, size_t* have, size_t need);
 

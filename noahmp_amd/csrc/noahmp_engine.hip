@@ -53,10 +53,19 @@ int ensure_init() {
   return 0;
 }
 
-void sum_counts(int* out) {
+void sum_counts(long long* out) {
   for (int c = 0; c < 4; c++) out[c] = 0;
   for (int s = 0; s < kCountSlots; s++)
     for (int c = 0; c < 4; c++) out[c] += g.h_counts[s * kCountStride + c];
+  for (int c = 0; c < 3; c++) g.last_counts[c] = out[c];
+}
+// the tallies as noahmp_status carries them (int32): one step always fits; a sync over many steps saturates and the caller
+// reads the 64-bit sums through noahmp_hip_sync_counts
+void status_counts(noahmp_status* st) {
+  long long cnt[4];
+  sum_counts(cnt);
+  auto sat = [](long long v) { return (int32_t)(v > 0x7FFFFFFFll ? 0x7FFFFFFFll : v); };
+  st->n_land = sat(cnt[0]); st->n_glacier = sat(cnt[1]); st->n_skipped = sat(cnt[2]);
 }
 
 int ensure_bytes(void** p, size_t* have, size_t need) {
@@ -436,9 +445,7 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
     float ms = 0.f;
     for (int c = 0; c < nchunk; c++) { float one = 0.f; hipEventElapsedTime(&one, g.pipe_events[3 * c + 1], g.pipe_events[3 * c + 2]); ms += one; }
     st->kernel_ms = ms;
-    int cnt[4];
-    nmp_host::sum_counts(cnt);
-    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+    nmp_host::status_counts(st);
   }
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);
@@ -473,9 +480,7 @@ static void fill_status(const noahmp_step_args* a, int nti, noahmp_status* st, i
   int code = 0;
   if (st) {
     st->kernel_ms = ms;
-    int cnt[4];
-    nmp_host::sum_counts(cnt);
-    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+    nmp_host::status_counts(st);
   }
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);
@@ -698,9 +703,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   int code = 0;
   if (st) {
     st->kernel_ms = ms;
-    int cnt[4];
-    nmp_host::sum_counts(cnt);
-    st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+    nmp_host::status_counts(st);
   }
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);
@@ -726,6 +729,17 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   }
   KArgs k;
   fill_kargs(k, a);
+  {
+    // the device tallies are int32 per slot (a slot takes the workgroups b with b mod kCountSlots equal): refuse a step that could
+    // wrap one before the next noahmp_hip_sync (7 M columns: ~77 000 pending steps); the sums over the slots are 64-bit
+    // (noahmp_hip_sync_counts).  The step ordinal of the error word has 24 bits.
+    const long long ncol = (long long)k.nti * k.ntj;
+    const long long per_slot = ((ncol + 255) / 256 + kCountSlots - 1) / kCountSlots * 256;
+    if ((long long)(g.async_pending + 1) * per_slot > 0x7FFFFFFFll || g.async_pending >= (1 << 24) - 1) {
+      g.last_error = "noahmp_hip_step_async: too many pending steps for the device tallies, call noahmp_hip_sync() first";
+      return -107;
+    }
+  }
   k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
   // three events per step (launch_any): kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
   // else the caller puts on the stream between them
@@ -737,7 +751,7 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   launch_any(k, s, true, &g.async_events[3 * g.async_pending]);
   HIPCHK(hipGetLastError());
   if ((int)g.async_kind.size() <= g.async_pending) g.async_kind.resize(g.async_pending + 1);
-  g.async_kind[g.async_pending] = (char)g.last_launch_kind;
+  g.async_kind[g.async_pending] = (signed char)g.last_launch_kind;
   g.async_pending++;
   g.async_stream = s;
   bool known = false;
@@ -784,9 +798,7 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
     g.sync_steps = nsteps;
     if (st) {
       st->kernel_ms = ms;
-      int cnt[4];
-      nmp_host::sum_counts(cnt);
-      st->n_land = cnt[0]; st->n_glacier = cnt[1]; st->n_skipped = cnt[2];
+      nmp_host::status_counts(st);
     }
   }
   if (*g.h_err != ~0ULL) {
@@ -836,6 +848,13 @@ int noahmp_hip_permute_step_arrays(const noahmp_step_args* src, const noahmp_ste
 // unsorted tile), out[1] = land-ice kernel, out[2] = skipped-cell kernel [ms, summed over the steps]; returns the number of steps.
 int noahmp_hip_sync_timing(float* out, int n) {
   for (int c = 0; c < n && c < 3; c++) out[c] = g.sync_class_ms[c];
+  return g.sync_steps;
+}
+
+// 64-bit tallies of the last noahmp_hip_sync (or synchronous step): out[0..2] = land, land-ice, skipped columns summed over its
+// steps (noahmp_status carries them as int32, saturated); returns the number of steps of that sync.
+int noahmp_hip_sync_counts(int64_t* out, int n) {
+  for (int c = 0; c < n && c < 3; c++) out[c] = (int64_t)g.last_counts[c];
   return g.sync_steps;
 }
 

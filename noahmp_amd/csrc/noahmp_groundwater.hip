@@ -244,10 +244,10 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     float ms = 0.f;
     if (timed) hipEventElapsedTime(&ms, g.ev0, g.ev1);
     st->kernel_ms = ms;
-    int cnt[4];
-    nmp_host::sum_counts(cnt);
-    st->n_land = cnt[0];
-    st->n_skipped = cnt[2];
+    noahmp_status t;
+    nmp_host::status_counts(&t);
+    st->n_land = t.n_land;
+    st->n_skipped = t.n_skipped;
   }
   return 0;
 }

@@ -48,7 +48,9 @@ __device__ __forceinline__ unsigned column_key(const KeyArgs& k, long p) {
 }
 constexpr unsigned kTskMask = 0xFFu;
 constexpr int kKeyBits = 23;
-const int* g_band_plane = nullptr;      // host-side: the plane the next sort / staleness call reads (device pointer, the store's column order)
+// host-side: the plane the NEXT sort / staleness call of this thread reads (device pointer, the store's column order); consumed by that
+// call (fill_key_args), so that a failed or forgotten call leaves nothing behind
+thread_local const int* g_band_plane = nullptr;
 
 __global__ void __launch_bounds__(256) sort_key_kernel(const KeyArgs k, unsigned* keys, int* idx) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,6 +130,7 @@ struct SegOffset {
 int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_mk) {
   if (a->ims != a->its || a->ime != a->ite || a->jms != a->jts || a->jme != a->jte) {
     g.last_error = "column sort: the memory block must be the tile (a tile that carries a halo keeps its (i,j) order)";
+    g_band_plane = nullptr;
     return -105;
   }
   k.xland = a->xland; k.xice = a->xice; k.tsk = a->tsk; k.ivgtyp = a->ivgtyp; k.isnow = a->isnowxy;
@@ -135,6 +138,7 @@ int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_
   if (flags & NOAHMP_SORT_TAIR) { k.tsk = a->t3d; k.t_nk = a->kme - a->kms + 1; k.t_k = 1 - a->kms; }   // the forcing air temperature (level 1)
   k.xice_thres = a->xice_thres; k.isice = a->isice; k.flags = flags;
   k.band = g_band_plane;
+  g_band_plane = nullptr;                 // one-shot (noahmp_hip_sort_set_band)
   k.inv_bin = tsk_bin_mk > 0 ? 1000.0f / (float)tsk_bin_mk : 0.f;
   k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
   return 0;
@@ -173,12 +177,22 @@ int noahmp_hip_sort_set_band(const int32_t* band_plane) {
 
 // buffers of noahmp_hip_sort_staleness_async: allocated when a layout is sorted (allocations synchronise the device -- not inside a run)
 static int ensure_async_count() {
-  if (sc.slots_async) return 0;
-  HIPCHK(hipMalloc(&sc.slots_async, 256 * sizeof(unsigned long long)));
-  HIPCHK(hipMemset(sc.slots_async, 0, 256 * sizeof(unsigned long long)));
-  HIPCHK(hipHostMalloc((void**)&sc.h_async, sizeof(long), hipHostMallocMapped));
-  HIPCHK(hipHostGetDevicePointer((void**)&sc.d_async_word, sc.h_async, 0));
-  HIPCHK(hipEventCreateWithFlags(&sc.ev_async, hipEventDisableTiming));
+  if (sc.slots_async && sc.h_async && sc.d_async_word && sc.ev_async) return 0;
+  auto fail = [](const char* what, hipError_t e) {          // all or nothing: a later call must not find half of the set
+    char b[200]; snprintf(b, sizeof b, "noahmp_hip_sort: %s failed: %s", what, hipGetErrorString(e));
+    g.last_error = b;
+    if (sc.slots_async) hipFree(sc.slots_async);
+    if (sc.h_async) hipHostFree(sc.h_async);
+    if (sc.ev_async) hipEventDestroy(sc.ev_async);
+    sc.slots_async = nullptr; sc.h_async = nullptr; sc.d_async_word = nullptr; sc.ev_async = nullptr;
+    return -100;
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&sc.slots_async, 256 * sizeof(unsigned long long))) != hipSuccess) { sc.slots_async = nullptr; return fail("hipMalloc", e); }
+  if ((e = hipMemset(sc.slots_async, 0, 256 * sizeof(unsigned long long))) != hipSuccess) return fail("hipMemset", e);
+  if ((e = hipHostMalloc((void**)&sc.h_async, sizeof(long), hipHostMallocMapped)) != hipSuccess) { sc.h_async = nullptr; return fail("hipHostMalloc", e); }
+  if ((e = hipHostGetDevicePointer((void**)&sc.d_async_word, sc.h_async, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
+  if ((e = hipEventCreateWithFlags(&sc.ev_async, hipEventDisableTiming)) != hipSuccess) { sc.ev_async = nullptr; return fail("hipEventCreate", e); }
   return 0;
 }
 

@@ -201,7 +201,7 @@ class Engine:
         snow-layer count bounds the layer loops and changes slowly (see sort_staleness), the skin temperature (`tsk_bin`
         K wide bins, 0 = off) is a cheap proxy for the stability / freezing regime a column is in.  Forcing that arrives
         in tile order goes through `scatter`.  band: name of an int32 device plane of the store (values 0..31, static; it is
-        permuted with the state) used as a sub-key between the snow-layer count and the temperature bin (noahmp_hip_sort_set_band),
+        permuted with the state) used as a sub-key between the snow-layer count and the temperature bin (noahmp_hip_sort_set_band: an argument of the next sort / staleness call, consumed by it),
         e.g. the 15-degree longitude band of a lat/lon grid: a wavefront's columns then share their local solar time."""
         import numpy as np
         import torch
@@ -243,7 +243,6 @@ class Engine:
         # classes are contiguous now: land, land ice, skipped -- each range gets its own kernel (noahmp_engine.hip, launch_any)
         store.class_ranges = (int(counts[0]), int(counts[1]))
         store.sort_perm, store.sort_keys, store.sort_flags, store.sort_band = perm, keys, flags, band
-        self.lib.noahmp_hip_sort_set_band(None)
         return perm
 
     def sort_staleness(self, store):
@@ -254,7 +253,6 @@ class Engine:
         band = getattr(store, "sort_band", None)
         self.lib.noahmp_hip_sort_set_band(store.a[band].data_ptr() if band else None)      # the key the store was sorted by
         rc = self.lib.noahmp_hip_sort_staleness(C.byref(a), store.sort_flags, store.sort_keys.data_ptr(), C.byref(changed), None)
-        self.lib.noahmp_hip_sort_set_band(None)
         if rc:
             raise RuntimeError("noahmp_hip_sort_staleness: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return int(changed.value)
@@ -266,7 +264,6 @@ class Engine:
         band = getattr(store, "sort_band", None)
         self.lib.noahmp_hip_sort_set_band(store.a[band].data_ptr() if band else None)
         rc = self.lib.noahmp_hip_sort_staleness_async(C.byref(a), store.sort_flags, store.sort_keys.data_ptr(), stream)
-        self.lib.noahmp_hip_sort_set_band(None)
         if rc:
             raise RuntimeError("noahmp_hip_sort_staleness_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
 
@@ -376,6 +373,12 @@ class Engine:
         out = (C.c_float * 3)()
         n = self.lib.noahmp_hip_sync_timing(out, 3)
         return [float(x) for x in out], n
+
+    def sync_counts(self):
+        """(land, land-ice, skipped) columns summed over the steps of the last sync(), as 64-bit integers (Status carries int32)."""
+        out = (C.c_int64 * 3)()
+        self.lib.noahmp_hip_sync_counts(out, 3)
+        return int(out[0]), int(out[1]), int(out[2])
 
     def sync_step_timing(self):
         """Land (or mixed) kernel ms of every step of the last sync(), in step order."""

@@ -155,3 +155,25 @@ def test_class_range_kernels_and_violation(engine, tables):
         engine.noahmplsm(srt, 3, 2000, 180.0)
     assert e.value.code == 17
     engine.noahmplsm(plain, 3, 2000, 180.0)                    # an undeclared store runs the mixed kernel again
+
+
+def test_tallies_of_a_long_sync_are_64_bit(engine, tables):
+    """More than 2^31 column-steps between two syncs: the int32 members of the status saturate, noahmp_hip_sync_counts is exact
+    (bench.py collects once per timed region: 7 M columns x a few hundred steps)."""
+    s = synth.config2(tables[1])                       # 1024 x 1024 land columns
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 2, t_offset=s.t_offset)   # night: the short kernel
+    d = s.to_device("cuda:0")
+    args = d.step_args(1, 2000, 180.0)
+    ncol = s.ni * s.nj
+    nsteps = (1 << 31) // ncol + 8
+    for it in range(nsteps):
+        args.itimestep = 2 + it
+        engine.noahmplsm_async(args)
+    st, step = engine.sync()
+    assert st.code == 0 and step == -1
+    counts = engine.sync_counts()
+    assert counts[0] == nsteps * ncol and counts[1] == 0 and counts[2] == 0
+    assert counts[0] > (1 << 31) and st.n_land == (1 << 31) - 1
+    st1 = engine.noahmplsm(d, 2 + nsteps, 2000, 180.0)   # a synchronous step: both views agree again
+    assert st1.n_land == ncol and engine.sync_counts()[0] == ncol

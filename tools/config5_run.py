@@ -118,7 +118,7 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
                 st, _ = eng.sync()
                 kernel_ms += st.kernel_ms
                 dev_codes.append(int(st.code))                           # 0 = every column passed the model's own balance checks
-                n_done += st.n_land + st.n_glacier + st.n_skipped
+                n_done += sum(eng.sync_counts())
                 if n + 1 in checkpoints:
                     t_hold = time.perf_counter()
                     inv = torch.empty(ni * nj, dtype=torch.int64, device=dev)
