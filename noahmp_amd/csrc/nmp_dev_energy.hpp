@@ -569,6 +569,12 @@ struct VegIn {
   double r_rhocp, r_gammav, r_gammag;     // 1 / (RHOAIR*CPAIR), 1 / GAMMAV, 1 / GAMMAG (div_rc)
 };
 
+#ifdef NMP_K2_EXPERIMENT
+}  // namespace nmp
+#include "nmp_k2_experiment.hpp"     // profiling build only: k2_dump
+namespace nmp {
+#endif
+
 // ---- the canopy iteration (loop1 of VEGE_FLUX, lsm:3234-3459) as an explicit state machine ------------------
 // Trip counts of this loop run from 6 to NITERC = 20 and differ from column to column: a 64-lane wavefront needs
 // ~18 rounds for a mean of ~9.  Everything an iteration reads or carries is in VegLoop, so
@@ -1285,6 +1291,9 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
     cmv = s.cm;
     s.chv = s.ch;
   }
+#if defined(NMP_K2_EXPERIMENT) && defined(__HIP_DEVICE_COMPILE__)
+  if (live) k2_dump(s, q, canopy);
+#endif
   vege_flux(c, P, s, q, cmv, psnsun, psnsha, canopy, runner);
   NMP_TIC(6);    // vege_flux
   if (!live) return;

@@ -141,9 +141,19 @@ int noahmp_hip_memcpy(void* dst, const void* src, size_t bytes, int kind) {
 }
 void noahmp_hip_free(void* p) { if (p) hipFree(p); }
 
+static void drop_host_regs();
+
+// page-locked registrations of caller arrays that are alive right now ("pin_host_arrays"): the test suite asserts 0 after every test
+int noahmp_hip_debug_live_host_registrations(void) {
+  int n = 0;
+  for (auto& kv : g.host_regs) n += kv.second.state == 1;
+  return n;
+}
+
 int noahmp_hip_set_tables(const noahmp_tables* t) {
   int rc = ensure_init();
   if (rc) return rc;
+  drop_host_regs();           // a new set of tables = a new run of the caller: nothing known about its arrays carries over
   // the ABI struct followed by the per-type constants derived from it (Derived, nmp_dev_common.hpp), evaluated here on the host
   static nmp::TablesDev img;
   img.t = *t;
@@ -173,12 +183,7 @@ int noahmp_hip_set_option(const char* key, int value) {
     prev = g.pin_host_arrays;
     if (value == 0 || value == 1) {
       g.pin_host_arrays = value;
-      if (!value) {                               // leaving the mode: drop every registration (the arrays may be freed now)
-        hipDeviceSynchronize();
-        for (auto& kv : g.host_regs) if (kv.second.state == 1) hipHostUnregister(const_cast<void*>(kv.first));
-        g.host_regs.clear();
-        (void)hipGetLastError();
-      }
+      if (!value) drop_host_regs();               // leaving the mode: drop every registration (the arrays may be freed now)
     }
   }
   else if (!strcmp(key, "trust_out_mirror")) {
@@ -352,15 +357,36 @@ static int check_step_args(const noahmp_step_args* a, noahmp_status* st) {
 }
 
 // hipHostRegister an array of the caller the second time it shows up at the same address (opt-in: the caller guarantees
-// that such arrays outlive the engine or calls noahmp_hip_finalize() first)
+// that such arrays outlive the engine or calls noahmp_hip_finalize() first).  A registration is dropped as soon as the engine can
+// tell that it is stale: an array of another size at the same address, an array at another address that OVERLAPS a known range
+// (two live arrays never overlap, so the known one was freed and its memory reused), noahmp_hip_set_tables, leaving the mode,
+// noahmp_hip_finalize.  A stale registration of freed memory is dangerous beyond the engine: the runtime treats whatever the process
+// maps there next as page-locked.
+static void drop_host_regs() {
+  bool any = false;
+  for (auto& kv : g.host_regs) any = any || kv.second.state == 1;
+  if (any) hipDeviceSynchronize();
+  for (auto& kv : g.host_regs) if (kv.second.state == 1) hipHostUnregister(const_cast<void*>(kv.first));
+  g.host_regs.clear();
+  (void)hipGetLastError();
+}
 static void maybe_pin(const void* host, size_t bytes) {
-  if (!g.pin_host_arrays) return;
+  if (!g.pin_host_arrays || !host || !bytes) return;
+  const char* lo = (const char*)host; const char* hi = lo + bytes;
+  for (auto it = g.host_regs.begin(); it != g.host_regs.end();) {           // ~120 entries at most
+    const char* olo = (const char*)it->first; const char* ohi = olo + it->second.bytes;
+    if (it->first != host && olo < hi && lo < ohi) {
+      if (it->second.state == 1) { hipDeviceSynchronize(); hipHostUnregister(const_cast<void*>(it->first)); }
+      it = g.host_regs.erase(it);
+    } else ++it;
+  }
   auto it = g.host_regs.find(host);
-  if (it == g.host_regs.end()) { g.host_regs[host] = nmp_host::Engine::HostReg{bytes, 1, 0}; return; }
+  if (it == g.host_regs.end()) { g.host_regs[host] = nmp_host::Engine::HostReg{bytes, 1, 0}; (void)hipGetLastError(); return; }
   nmp_host::Engine::HostReg& r = it->second;
   if (r.bytes != bytes) {
-    if (r.state == 1) hipHostUnregister(const_cast<void*>(host));
+    if (r.state == 1) { hipDeviceSynchronize(); hipHostUnregister(const_cast<void*>(host)); }
     r = nmp_host::Engine::HostReg{bytes, 1, 0};
+    (void)hipGetLastError();
     return;
   }
   r.seen++;
@@ -934,7 +960,7 @@ void noahmp_hip_finalize(void) {
   for (auto& p : g.init_mirror) { if (p) hipFree(p); p = nullptr; }
   for (auto e : g.async_events) hipEventDestroy(e);
   for (auto e : g.pipe_events) hipEventDestroy(e);
-  for (auto& kv : g.host_regs) if (kv.second.state == 1) hipHostUnregister(const_cast<void*>(kv.first));
+  drop_host_regs();
   if (g.s_up) hipStreamDestroy(g.s_up);
   if (g.s_dn) hipStreamDestroy(g.s_dn);
   if (g.gw_kcell) hipFree(g.gw_kcell);

@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _no_live_host_registrations():
+    """After every test: the engine holds no page-locked registration of a caller array ("pin_host_arrays").  A registration that
+    outlives the array it was made for lets the runtime treat whatever the process maps there next as page-locked memory --
+    the signature of the sporadic "Memory access fault by GPU ... Write access to a read-only page" of round 4."""
+    yield
+    from noahmp_amd import abi
+    lib = getattr(abi, "_lib", None)
+    if lib is not None:
+        n = lib.noahmp_hip_debug_live_host_registrations()
+        if n:
+            lib.noahmp_hip_set_option(b"pin_host_arrays", 0)          # do not let one leak fail every later test
+        assert n == 0, "%d host arrays are still page-locked by the engine after this test" % n
+
+
 @pytest.fixture(scope="session")
 def tables():
     from noahmp_amd.tables import load_tables

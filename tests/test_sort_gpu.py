@@ -3,6 +3,8 @@ BASELINE configs[2] workload at its full size.  north_star: columns sorted by (v
 the snow-layer count changes at lsm:7044 (COMBINE), 7110 (DIVIDE), 7177 (COMBO), 7294-7343 (SNOWH2O), so a run re-sorts."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -30,11 +32,15 @@ def _up(x):
     host-heap address inside torch's own copy -- the runtime page-locks a pageable buffer where it lies.  Nothing of the engine is
     involved in those copies; page-locked staging keeps the test about the plan.)"""
     import torch
+    if os.environ.get("NMP_TEST_PAGEABLE_COPIES"):          # the round-4 behaviour, for the fault hunt (tools/experiments.sh faulthunt)
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
     return torch.from_numpy(np.ascontiguousarray(x)).pin_memory().cuda()
 
 
 def _down(t):
     import torch
+    if os.environ.get("NMP_TEST_PAGEABLE_COPIES"):
+        return t.cpu().numpy()
     h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     h.copy_(t)
     return h.numpy()

@@ -18,6 +18,10 @@
 #   pmc5 [BAND...]                 config 5: lane utilisation / instructions per wave of the land kernel for longitude-band widths
 #   band [WIDTH...]                config 5 bench for longitude-band widths (degrees; 0 = no band key)
 #   phase [LIB...]                 phase shares of the profiling build (-DNMP_PHASE_TIMERS: variants/lib_prof.so), after an optional A/B
+#   k2                             the flux solvers as a kernel of their own (variants/lib_k2.so: -DNMP_K2_EXPERIMENT) at 1..4 waves per SIMD, and
+#                                  the land kernel truncated before / behind them (lib_t3.so, lib_t7.so: -DNMP_TRUNC=3 / 7)
+#   faulthunt [N [pageable]]       the whole -m gpu suite N times (default 10), each in its own process, with the abort shim; `pageable`: the
+#                                  sort tests' large copies through pageable memory (the round-4 condition of the sporadic GPU memory fault)
 #   micro NAME                     run tools/micro/NAME.bin (built in the dev container: hipcc --offload-arch=gfx950 -O3 NAME.hip -o NAME.bin)
 #   fuzz [SEEDS [COLUMNS]]         randomised GPU-vs-oracle runs over option sets (tools/fuzz_parity.py) + a config-5 chain
 #   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
@@ -173,6 +177,29 @@ phase)
   [ $# -gt 0 ] && "$0" ab "$@"
   NMP_PHASE_PROF=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_prof.so timeout 600 python bench.py --steps 24 --warmup 2 $QUIET > $O/prof.json 2> $O/prof.err
   grep "^phase" $O/prof.err; grep -v "^phase" $O/prof.err | tail -3
+  ;;
+k2)
+  NMP_K2_EXP=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_k2.so timeout 900 python bench.py --steps 24 --warmup 2 $QUIET --no-options-reference --no-host-path-reference > $O/k2.json 2> $O/k2.err
+  grep "^K2EXP" $O/k2.err; grep -v "^K2EXP" $O/k2.err | tail -3
+  for v in t3 t7; do
+    [ -f noahmp_amd/csrc/variants/lib_$v.so ] || continue
+    NMP_LIB=$R/noahmp_amd/csrc/variants/lib_$v.so timeout 600 python bench.py $QUIET --no-options-reference --no-host-path-reference --steps 24 --warmup 6 --resort-every 0 > $O/$v.json 2> $O/$v.err
+    summarise $O/$v.json $v
+  done
+  timeout 600 python bench.py $QUIET --no-options-reference --no-host-path-reference --steps 24 --warmup 6 --resort-every 0 > $O/default.json 2> $O/default.err
+  summarise $O/default.json default
+  ;;
+faulthunt)
+  n=${1:-10}; bad=0
+  [ "$2" == "pageable" ] && export NMP_TEST_PAGEABLE_COPIES=1
+  for i in $(seq 1 $n); do
+    ABORT_SHIM_OUT=$O/abort$i.txt LD_PRELOAD=$R/tools/dbg/libabort_shim.so timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/run$i.log 2>&1
+    rc=$?
+    [ $rc -ne 0 ] && bad=$((bad+1))
+    echo "run $i rc=$rc $(tail -1 $O/run$i.log | cut -c1-120)"
+    [ -f $O/abort$i.txt ] && head -30 $O/abort$i.txt
+  done
+  echo "faulthunt: $bad of $n runs failed (NMP_TEST_PAGEABLE_COPIES=${NMP_TEST_PAGEABLE_COPIES:-0})"
   ;;
 micro)
   timeout 300 ./tools/micro/$1.bin > $O/$1.txt 2>&1; echo "$1 rc=$?"; cat $O/$1.txt
