@@ -356,6 +356,7 @@ class Run:
         if not hasattr(self, "first_hour"):
             self.first_hour = h
         self.step_hours.append(h)
+        self.steps_since_sort = getattr(self, "steps_since_sort", 0) + 1
         if self.sorted and self.gw is not None:
             # config 4: forcing (tile order, ring-carrying block) -> sorted working set; the groundwater planes of the previous
             # step's WTABLE call return to sorted order in the same launch
@@ -422,14 +423,23 @@ class Run:
         vanished)?  Above the threshold the state is sorted again on the device -- all of it inside the timed region.  The count is
         enqueued on the run's stream and read at the NEXT check: a check that waited for it drained the stream (~0.4 ms of idle GPU while
         the host refills the queue); a re-sort, which is rare, still does."""
-        if self.stale_result() > self.args.resort_frac * self.d.ncol:
-            self.collect()
-            self.ts.synchronize()
-            self.perm = self.eng.sort_store(self.d, **self.sort_kw)
-            self._bind_sorted()
-            self.resorts += 1
+        cost_due = self.args.cost_key and self.args.cost_resort_every and self.steps_since_sort >= self.args.cost_resort_every
+        if self.stale_result() > self.args.resort_frac * self.d.ncol or cost_due:
+            self.resort()
         self.eng.sort_staleness_async(self.d, self.sp)
         self.stale_pending = True
+
+    def resort(self, it=None):
+        """Sort the device-resident state again (drains the stream).  With --cost-key the key carries a bucket of every land column's own
+        trip counts in the step just run (set_option record_cost + NOAHMP_SORT_COST)."""
+        self.collect()
+        self.ts.synchronize()
+        if self.args.cost_key:
+            self.sort_kw["cost"] = True
+        self.perm = self.eng.sort_store(self.d, **self.sort_kw)
+        self._bind_sorted()
+        self.resorts += 1
+        self.steps_since_sort = 0
 
     def stale_result(self):
         """The count the previous check enqueued (one interval ago: it has long arrived, nothing drains); 0 if there was none."""
@@ -541,6 +551,7 @@ class Run5:
             self.lon_d = self.lon_t.reshape(self.nj, self.ni)
             st = {k: v.reshape(self.nj, self.ni) for k, v in self.static_t.items()}
         self.recs = self.synth5.Records(self.d.a["xlatin"], self.lon_d, st)
+        self.torch.cuda.current_stream().synchronize()      # built on torch's current stream, read on the run's stream (a re-sort inside a run)
 
     def step(self, it):
         n = it - 1
@@ -557,21 +568,30 @@ class Run5:
                 self.first_hour = ihour
             self.step_hours.append(ihour)
             eng.noahmplsm_async(d.step_args(it, 2000, jul), stream=self.sp)
+        self.steps_since_sort = getattr(self, "steps_since_sort", 0) + 1
         if self.sorted and self.args.resort_every and it % self.args.resort_every == 0:
             self.maybe_resort(it)
 
     def maybe_resort(self, it):
-        if self.stale_result() > self.args.resort_frac * self.d.ncol:
-            self.collect()
-            self.ts.synchronize()
-            self.perm = self.eng.sort_store(self.d, **self.sort_kw)
-            self._bind()
-            ri, k = divmod(it, self.synth5.RECORD_HOURS)                     # records are in the store's column order: evaluate them again
-            with self.torch.cuda.stream(self.ts):
-                self.rec_a, self.rec_b = (self.recs.at(ri), self.recs.at(ri + 1)) if k else (None, None)
-            self.resorts += 1
+        cost_due = self.args.cost_key and self.args.cost_resort_every and self.steps_since_sort >= self.args.cost_resort_every
+        if self.stale_result() > self.args.resort_frac * self.d.ncol or cost_due:
+            self.resort(it)
         self.eng.sort_staleness_async(self.d, self.sp)
         self.stale_pending = True
+
+    def resort(self, it):
+        """`it` = the step just enqueued (the forcing records of the next one are evaluated again in the new column order)"""
+        self.collect()
+        self.ts.synchronize()
+        if self.args.cost_key:
+            self.sort_kw["cost"] = True
+        self.perm = self.eng.sort_store(self.d, **self.sort_kw)
+        self._bind()
+        ri, k = divmod(it, self.synth5.RECORD_HOURS)                     # records are in the store's column order: evaluate them again
+        with self.torch.cuda.stream(self.ts):
+            self.rec_a, self.rec_b = (self.recs.at(ri), self.recs.at(ri + 1)) if k else (None, None)
+        self.resorts += 1
+        self.steps_since_sort = 0
 
     stale_result = Run.stale_result
     collect = Run.collect
@@ -659,6 +679,8 @@ def timed_leg(run, steps, warmup, barrier):
     for _ in range(warmup):
         it += 1
         run.step(it)
+    if run.args.cost_key and run.sorted and warmup:
+        run.resort(it)
     run.collect()
     run.reset_counters()
     barrier()
@@ -704,6 +726,29 @@ def options_legs(args, comm, eng, tb, dev, barrier, torch):
         finally:
             for k, v in prev.items():
                 eng.set_option(k, v)
+        torch.cuda.empty_cache()
+    # The price of bit-exactness: the same kernel with ocml's float32 routines instead of the restated reference libm
+    # (-DNMP_EXACT_LIBM=0, noahmp_amd/csrc/variants/lib_ocml.so, built by __graft_entry__.build()).  NOT bit-identical to the reference
+    # (statistics: profiles/r05_parity_ocml.md); never the default.
+    ocml = os.path.join(ROOT, "noahmp_amd", "csrc", "variants", "lib_ocml.so")
+    if os.path.exists(ocml) and not os.environ.get("NMP_LIB"):
+        from noahmp_amd.driver import Engine
+        from noahmp_amd.tables import load_tables
+        eng2 = Engine(load_tables("usgs")[0], device=dev.index, lib_path=ocml)
+        try:
+            a = argparse.Namespace(**vars(args))
+            a.opts, a.dump = {}, None
+            r = Run(a, "config3", comm, eng2, tb, dev)
+            dt = timed_leg(r, steps, warmup, barrier)
+            out.append({"options": "namelist options, ocml libm instead of the reference's (-DNMP_EXACT_LIBM=0; results NOT bit-identical, "
+                                   "profiles/r05_parity_ocml.md)", "kernel": "ahead-of-time specialised, variants/lib_ocml.so",
+                        "value": r.n_adv / dt, "unit": "column-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                        "land_kernel_ms": r.class_ms[0] / steps, "columns_per_launch": int(r.n_land / steps),
+                        "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_land / steps) / (r.class_ms[0] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "first_forcing_hour": forcing_hour(warmup + 1, args.dt)})
+            del r
+        finally:
+            eng2.finalize()
         torch.cuda.empty_cache()
     return out
 
@@ -753,16 +798,37 @@ def host_path_leg(args, eng, tb, torch):
     res["stage_everything"] = {"value": adv / dt, "ms_per_step": dt / 2 * 1e3, "kernel_ms": km / 2, "steps": 2,
                                "bytes_up_per_step": int(sum(v.nbytes for k, v in s.a.items() if k != "dzs")),
                                "note": "pageable host arrays, every array H2D and INOUT + OUT D2H per call"}
+    # (1b) what the generated Fortran shim sets by itself (module_sf_noahmpdrv_hip.F90: pin_host_arrays = 1, row chunks with upload |
+    # kernel | download overlapped): still every array both ways, every call -- the unedited drop-in
+    eng.set_option("host_chunks", prev["host_chunks"])
+    prev["pin_host_arrays"] = eng.set_option("pin_host_arrays", 1)
+    for it in (4, 5):                             # second sighting of every array: registered
+        eng.noahmplsm(s, it, 2000, 180.0)
+    dt, km, adv = loop(3, 6)
+    res["shim_default"] = {"value": adv / dt, "ms_per_step": dt / 3 * 1e3, "kernel_ms": km / 3, "steps": 3,
+                           "host_chunks": eng.set_option("host_chunks", prev["host_chunks"]),
+                           "page_locked_arrays": int(eng.lib.noahmp_hip_debug_live_host_registrations()),
+                           "note": "the Fortran shim's own defaults: caller arrays page-locked in place, the tile advanced in row chunks "
+                                   "(H2D | kernel | D2H on three streams); every array H2D and INOUT + OUT D2H per call"}
+    # (1c) the same plus "trust_out_mirror": the 119 OUT / INOUT words still come back every call, but pure OUT arrays are not uploaded again
+    # (the HRLDAS driver only reads them, for output: hdrv:453-558)
+    prev["trust_out_mirror"] = eng.set_option("trust_out_mirror", 1)
+    eng.noahmplsm(s, 9, 2000, 180.0)
+    dt, km, adv = loop(3, 10)
+    res["shim_default_trust_out"] = {"value": adv / dt, "ms_per_step": dt / 3 * 1e3, "kernel_ms": km / 3, "steps": 3,
+                                     "note": "shim defaults + set_option(trust_out_mirror, 1): OUT arrays are not re-uploaded"}
+    eng.set_option("trust_out_mirror", prev["trust_out_mirror"])
     # (2) resident state behind the same call
     opts = dict(pin_host_arrays=1, resident_state=1, lazy_download=1, static_inputs=1, deferred_status=1)
     for k, v in opts.items():
-        prev[k] = eng.set_option(k, v)
+        old = eng.set_option(k, v)
+        prev.setdefault(k, old)                   # (pin_host_arrays: the value from before (1b))
     try:
-        for it in (4, 5, 6):                      # state rebuilt, arrays registered (second sighting), both IN buffers filled
+        for it in (13, 14, 15):                   # state rebuilt, arrays registered (second sighting), both IN buffers filled
             eng.noahmplsm(s, it, 2000, 180.0)
         n = 12
         t0 = time.perf_counter()
-        dt, km, adv = loop(n, 7)
+        dt, km, adv = loop(n, 16)
         tf = time.perf_counter()
         eng.fetch()                               # waits for the last step, brings INOUT + OUT arrays back
         t1 = time.perf_counter()
@@ -771,7 +837,7 @@ def host_path_leg(args, eng, tb, torch):
                            "options": sorted(opts), "note": "value = all cells of the tile x steps / wall time incl. the final fetch (the "
                            "deferred status of a call reports the PREVIOUS step, so tallies lag by one)"}
     finally:
-        for k in ("deferred_status", "static_inputs", "lazy_download", "resident_state", "pin_host_arrays", "host_chunks"):
+        for k in ("deferred_status", "static_inputs", "lazy_download", "resident_state", "trust_out_mirror", "pin_host_arrays", "host_chunks"):
             if k in prev:
                 eng.set_option(k, prev[k])
     return res
@@ -797,6 +863,12 @@ def main():
     ap.add_argument("--resort-frac", type=float, default=0.10,
                     help="re-sort when this share of the columns left their bucket (measured: 11 %% stale columns cost the land kernel 0.8 %%, "
                          "a re-sort 1.7 ms -- profiles/r02_experiments.md)")
+    ap.add_argument("--cost-key", action="store_true",
+                    help="sorted layout: the steps record every land column's trip counts (canopy iterations, STOMATA bisection steps); the state "
+                         "is sorted again at the end of the warm-up with a bucket of them in the key (a wavefront runs as long as its slowest lane)")
+    ap.add_argument("--cost-resort-every", type=int, default=0,
+                    help="with --cost-key: sort again (inside the timed region) whenever this many steps have passed since the last sort, "
+                         "checked at the --resort-every cadence (0 = only at the end of the warm-up and when stale)")
     ap.add_argument("--lon-band", type=float, default=15.0,
                     help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
     ap.add_argument("--no-sort", action="store_true")
@@ -813,6 +885,8 @@ def main():
                     help="N = 1, default workload: skip the legs under other option sets (run-time specialised kernels, generic kernel)")
     ap.add_argument("--no-host-path-reference", action="store_true",
                     help="N = 1, default workload: skip the PCIe-inclusive leg through noahmp_hip_step(NOAHMP_MEM_HOST)")
+    ap.add_argument("--no-n1-reference", action="store_true",
+                    help="N > 1: skip rank 0's own run of the same workload on the whole grid (n1_reference / strong_scaling_efficiency)")
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="N = 1, default workload: skip the short config-4 run that gives the N = 1 point of the --gpus N curve")
     ap.add_argument("--dump", default=None, help="write every rank's tile (tile order, without the ring) to DUMP.rank<r>.npz after the run")
@@ -848,20 +922,45 @@ def main():
     if os.environ.get("NMP_BLOCK"):
         eng.set_option("block", int(os.environ["NMP_BLOCK"]))
 
+    def barrier():
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    # N > 1: the N = 1 point of the strong-scaling curve on the SAME workload, inside this very run -- rank 0 advances the whole grid on
+    # its GPU (same steps, same warm-up) while the other ranks wait at a barrier; the line then carries n1_reference and
+    # strong_scaling_efficiency = value / (N x n1_reference.value) and needs no second run to be read.  (The default N = 1 run is the
+    # headline workload, config 3; the default N > 1 workload is config 4, ~13 % more work per column.)
+    n1_ref = None
+    if world > 1 and not args.no_n1_reference:
+        if rank == 0:
+            t1 = time.perf_counter()
+            solo = Comm.solo(dev_index)
+            r1 = Run5(args, solo, eng, tb, dev) if workload == "config5" else Run(args, workload, solo, eng, tb, dev)
+            dt1 = timed_leg(r1, args.steps, args.warmup, lambda: torch.cuda.synchronize())
+            n1_ref = {"workload": "the same workload (`--workload %s`, %d x %d) on ONE GPU: rank 0 of this run, before the distributed region"
+                                  % (workload, args.ni, args.nj),
+                      "value": r1.n_adv / dt1, "unit": "column-steps/s", "ms_per_step": dt1 / args.steps * 1e3, "steps": args.steps,
+                      "warmup": args.warmup, "column_kernels_ms_per_step": r1.kernel_ms / args.steps, "groundwater_calls": r1.gw_calls,
+                      "wall_s_incl_setup": None}
+            del r1
+            torch.cuda.empty_cache()
+            n1_ref["wall_s_incl_setup"] = time.perf_counter() - t1
+        comm.barrier()
+
     t_setup = time.perf_counter()
     run = Run5(args, comm, eng, tb, dev) if workload == "config5" else Run(args, workload, comm, eng, tb, dev)
     t_setup = time.perf_counter() - t_setup
 
+    if args.cost_key:
+        eng.set_option("record_cost", 1)
     it = 0
     for _ in range(args.warmup):
         it += 1
         run.step(it)
+    if args.cost_key and run.sorted and args.warmup:
+        run.resort(it)                                  # outside the timed region, like the first sort
     run.collect()
     run.reset_counters()
-
-    def barrier():
-        comm.barrier()
-        torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
@@ -878,6 +977,7 @@ def main():
     halo_ms = sum(e0.elapsed_time(e1) for e0, e1 in run.halo_events)
     halo_ms_max = comm.reduce_max(halo_ms)
     kernel_ms_max = comm.reduce_max(run.kernel_ms)
+    kernel_ms_min = comm.reduce_min(run.kernel_ms)
 
     if args.dump:
         run.dump(args.dump + ".rank%d.npz" % rank)
@@ -891,6 +991,20 @@ def main():
         tot = float(sum(ticks)) or 1.0
         for ph in sorted(NAMES, key=lambda ph: -ticks[ph]):
             print("phase %-42s %5.1f %%" % (NAMES[ph], 100.0 * ticks[ph] / tot), file=sys.stderr)
+
+    if rank == 0 and os.environ.get("NMP_COST_SPREAD") and run.sorted:
+        # analysis only (tools/cost_spread.py): the recorded trip counts per wavefront under the current column order, at a few hours
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import cost_spread
+        eng.set_option("record_cost", 1)
+        for _ in range(4):
+            for _ in range(int(os.environ.get("NMP_COST_SPREAD_STRIDE", "5"))):
+                it += 1
+                run.step(it)
+            run.collect()
+            cost_spread.report(eng, run, run.step_hours[-1], run.d.class_ranges[0])
+        if not args.cost_key:
+            eng.set_option("record_cost", 0)
 
     if rank == 0 and os.environ.get("NMP_K2_EXP"):
         # profiling library only (-DNMP_K2_EXPERIMENT, noahmp_amd/csrc/nmp_k2_experiment.hpp): the flux solvers as a kernel of their own,
@@ -1056,6 +1170,12 @@ def main():
                                   "halo_exchange_us_per_call_max_over_ranks": (halo_ms_max / run.gw_calls * 1e3) if run.gw_calls else None,
                                   "algorithmic_bytes_per_cell_per_call": GW_BYTES_PER_CELL}
         if world > 1:
+            out["kernel_ms_per_step_min_max_over_ranks"] = [kernel_ms_min / K, kernel_ms_max / K]
+            out["halo_mover"] = getattr(run, "halo_mover", None) if run.lateral else "none (no exchange in this workload)"
+            out["halo_ms_per_call"] = (halo_ms_max / run.gw_calls) if (run.lateral and run.gw_calls) else None
+            if n1_ref is not None:
+                out["n1_reference"] = n1_ref
+                out["strong_scaling_efficiency"] = value / (world * n1_ref["value"])
             out["distributed"] = {"backend": comm.backend, "note": getattr(comm, "backend_note", None), "halo_requested": args.halo,
                                   "halo": comm.halo, "halo_note": comm.halo_note}
         if scaling_ref is not None:

@@ -430,8 +430,10 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   float zt = nmp_max(1.E-6f, nmp_expf(zilfc * sqrtf(ustar * z0)) * z0);
   float zslu = zlm + zu;
   float zslt = zlm + zt;
+  // RLOGU = LOG(ZSLU / ZU) and RLOGT = LOG(ZSLT / ZT) (lsm:4336-4337) feed only SIMM / SIMH at the end: they join the batch of the branch
+  // that follows (eight independent LOGs in the unstable branch: one round of table look-ups instead of two dependent ones)
+  const float rlu_arg = zslu / zu, rlt_arg = zslt / zt;
   float rlogu, rlogt;
-  { const float la[2] = {zslu / zu, zslt / zt}; float lg[2]; nmp_logfN<2>(la, lg); rlogu = lg[0]; rlogt = lg[1]; }   // independent: one batch of look-ups
   float zetalt = nmp_max(zslt * rlmo, ZTMIN);
   rlmo = zetalt / zslt;
   float zetalu = zslu * rlmo;
@@ -443,16 +445,18 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
           xu = sqrtf(sqrtf(1.f - 16.f * zetau)), xt = sqrtf(sqrtf(1.f - 16.f * zetat));
     // PSPMU(xu), PSPMU(xlu), PSPHU(xt), PSPHU(xlt) (lsm:4290-4299 statement functions): their six LOGs are independent -- one batch of
     // table look-ups instead of six dependent LDS round trips per iteration; the arithmetic of pspmu / psphu is unchanged
-    const float la[6] = {(xu + 1.f) * 0.5f, (xu * xu + 1.f) * 0.5f, (xlu + 1.f) * 0.5f, (xlu * xlu + 1.f) * 0.5f,
-                         (xt * xt + 1.f) * 0.5f, (xlt * xlt + 1.f) * 0.5f};
-    float lg[6];
-    nmp_logfN<6>(la, lg);
+    const float la[8] = {(xu + 1.f) * 0.5f, (xu * xu + 1.f) * 0.5f, (xlu + 1.f) * 0.5f, (xlu * xlu + 1.f) * 0.5f,
+                         (xt * xt + 1.f) * 0.5f, (xlt * xlt + 1.f) * 0.5f, rlu_arg, rlt_arg};
+    float lg[8];
+    nmp_logfN<8>(la, lg);
+    rlogu = lg[6]; rlogt = lg[7];
     psmz = -2.f * lg[0] - lg[1] + 2.f * nmp_atanf(xu) - (3.14159265f / 2.f);
     const float pspmu_xlu = -2.f * lg[2] - lg[3] + 2.f * nmp_atanf(xlu) - (3.14159265f / 2.f);
     simm = pspmu_xlu - psmz + rlogu;
     pshz = -2.f * lg[4];
     simh = -2.f * lg[5] - pshz + rlogt;
   } else {
+    { const float la[2] = {rlu_arg, rlt_arg}; float lg[2]; nmp_logfN<2>(la, lg); rlogu = lg[0]; rlogt = lg[1]; }
     zetalu = nmp_min(zetalu, ZTMAX);
     zetalt = nmp_min(zetalt, ZTMAX);
     psmz = 5.f * zetau;
@@ -498,7 +502,7 @@ NMP_DEV StomataT stomata_temperature(const StomataP& T, float tv, float o2) {
 
 NMP_DEV void stomata(const StomataP& T, float mpe, float apar, float foln, float tv, float ei,
                      float ea, float sfctmp, float sfcprs, float o2, float co2, float igs,
-                     float btran, float rb, const StomataT& st, float avcmx_pow, float& rs, float& psn) {
+                     float btran, float rb, const StomataT& st, float avcmx_pow, float& rs, float& psn, int& steps) {
   const float bpv = T.bp;
   float cf = sfcprs / (8.314f * sfctmp) * 1.0e06f;
   rs = 1.0f / bpv * cf;
@@ -533,6 +537,7 @@ NMP_DEV void stomata(const StomataP& T, float mpe, float apar, float foln, float
     float r1 = q / a, r2 = cq / q;
     rs = nmp_max(r1, r2);
     float fci = nmp_max(cs - psn * sfcprs * 1.65f * rs, 0.0f);
+    steps++;
     if (((cihi - cilow) <= 5e-2f) || fabsf(fci - ci) <= mpe) break;
     else if (fci > ci) cilow = ci;
     else cihi = ci;
@@ -596,6 +601,7 @@ constexpr int VEGLOOP_WORDS = sizeof(VegLoop) / 4;
 struct VegFirst {   // what only iteration 1 needs (STOMATA / CANRES run there, lsm:3287-3320)
   const Parm* P; int v; float parsun, parsha, foln, o2air, co2air, igs, btran; float psnsun, psnsha;
   StomataP sp;
+  int bisections;     // STOMATA's bisection steps, both leaves (record_cost)
 };
 
 // one pass of the loop body, lsm:3236-3456
@@ -657,7 +663,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
       float par = leaf ? f->parsha : f->parsun, rs_, psn_;
       if (c.O.crs == 1)
         stomata(f->sp, MPE, par, f->foln, L.tv, estv, L.eah, sfctmp, L.sfcprs, f->o2air, f->co2air, f->igs,
-                f->btran, rb, st, avcmx_pow, rs_, psn_);
+                f->btran, rb, st, avcmx_pow, rs_, psn_, f->bisections);
       else
         canres(*f->P, par, L.tv, f->btran, L.eah, L.sfcprs, rs_, psn_);
       if (leaf) { L.rssha = rs_; f->psnsha = psn_; } else { L.rssun = rs_; f->psnsun = psn_; }
@@ -765,9 +771,13 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     f.parsun = q.parsun; f.parsha = q.parsha; f.foln = s.foln; f.o2air = s.o2air; f.co2air = s.co2air; f.igs = s.igs; f.btran = s.btran;
     vege_iter<true>(c, L, 1, &f);                       // iteration 1 (with STOMATA / CANRES)
     psnsun = f.psnsun; psnsha = f.psnsha;
+    record_cost(c, 1, f.bisections);
+  } else {
+    record_cost(c, 1, 0);
   }
   if (NMP_TRUNC == 4) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch; s.err = 99; return; }
   runner.run(c, L, canopy);                             // iterations 2..20
+  record_cost(c, 0, canopy ? L.iter - 1 : 0);
   NMP_TIC(21);
   if (NMP_TRUNC == 5) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch + L.mo.fv + L.mo.fh2; s.err = 99; return; }
   if (!canopy) return;

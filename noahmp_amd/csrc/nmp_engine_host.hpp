@@ -53,6 +53,9 @@ struct Engine {
   std::vector<float> sync_step_ms;            // noahmp_hip_sync_step_timing: land (or mixed) kernel of each step of the last sync
   std::vector<signed char> async_kind;              // per pending step: launch_any's kind (0 one kernel, 1 class kernels in a row, 2 forked)
   int last_launch_kind = 0;
+  // "record_cost": per-column trip counts of the last device-resident step, in the tile's current column order (Ctx::cost)
+  unsigned char* d_cost = nullptr; size_t d_cost_bytes = 0; long cost_cols = 0; int record_cost = 0;
+  bool cost_fresh = false;                    // written by a step since the last permutation of the state
   long long last_counts[3] = {0, 0, 0};       // 64-bit tallies behind the last status (noahmp_hip_sync_counts)
   int deferred_code = 0;                      // fatal code of a deferred step that no call has returned yet
   // host-memory path: row-chunk pipeline H2D | kernel | D2H on three streams, optional pinning of the caller's arrays
@@ -99,6 +102,7 @@ struct LaunchDesc {
   int* counts;
   unsigned long long err_base;
   long t_offset, t_first, t_count;
+  unsigned char* cost;           // Ctx::cost of this launch (already offset to its first column) or NULL
 };
 // mode: 0 mixed tile, 1 land-only range, 2 land-ice-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
 void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);

@@ -218,6 +218,10 @@ int noahmp_hip_set_option(const char* key, int value) {
       g.deferred_status = value; g.resident_valid = false;
     }
   }
+  else if (!strcmp(key, "record_cost")) {
+    prev = g.record_cost;
+    if (value == 0 || value == 1) { g.record_cost = value; if (!value) g.cost_fresh = false; }
+  }
   else if (!strcmp(key, "exact_libm")) prev = NMP_EXACT_LIBM;   // read-only: how this library was built
   return prev;
 }
@@ -288,6 +292,7 @@ static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
   for (int l = 0; l < NL; l++) d.zsoil[l] = k.c.zsoil[l];
   d.ni = k.ni; d.nka = k.nka; d.nti = k.nti; d.ntj = k.ntj; d.k1 = k.k1; d.kp_lo = k.kp_lo; d.kp_hi = k.kp_hi; d.yearlen = k.yearlen;
   d.err = k.err; d.counts = k.counts; d.err_base = k.err_base; d.t_offset = k.t_offset; d.t_first = k.t_first; d.t_count = k.t_count;
+  d.cost = k.c.cost;
   if (level > 0) { kFixed[level - 1].launch(d, mode, s); return true; }
   const Opt& o = k.c.O;
   const int opts[12] = {o.dveg, o.crs, o.btr, o.run, o.sfc, o.frz, o.inf, o.rad, o.alb, o.snf, o.tbot, o.stc};
@@ -299,6 +304,7 @@ template <int MODE>
 static void launch_range(KArgs k, long first, long count, hipStream_t s) {
   if (count <= 0) return;
   k.t_first = first; k.t_count = count;
+  if (k.c.cost) k.c.cost += 2 * first;                 // the kernel indexes it by its own thread number
   const int fx = (MODE != 3) ? fixed_level(k) : 0;      // skipped cells do not depend on the options
   if (fx && launch_fixed(k, fx, MODE, s)) return;
   hipLaunchKernelGGL((noahmp_column_kernel<256, true, MODE>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k);
@@ -309,10 +315,20 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
 // kernels.  Every event is one more packet between two kernels of the caller's stream (~5 us each on this chip), so they double as the
 // fork / join events of the second stream and nothing else is recorded; g.last_launch_kind tells noahmp_hip_sync which of them exist
 // (-1: an empty tile, none).
-static void launch_any(const KArgs& k, hipStream_t s, bool class_ranges = false, hipEvent_t* ev = nullptr) {
+static void launch_any(const KArgs& k_in, hipStream_t s, bool class_ranges = false, hipEvent_t* ev = nullptr) {
+  KArgs k = k_in;
   const long ncol = (long)k.nti * k.ntj;
   g.last_launch_kind = 0;
   if (ncol <= 0) { g.last_launch_kind = -1; return; }          // an empty tile: nothing is enqueued, no event is recorded (kind -1: no times)
+  // "record_cost": the land columns of a device-resident tile leave their two trip counts in an engine-owned plane (Ctx::cost), in the
+  // tile's CURRENT column order; noahmp_hip_sort_columns(NOAHMP_SORT_COST) reads it.  Not for row chunks of the host path.
+  k.c.cost = nullptr;
+  if (g.record_cost && class_ranges && k.t_offset == 0) {
+    if (nmp_host::ensure_bytes((void**)&g.d_cost, &g.d_cost_bytes, (size_t)ncol * 2) == 0) {
+      if (g.cost_cols != ncol) (void)hipMemsetAsync(g.d_cost, 0, (size_t)ncol * 2, s);
+      k.c.cost = g.d_cost; g.cost_cols = ncol; g.cost_fresh = true;
+    }
+  }
   // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
   if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
       g.block == 256 && g.use_lds) {
@@ -845,6 +861,8 @@ int noahmp_hip_stream_sync(void* stream) {
 
 // dst column p <- src column perm[p] for every array of the step block ((re-)sorting a device-resident run)
 int noahmp_hip_permute_step_arrays(const noahmp_step_args* src, const noahmp_step_args* dst, const int32_t* perm, void* stream) {
+  g.cost_fresh = false;          // the cost record ("record_cost") is in the order the last step found the tile in
+
   int rc = ensure_init();
   if (rc) return rc;
   if (src->ims != dst->ims || src->ime != dst->ime || src->jms != dst->jms || src->jme != dst->jme || src->nsoil != dst->nsoil ||
@@ -882,6 +900,17 @@ int noahmp_hip_sync_timing(float* out, int n) {
 int noahmp_hip_sync_counts(int64_t* out, int n) {
   for (int c = 0; c < n && c < 3; c++) out[c] = (int64_t)g.last_counts[c];
   return g.sync_steps;
+}
+
+// The cost record of the last device-resident step ("record_cost"): two bytes per column of the tile in its current order (canopy-loop
+// iterations, STOMATA bisection steps); returns the number of columns copied (0: nothing recorded), waits for `stream`.
+long noahmp_hip_fetch_cost(uint8_t* host_out, long ncol, void* stream) {
+  if (!g.d_cost || !g.cost_fresh || !host_out) return 0;
+  const long n = ncol < g.cost_cols ? ncol : g.cost_cols;
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  if (hipMemcpyAsync(host_out, g.d_cost, (size_t)n * 2, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+  if (hipStreamSynchronize(s) != hipSuccess) return 0;
+  return n;
 }
 
 // The same per step: out[i] = land (or mixed) kernel time of step i of the last noahmp_hip_sync [ms]; returns the number of steps.
@@ -968,6 +997,8 @@ void noahmp_hip_finalize(void) {
   if (g.d_tables) hipFree(g.d_tables);
   if (g.d_err) hipFree(g.d_err);
   if (g.d_counts) hipFree(g.d_counts);
+  if (g.d_cost) hipFree(g.d_cost);
+  g.d_cost = nullptr; g.d_cost_bytes = 0; g.cost_cols = 0; g.cost_fresh = false;
   if (g.d_gw_counts) hipFree(g.d_gw_counts);
   if (g.h_err) hipHostFree(g.h_err);
   if (g.h_counts) hipHostFree(g.h_counts);

@@ -20,34 +20,43 @@ struct KeyArgs {
   int t_nk, t_k, ni;                                          // its levels per row, the level taken, the row length
   const int* ivgtyp; const int* isnow;
   const int* band;                                            // optional caller-defined sub-key plane (noahmp_hip_sort_set_band), or NULL
+  const unsigned char* cost;                                  // the engine's cost record of the last step (NOAHMP_SORT_COST), or NULL
   float xice_thres, inv_bin;
   int isice, flags;
   long n;
 };
 
-// key = class(2) | vegetation type and snow-layer count (8, in the order the flags ask for) | band(5) | tsk bin(8): class 0 land, 1 land ice,
-// 2 skipped (the classification of drv:426-441); skipped columns carry no sub-key.  band: a caller-defined static sub-key, 0..31
+// key = class(2) | vegetation type and snow-layer count (8, in the order the flags ask for) | band(5) | cost(4) | tsk bin(8): class 0 land,
+// 1 land ice, 2 skipped (the classification of drv:426-441); skipped columns carry no sub-key.  band: a caller-defined static sub-key, 0..31
 // (noahmp_hip_sort_set_band; e.g. the 15-degree longitude band of a lat/lon grid, so that a wavefront's columns share their local solar time).
-constexpr int kClsShift = 21, kHiShift = 13, kBandShift = 8;
+// cost (NOAHMP_SORT_COST): a bucket of the column's own trip counts in the step before the sort -- iterations of VEGE_FLUX's canopy loop and
+// STOMATA's bisection steps, the two loops whose length differs from column to column (a wavefront runs as long as its slowest lane).
+constexpr int kClsShift = 25, kHiShift = 17, kBandShift = 12, kCostShift = 8;
+// one canopy iteration ~ 1070 vector instructions, one bisection step ~ 130 (tools/isa_loops.py): cost units of one bisection step
+__device__ __forceinline__ unsigned cost_bucket(unsigned iters, unsigned bisections) {
+  const unsigned c = 8u * iters + bisections;                 // 0 (no canopy) .. 200
+  return c == 0u ? 0u : min(1u + c / 14u, 15u);
+}
 __device__ __forceinline__ unsigned column_key(const KeyArgs& k, long p) {
   const float xland = k.xland[p], xice = k.xice[p];
   const int ivg = k.ivgtyp[p];
   const unsigned cls = ((xland - 1.5f) >= 0.f || xice >= k.xice_thres) ? 2u : (ivg == k.isice ? 1u : 0u);
   if (cls == 2u) return 2u << kClsShift;
-  unsigned veg = 0, sn = 0, tb = 0, band = 0;
+  unsigned veg = 0, sn = 0, tb = 0, band = 0, cost = 0;
   if (cls == 0u && (k.flags & NOAHMP_SORT_VEG)) veg = (unsigned)min(max(ivg, 0), 63);
   if (k.flags & NOAHMP_SORT_SNOW) sn = (unsigned)min(max(-k.isnow[p], 0), 3);
   if (k.band) band = (unsigned)min(max(k.band[p], 0), 31);
+  if (k.cost && cls == 0u) cost = cost_bucket(k.cost[2 * p], k.cost[2 * p + 1]);
   if (k.inv_bin > 0.f) {
     float t = k.t_nk == 1 ? k.tsk[p] : k.tsk[((size_t)(p / k.ni) * k.t_nk + k.t_k) * k.ni + p % k.ni];
     if (!(t == t)) t = 250.f;
     tb = (unsigned)min(max((int)((t - 230.0f) * k.inv_bin), 0), 255);
   }
   const unsigned hi = (k.flags & NOAHMP_SORT_SNOW_FIRST) ? (sn << 6 | veg) : (veg << 2 | sn);
-  return cls << kClsShift | hi << kHiShift | band << kBandShift | tb;
+  return cls << kClsShift | hi << kHiShift | band << kBandShift | cost << kCostShift | tb;
 }
-constexpr unsigned kTskMask = 0xFFu;
-constexpr int kKeyBits = 23;
+constexpr unsigned kTskMask = 0xFFFu;       // what a staleness count ignores: temperature bin and cost bucket (they change every step)
+constexpr int kKeyBits = 27;
 // host-side: the plane the NEXT sort / staleness call of this thread reads (device pointer, the store's column order); consumed by that
 // call (fill_key_args), so that a failed or forgotten call leaves nothing behind
 thread_local const int* g_band_plane = nullptr;
@@ -139,6 +148,9 @@ int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_
   k.xice_thres = a->xice_thres; k.isice = a->isice; k.flags = flags;
   k.band = g_band_plane;
   g_band_plane = nullptr;                 // one-shot (noahmp_hip_sort_set_band)
+  k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
+  // the cost record is in the order the last step found the tile in: usable only if no permutation happened since
+  k.cost = ((flags & NOAHMP_SORT_COST) && g.cost_fresh && g.d_cost && g.cost_cols == k.n) ? g.d_cost : nullptr;
   k.inv_bin = tsk_bin_mk > 0 ? 1000.0f / (float)tsk_bin_mk : 0.f;
   k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
   return 0;

@@ -190,7 +190,7 @@ class Engine:
         if rc:
             raise RuntimeError("noahmp_hip_stream_sync: " + self.lib.noahmp_hip_last_error().decode())
 
-    def sort_store(self, store, tsk_bin=1.0, veg=True, snow=True, snow_first=False, allow_lateral=False, tair=False, band=None):
+    def sort_store(self, store, tsk_bin=1.0, veg=True, snow=True, snow_first=False, allow_lateral=False, tair=False, band=None, cost=False):
         """Reorder a DeviceColumnStore in place so that columns with equal (class, vegetation type, snow-layer count,
         skin-temperature bin) are adjacent, and return the permutation as an int32 device tensor: sorted position p holds the
         column that sits at linear tile index perm[p] of the ORIGINAL tile order (a second call on an already sorted
@@ -211,7 +211,8 @@ class Engine:
         assert store.cfg.iopt_run != 5 or allow_lateral, "OPT_RUN=5 needs the (i,j) order for WTABLE_mmf_noahmp"
         n = store.ncol
         flags = ((abi.SORT_VEG if veg else 0) | (abi.SORT_SNOW if snow else 0) | (abi.SORT_SNOW_FIRST if snow_first else 0) |
-                 (abi.SORT_TAIR if tair else 0))         # tair: temperature bins from the forcing air temperature instead of TSK
+                 (abi.SORT_TAIR if tair else 0) |        # tair: temperature bins from the forcing air temperature instead of TSK
+                 (abi.SORT_COST if cost else 0))         # cost: bucket of the columns' own trip counts in the last step (set_option record_cost)
         a = store.step_args(1, 2000, 1.0)
         perm = torch.empty(n, dtype=torch.int32, device=store.device)
         keys = torch.empty(n, dtype=torch.int32, device=store.device)

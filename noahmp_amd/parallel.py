@@ -65,18 +65,39 @@ class Comm:
         self.dist = dist
         self.backend = "gloo"
         if want == "nccl":
-            err = None
+            # Three steps, each AGREED over the control plane before the next starts, so that no rank is left alone inside a collective:
+            # (1) bind the GPU; (2) create the RCCL group (new_group is itself collective over the control plane, it does not touch RCCL yet);
+            # (3) one all-reduce, asynchronous and polled against a deadline -- the call that creates the communicator and the one a broken
+            # RCCL hangs in.  A failure that is an exception on some rank: all ranks run over gloo.  A failure that is a TIMEOUT: that
+            # collective may still be pending on the device, nothing sane can follow in this process -- all ranks leave together, non-zero.
+            import time
+            err, pg, hung = None, None, False
             try:
                 torch.cuda.set_device(self.device_index)
-                pg = dist.new_group(backend="nccl", timeout=self._tmo)
-                t = torch.ones(1, device=torch.device("cuda", self.device_index))
-                dist.all_reduce(t, group=pg)                      # creates the communicator: a broken RCCL shows here
-                torch.cuda.synchronize()
-                if int(t.item()) != self.world:
-                    err = "all-reduce over RCCL returned %r" % t.item()
             except Exception as e:                                # noqa: BLE001
-                err = str(e).splitlines()[0][:200] if str(e) else repr(e)
-                pg = None
+                err = "set_device(%d): %s" % (self.device_index, str(e).splitlines()[0][:160] if str(e) else repr(e))
+            if not self._agree_any(err is not None):
+                try:
+                    pg = dist.new_group(backend="nccl", timeout=self._tmo)
+                    t = torch.ones(1, device=torch.device("cuda", self.device_index))
+                    work = dist.all_reduce(t, group=pg, async_op=True)
+                    limit = time.monotonic() + float(os.environ.get("NMP_RCCL_PROBE_TIMEOUT_S", "120"))
+                    while not work.is_completed():
+                        if time.monotonic() > limit:
+                            hung = True
+                            raise TimeoutError("the probe all-reduce over RCCL did not complete within its deadline")
+                        time.sleep(0.005)
+                    work.wait()
+                    torch.cuda.synchronize()
+                    if int(t.item()) != self.world:
+                        err = "all-reduce over RCCL returned %r" % t.item()
+                except Exception as e:                            # noqa: BLE001
+                    err = str(e).splitlines()[0][:200] if str(e) else repr(e)
+                    pg = None
+            if self._agree_any(hung):
+                print("noahmp_amd.parallel: rank %d: an RCCL collective hung on %s; all ranks stop (set NMP_DIST_BACKEND=gloo to run "
+                      "without RCCL)" % (self.rank, "this rank" if hung else "another rank"), file=sys.stderr, flush=True)
+                os._exit(3)          # a pending collective cannot be cancelled; destructors would wait for it
             bad = self._agree_any(err is not None)                # every rank learns whether ANY rank failed, then all act alike
             if bad:
                 self.backend_note = ("nccl (RCCL) initialisation failed on %s: %s; running over gloo"
@@ -90,6 +111,18 @@ class Comm:
         elif halo == "auto" and os.environ.get("NMP_HALO_AUTO", "1") != "0" and (
                 self.backend == "nccl" or os.environ.get("NMP_HALO_AUTO_TRANSPORT") == "tcp"):
             self._try_cabi_rccl(halo_port)
+
+    @classmethod
+    def solo(cls, device_index=0):
+        """A one-rank communicator whatever the environment says: rank 0 of a `--gpus N` run uses it to time the SAME workload on the
+        whole grid by itself (bench.py's n1_reference) before the distributed region starts."""
+        c = cls.__new__(cls)
+        c.rank, c.local_rank, c.world, c.device_index = 0, 0, 1, int(device_index)
+        c.dist = c.backend = c.backend_note = c.dev_group = c.halo_note = c.halo_lib = c.probe_results = None
+        c.halo_requested = c.halo = "torch"
+        c._halo_plans = {}
+        c.p2p_host = False
+        return c
 
     # ---- agreement over the control plane
     def _agree_any(self, flag):
@@ -173,16 +206,25 @@ class Comm:
         th.start()
         th.join(limit)
         late = th.is_alive()
-        err = "no answer within %g s" % limit if late else box.get("err")
+        if self._agree_any(late):
+            # A helper that has not answered is still INSIDE the library (rendezvous, communicator creation) and the engine's globals are not
+            # thread-safe: nothing of the library may be called from this process any more.  All ranks learn of it and leave together.
+            print("noahmp_amd.parallel: rank %d: the engine's RCCL mover gave no answer within %g s on %s; all ranks stop (--halo torch "
+                  "skips it)" % (self.rank, limit, "this rank" if late else "another rank"), file=sys.stderr, flush=True)
+            os._exit(3)
+        err = box.get("err")
         if self._agree_any(err is not None):
             self.halo_note = ("C-ABI RCCL mover not used (%s): torch.distributed send/recv moves the ring"
                               % (("rank %d: %s" % (self.rank, err)) if err else "another rank failed"))
             print("noahmp_amd.parallel: " + self.halo_note, file=sys.stderr, flush=True)
-            if box.get("lib") is not None and not late:
+            if box.get("lib") is not None:
                 box["lib"].noahmp_hip_halo_finalize()
             self.halo_lib, self.halo = None, "torch"
         else:
             self.halo_lib, self.halo = box["lib"], transport
+            # hipSetDevice is per thread: the helper bound ITS thread; bind the caller's too before it uses the library
+            if transport == "rccl" or self.halo_lib.noahmp_hip_device_count() > 0:
+                self.halo_lib.noahmp_hip_set_device(self.device_index)
 
     # ---- tile assignment (mpp_land_partition_calc, mpp:227-288)
     def my_tile(self, global_nx, global_ny):
@@ -314,6 +356,9 @@ class Comm:
         t = torch.tensor([float(x)], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def reduce_min(self, x):
+        return -self.reduce_max(-float(x))
 
     def reduce_sum(self, x):
         if not self.dist:

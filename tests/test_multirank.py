@@ -435,9 +435,18 @@ def test_bench_north_star_tiling_equals_one_rank(world, workload, halo, tmp_path
         whole = _one_rank_dump(workload, tmp_path_factory)
     res, dn = _run_bench(["--gpus", str(world)] + common + (["--halo", halo] if workload == "config4" else []), str(tmp_path), "many")
     assert res["n_gpus"] == world and res["scaling"] == "strong"
+    # the N > 1 line is self-contained: the N = 1 point of the SAME workload (rank 0, whole grid, same steps) and the efficiency against it
+    n1 = res["n1_reference"]
+    assert n1["steps"] == res["steps"] and n1["value"] > 0 and ("--workload %s" % workload) in n1["workload"]
+    assert abs(res["strong_scaling_efficiency"] - res["value"] / (world * n1["value"])) < 1e-12
+    lo, hi = res["kernel_ms_per_step_min_max_over_ranks"]
+    assert 0 < lo <= hi
     if workload == "config4":
         assert res["groundwater"]["calls"] == 5 and "ring exchange" in res["config"]["parallelism"]
         assert ("noahmp_hip_exchange_halo" in res["config"]["parallelism"]) == (halo == "tcp")
+        assert res["halo_mover"] == res["groundwater"]["halo_mover"] and res["halo_ms_per_call"] > 0 and n1["groundwater_calls"] == 5
+    else:
+        assert res["halo_ms_per_call"] is None and "no exchange" in res["halo_mover"]
     from noahmp_amd.partition import tile_geometry, neighbours
     seen, most_nb = 0, 0
     for r in range(world):

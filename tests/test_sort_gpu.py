@@ -60,7 +60,7 @@ def _host_key(s, tsk_bin=1.0, veg=True, snow=True, snow_first=False, band=None):
         tb = np.clip(((t - np.float32(230.0)) * np.float32(1000.0 / int(round(tsk_bin * 1000)))).astype(np.int64), 0, 255)
     hi = (sk << 6 | vk) if snow_first else (vk << 2 | sk)
     bd = np.clip(band.ravel().astype(np.int64), 0, 31) if band is not None else np.zeros_like(ivg)
-    return np.where(cls == 2, 2 << 21, cls << 21 | hi << 13 | bd << 8 | tb), cls     # class(2) | veg, snow(8) | band(5) | tsk bin(8)
+    return np.where(cls == 2, 2 << 25, cls << 25 | hi << 17 | bd << 12 | tb), cls     # class(2) | veg, snow(8) | band(5) | cost(4) = 0 | tsk bin(8)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(tsk_bin=0), dict(snow_first=True, tsk_bin=0.5), dict(veg=False), dict(snow=False), dict(band="lonband")],
@@ -252,3 +252,51 @@ def test_config3_full_size_sorted_sample_bit_identical(engine, port, tables):
             assert ok, "step %d:\n%s" % (it, "\n".join(lines[:6]))
     isn = set(np.unique(osamp.a["isnowxy"]).tolist())
     assert {0, -3} <= isn and (osamp.a["ivgtyp"] == cfg.isice).sum() > 10 and (osamp.a["ivgtyp"] == cfg.isurban).sum() > 20
+
+
+def test_cost_key_sorts_by_recorded_trip_counts(engine, tables):
+    """set_option record_cost: a device-resident step leaves every land column's canopy-loop iterations and STOMATA bisection steps in an
+    engine-owned plane (tile's current order); noahmp_hip_sort_columns(NOAHMP_SORT_COST) puts a bucket of them into the key, between the
+    band and the temperature bin.  The order is the stable sort of that key, staleness ignores the bucket, a permutation invalidates the
+    record, and the sorted store advances to the same bits as the tile-order one."""
+    import torch
+    s = synth.mixed_small(tables[1], ni=192, nj=40, glacier_frac=0.05, seed=73)
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
+    d, ref = s.to_device("cuda:0"), s.to_device("cuda:0")
+    prev = engine.set_option("record_cost", 1)
+    try:
+        engine.noahmplsm(d, 1, 2000, 180.0)
+        engine.noahmplsm(ref, 1, 2000, 180.0)
+        n = s.ni * s.nj
+        cost = np.zeros(2 * n, dtype=np.uint8)
+        assert engine.lib.noahmp_hip_fetch_cost(cost.ctypes.data, n, None) == n
+        iters, bis = cost[0::2].astype(np.int64), cost[1::2].astype(np.int64)
+        h = d.to_host()
+        veg_cols = (h.a["fvegxy"].ravel() > 0) & (h.a["ivgtyp"].ravel() != s.cfg.isice)
+        assert iters.max() <= 20 and (iters[veg_cols] >= 6).all() and bis.max() <= 40 and (bis > 0).any()      # loop 1 runs >= 6 iterations (lsm:3453)
+        key, cls = _host_key(h, tsk_bin=1.0)
+        assert (iters[cls != 0] == 0).all()
+        c = 8 * iters + bis
+        bucket = np.where(c == 0, 0, np.minimum(1 + c // 14, 15))
+        key = np.where(cls == 0, key | bucket << 8, key)
+        perm = engine.sort_store(d, cost=True).cpu().numpy().astype(np.int64)
+        np.testing.assert_array_equal(perm, np.argsort(key, kind="stable"))
+        assert len(np.unique(bucket[cls == 0])) >= 3
+        assert engine.sort_staleness(d) == 0                       # the bucket is not part of what "stale" means
+        assert engine.lib.noahmp_hip_fetch_cost(cost.ctypes.data, n, None) == 0     # the record died with the permutation
+        synth.diurnal_forcing(s, 14, t_offset=s.t_offset)
+        for k in ("coszin", "swdown", "glw", "t3d", "rainbl"):
+            ref.a[k] = torch.from_numpy(s.a[k].copy()).cuda()
+            v = s.a[k]
+            vs = _cols(v, perm)
+            d.a[k] = torch.from_numpy(np.ascontiguousarray((vs.reshape(v.shape[0], v.shape[2], v.shape[1]).transpose(0, 2, 1) if v.ndim == 3
+                                                            else vs.reshape(v.shape)))).cuda()
+        engine.noahmplsm(d, 2, 2000, 180.0)
+        engine.noahmplsm(ref, 2, 2000, 180.0)
+        hd, hr = d.to_host(), ref.to_host()
+        for k in _outs(hr):
+            assert np.array_equal(_cols(hr.a[k], perm), _cols(hd.a[k]), equal_nan=True), k
+    finally:
+        engine.set_option("record_cost", prev)
+        engine._apply_ranges(None)

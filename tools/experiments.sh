@@ -20,8 +20,10 @@
 #   phase [LIB...]                 phase shares of the profiling build (-DNMP_PHASE_TIMERS: variants/lib_prof.so), after an optional A/B
 #   k2                             the flux solvers as a kernel of their own (variants/lib_k2.so: -DNMP_K2_EXPERIMENT) at 1..4 waves per SIMD, and
 #                                  the land kernel truncated before / behind them (lib_t3.so, lib_t7.so: -DNMP_TRUNC=3 / 7)
-#   faulthunt [N [pageable]]       the whole -m gpu suite N times (default 10), each in its own process, with the abort shim; `pageable`: the
+#   faulthunt [N [pageable|- [ENV=VALUE...]]]   the whole -m gpu suite N times (default 10), each in its own process, with the abort shim; `pageable`: the
 #                                  sort tests' large copies through pageable memory (the round-4 condition of the sporadic GPU memory fault)
+#   cost [WORKLOAD...]             the cost sub-key of the column order (bench.py --cost-key: trip counts recorded by the step before the sort),
+#                                  A/B per workload (default config3 config5): off | on after the warm-up | on + a re-sort every 6 / 12 steps
 #   micro NAME                     run tools/micro/NAME.bin (built in the dev container: hipcc --offload-arch=gfx950 -O3 NAME.hip -o NAME.bin)
 #   fuzz [SEEDS [COLUMNS]]         randomised GPU-vs-oracle runs over option sets (tools/fuzz_parity.py) + a config-5 chain
 #   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
@@ -192,6 +194,9 @@ k2)
 faulthunt)
   n=${1:-10}; bad=0
   [ "$2" == "pageable" ] && export NMP_TEST_PAGEABLE_COPIES=1
+  shift 2 2>/dev/null
+  for kv in "$@"; do export "$kv"; echo "faulthunt: $kv"; done          # e.g. GPU_PINNED_MIN_XFER_SIZE=100000 (MiB: never pin a pageable buffer in place)
+  O=$O/$(echo "run$*" | tr -c 'A-Za-z0-9=_\n' '_'); mkdir -p $O
   for i in $(seq 1 $n); do
     ABORT_SHIM_OUT=$O/abort$i.txt LD_PRELOAD=$R/tools/dbg/libabort_shim.so timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/run$i.log 2>&1
     rc=$?
@@ -200,6 +205,16 @@ faulthunt)
     [ -f $O/abort$i.txt ] && head -30 $O/abort$i.txt
   done
   echo "faulthunt: $bad of $n runs failed (NMP_TEST_PAGEABLE_COPIES=${NMP_TEST_PAGEABLE_COPIES:-0})"
+  ;;
+cost)
+  if [ $# -eq 0 ]; then set -- config3 config5; fi
+  for w in "$@"; do
+    for v in "" "--cost-key" "--cost-key --cost-resort-every 12 --resort-every 12" "--cost-key --cost-resort-every 6 --resort-every 6" ""; do
+      tag=$(echo "$w$v" | tr -d ' ' | tr -s '-' '_')
+      timeout 900 python bench.py --workload $w --steps 48 --warmup 6 --no-cpu-baseline $v > $O/$tag.json 2> $O/$tag.err
+      summarise $O/$tag.json "$w $v"
+    done
+  done
   ;;
 micro)
   timeout 300 ./tools/micro/$1.bin > $O/$1.txt 2>&1; echo "$1 rc=$?"; cat $O/$1.txt
