@@ -29,6 +29,11 @@ import subprocess
 import sys
 import time
 
+# Set-up copies of whole 7 M-column arrays (up to 200 MB each) go through torch's pageable copies: keep the HIP runtime from page-locking such
+# buffers in place (its cached mappings of heap memory fault later on this stack: tests/conftest.py, profiles/r05_experiments.md section 3).
+# Nothing inside a timed region copies from or to pageable memory except the host_path_reference legs, whose copies the engine cuts into
+# 32-MiB pieces anyway (nmp_engine_host.hpp: host_copy_async).
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -99,10 +104,11 @@ def host_cpus():
     return info
 
 
-def cpu_baseline(workload, ncol=16384, nsteps=12, budget_s=45.0):
+def cpu_baseline(workload, ncol=16384, nsteps=36, budget_s=60.0):
     """Time the CPU path on this box's host cores: the compiled reference (oracle/_ref, -O2) when its .so travelled with the
     repo, else the C restatement.  The reference has no threads, so the node-level figure is P independent processes,
-    each on its own `ncol`-column sample of the bench workload (same generator, same class / snow mix), `nsteps` hourly steps,
+    each on its own `ncol`-column sample of the bench workload (same generator, same class / snow mix), `nsteps` steps (three passes over
+    a day of every second hour: ~1.4 s per process, ~20 CPU-seconds at the largest process count),
     started together behind a barrier; rate = P x ncol x nsteps / (last end - first start).  P sweeps 1, 2, 4, ... up to the CPUs
     this process may use (affinity mask and cgroup quota, not os.cpu_count()); the best aggregate is reported with the process
     count that gave it, and the whole sweep beside it so that the scaling over P can be read (bounded: `budget_s` of wall clock)."""
@@ -142,7 +148,7 @@ def cpu_baseline(workload, ncol=16384, nsteps=12, budget_s=45.0):
             "speedup_over_single_process": best["value"] / one["value"],
             "sweep": sweep,
             "sample": "%d processes (best of the sweep %s; CPUs usable by this process: %d of %d logical, %s physical cores, cgroup quota %s) "
-                      "x %d columns x %d hourly steps of the %s workload (%s, float32), the noahmplsm call loop"
+                      "x %d columns x %d steps (every second hour of the diurnal cycle) of the %s workload (%s, float32), the noahmplsm call loop"
                       % (best["processes"], [e["processes"] for e in sweep], hw["usable_cpus"], hw["logical_cpus"], hw["physical_cores"],
                          hw["cgroup_cpu_quota"], ncol, nsteps, what,
                          "reference Fortran flang -O2" if kind == "reference" else "C restatement gcc -O2")}
@@ -169,7 +175,7 @@ def _cpu_worker(kind, workload, ncol, nsteps, r, barrier, q):
     lib.set_tables(T)
     forcing = []
     for it in range(1, nsteps + 1):                                          # forcing prep is not timed
-        synth.diurnal_forcing(s, (2 * it + 4) % 24, t_offset=s.t_offset)    # every second hour: a whole day in 12 steps
+        synth.diurnal_forcing(s, (2 * it + 4) % 24, t_offset=s.t_offset)    # every second hour: a whole day per 12 steps
         forcing.append({k: s.a[k].copy() for k in FKEYS})
     barrier.wait()
     t0 = time.perf_counter()
@@ -350,6 +356,35 @@ class Run:
         self.lvl1 = tuple(i for i, k in enumerate(FKEYS) if self.work[k].dim() == 3)
         self.scat = eng.scatter([self.work[k] for k in FKEYS], src0, self.perm, self.ni, self.nj, first_level_only=self.lvl1)
         self.sarg = d.step_args(1, 2000, 180.0)
+        # Forcing prefetch: a second forcing working set, so that the permutation of step n + 1's
+        # forcing runs on a second stream BESIDE step n's column kernel (the kernel is issue-bound at ~21 % of HBM, the permutation
+        # memory-bound) instead of in front of it.  Two event waits per step order the two streams (read-after-write on the set the
+        # kernel is about to read, write-after-read on the set the previous kernel read).
+        self.work2 = None
+        self.prefetched = None
+        if not self.args.no_prefetch:
+            torch = self.torch
+            self.work2 = ({k: self.work[k] for k in FKEYS}, {k: self.work[k].clone() for k in FKEYS})
+            sarg_b = d.step_args(1, 2000, 180.0)
+            for k in FKEYS:
+                setattr(sarg_b, k, self.work2[1][k].data_ptr())
+            self.sargs2 = (self.sarg, sarg_b)
+            if not hasattr(self, "ts2"):
+                self.ts2 = torch.cuda.Stream(device=self.dev)
+                self.ev_scat = (torch.cuda.Event(), torch.cuda.Event())
+                self.ev_kern = (torch.cuda.Event(), torch.cuda.Event())
+            torch.cuda.current_stream().synchronize()
+
+    def _permute_forcing(self, h, b, stream):
+        """hour h's forcing (tile order) -> forcing working set b of the sorted store, enqueued on `stream`"""
+        dst = [(self.work2[b] if self.work2 is not None else self.work)[k] for k in FKEYS]
+        if self.gw is not None:
+            # config 4: the forcing arrives shaped like the rank's memory block (tile + ring), as the groundwater planes are
+            self.scat.exchange(dst, [self.forcing[h][k] for k in FKEYS], False, self.gw.ni, self.i_off, self.j_off, stream, first_level_only=self.lvl1)
+        else:
+            self.scat.set_dests(dst)
+            self.scat.set_sources([self.forcing[h][k] for k in FKEYS])
+            self.scat(stream)
 
     def step(self, it):
         h = forcing_hour(it, self.cfg.dt)
@@ -357,17 +392,27 @@ class Run:
             self.first_hour = h
         self.step_hours.append(h)
         self.steps_since_sort = getattr(self, "steps_since_sort", 0) + 1
-        if self.sorted and self.gw is not None:
-            # config 4: forcing (tile order, ring-carrying block) -> sorted working set; the groundwater planes of the previous
-            # step's WTABLE call return to sorted order in the same launch
-            srt = [self.work[k] for k in FKEYS]
-            til = [self.forcing[h][k] for k in FKEYS]
-            self.scat.exchange(srt, til, False, self.gw.ni, self.i_off, self.j_off, self.sp, first_level_only=self.lvl1)
+        if self.sorted and self.work2 is not None:
+            b = it & 1
+            if self.prefetched != it:                     # the first step, or the first one after a re-sort: permute in front of the kernel
+                self._permute_forcing(h, b, self.sp)
+            else:
+                self.ts.wait_event(self.ev_scat[b])       # this step's forcing has arrived in set b
+            sa = self.sargs2[b]
+            sa.itimestep = it
+            self.eng.noahmplsm_async(sa, self.sp)
+            self.ev_kern[b].record(self.ts)
+            h1 = forcing_hour(it + 1, self.cfg.dt)        # the next step's forcing into the other set, beside this step's kernel
+            self.ts2.wait_event(self.ev_kern[1 - b])      # (the previous step's kernel read that set)
+            self._permute_forcing(h1, 1 - b, self.ts2.cuda_stream)
+            self.ev_scat[1 - b].record(self.ts2)
+            self.prefetched = it + 1
+        elif self.sorted and self.gw is not None:
+            self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
             self.eng.noahmplsm_async(self.sarg, self.sp)
         elif self.sorted:
-            self.scat.set_sources([self.forcing[h][k] for k in FKEYS])
-            self.scat(self.sp)
+            self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
             self.eng.noahmplsm_async(self.sarg, self.sp)
         else:
@@ -434,6 +479,8 @@ class Run:
         trip counts in the step just run (set_option record_cost + NOAHMP_SORT_COST)."""
         self.collect()
         self.ts.synchronize()
+        if getattr(self, "work2", None) is not None:
+            self.ts2.synchronize()                        # a prefetched forcing set dies with the old column order
         if self.args.cost_key:
             self.sort_kw["cost"] = True
         self.perm = self.eng.sort_store(self.d, **self.sort_kw)
@@ -539,6 +586,7 @@ class Run5:
         self._bind()
         self.rain = torch.zeros((ny, nx), dtype=torch.float32, device=dev)
         self.rec_a = self.rec_b = None
+        self.rec_idx = None
         self.reset_counters()
 
     def _bind(self):
@@ -553,21 +601,65 @@ class Run5:
         self.recs = self.synth5.Records(self.d.a["xlatin"], self.lon_d, st)
         self.torch.cuda.current_stream().synchronize()      # built on torch's current stream, read on the run's stream (a re-sort inside a run)
 
+    F5 = ("t3d", "qv3d", "u_phy", "v_phy", "p8w3d", "glw", "swdown", "rainbl", "dz8w", "coszin")    # what the forcing chain writes every step
+
+    def _forcing_sets(self):
+        """Two working sets of the forcing arrays (views of the store that share its state arrays), so that the forcing chain of step
+        n + 1 -- record evaluation, interpolation, preparation -- runs on a second stream beside step n's column kernel."""
+        import copy
+        torch = self.torch
+        d2 = copy.copy(self.d)
+        d2.a = dict(self.d.a)
+        for k in self.F5:
+            d2.a[k] = self.d.a[k].clone()
+        self.dv = (self.d, d2)
+        self.rain2 = (self.rain, torch.zeros_like(self.rain))
+        self.jul2 = [0.0, 0.0]
+        self.prefetched = None
+        self.rec_idx = None
+        if not hasattr(self, "ts2"):
+            self.ts2 = torch.cuda.Stream(device=self.dev)
+            self.ev_forc = (torch.cuda.Event(), torch.cuda.Event())
+            self.ev_kern = (torch.cuda.Event(), torch.cuda.Event())
+        torch.cuda.current_stream().synchronize()
+
+    def _chain(self, n, b, stream):
+        """the forcing of 0-based step n into working set b, enqueued on `stream` (a torch stream)"""
+        s5, eng = self.synth5, self.eng
+        ri, k = divmod(n, s5.RECORD_HOURS)
+        with self.torch.cuda.stream(stream):                                # record evaluation (torch) and the engine's kernels share one stream
+            if self.rec_idx != ri:
+                self.rec_a = self.rec_b if (self.rec_idx is not None and self.rec_idx == ri - 1) else self.recs.at(ri)
+                self.rec_b = self.recs.at(ri + 1)
+                self.rec_idx = ri
+            eng.forcing_interpolate(self.dv[b], self.rec_a, self.rec_b if k else None, 3600 * k, 3600 * s5.RECORD_HOURS, self.rain2[b],
+                                    stream=stream.cuda_stream, wait=False)
+            iday, ihour = s5.step_time(n)
+            self.jul2[b] = eng.forcing_prep(self.dv[b], self.lon_d, self.rain2[b], iday, ihour, first_step=(n == 0), stream=stream.cuda_stream, wait=False)
+
     def step(self, it):
         n = it - 1
-        s5, eng, d = self.synth5, self.eng, self.d
-        ri, k = divmod(n, s5.RECORD_HOURS)
-        with self.torch.cuda.stream(self.ts):                               # record evaluation (torch) and the engine's kernels share one stream
-            if k == 0 or self.rec_b is None:
-                self.rec_a = self.recs.at(ri) if (self.rec_b is None or k) else self.rec_b
-                self.rec_b = self.recs.at(ri + 1)
-            eng.forcing_interpolate(d, self.rec_a, self.rec_b if k else None, 3600 * k, 3600 * s5.RECORD_HOURS, self.rain, stream=self.sp, wait=False)
-            iday, ihour = s5.step_time(n)
-            jul = eng.forcing_prep(d, self.lon_d, self.rain, iday, ihour, first_step=(n == 0), stream=self.sp, wait=False)
-            if not hasattr(self, "first_hour"):
-                self.first_hour = ihour
-            self.step_hours.append(ihour)
-            eng.noahmplsm_async(d.step_args(it, 2000, jul), stream=self.sp)
+        if not hasattr(self, "dv"):
+            self._forcing_sets()
+        prefetch = not self.args.no_prefetch
+        b = (it & 1) if prefetch else 0
+        ihour = self.synth5.step_time(n)[1]
+        if not hasattr(self, "first_hour"):
+            self.first_hour = ihour
+        self.step_hours.append(ihour)
+        if self.prefetched != it:                                           # the first step, the first one after a re-sort, or no prefetch
+            self._chain(n, b, self.ts if not prefetch else self.ts2)
+            if prefetch:
+                self.ev_forc[b].record(self.ts2)
+        if prefetch:
+            self.ts.wait_event(self.ev_forc[b])
+        self.eng.noahmplsm_async(self.dv[b].step_args(it, 2000, self.jul2[b]), stream=self.sp)
+        if prefetch:
+            self.ev_kern[b].record(self.ts)
+            self.ts2.wait_event(self.ev_kern[1 - b])                        # the previous step's kernel read that working set
+            self._chain(n + 1, 1 - b, self.ts2)
+            self.ev_forc[1 - b].record(self.ts2)
+            self.prefetched = it + 1
         self.steps_since_sort = getattr(self, "steps_since_sort", 0) + 1
         if self.sorted and self.args.resort_every and it % self.args.resort_every == 0:
             self.maybe_resort(it)
@@ -583,13 +675,13 @@ class Run5:
         """`it` = the step just enqueued (the forcing records of the next one are evaluated again in the new column order)"""
         self.collect()
         self.ts.synchronize()
+        if hasattr(self, "ts2"):
+            self.ts2.synchronize()
         if self.args.cost_key:
             self.sort_kw["cost"] = True
         self.perm = self.eng.sort_store(self.d, **self.sort_kw)
         self._bind()
-        ri, k = divmod(it, self.synth5.RECORD_HOURS)                     # records are in the store's column order: evaluate them again
-        with self.torch.cuda.stream(self.ts):
-            self.rec_a, self.rec_b = (self.recs.at(ri), self.recs.at(ri + 1)) if k else (None, None)
+        self._forcing_sets()                                             # records and a prefetched set die with the old column order
         self.resorts += 1
         self.steps_since_sort = 0
 
@@ -872,6 +964,9 @@ def main():
     ap.add_argument("--lon-band", type=float, default=15.0,
                     help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
     ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="sorted config 2 / 3: permute each step's forcing in front of its kernel on the run's stream (rounds 1-4) instead of on a "
+                         "second stream beside the previous step's kernel")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
@@ -951,8 +1046,8 @@ def main():
     run = Run5(args, comm, eng, tb, dev) if workload == "config5" else Run(args, workload, comm, eng, tb, dev)
     t_setup = time.perf_counter() - t_setup
 
-    if args.cost_key:
-        eng.set_option("record_cost", 1)
+    if args.cost_key and eng.set_option("record_cost", 1) < 0:
+        raise RuntimeError("--cost-key needs a library built with -DNMP_COST_RECORD (tools/build_variants.py cost=-DNMP_COST_RECORD; NMP_LIB=...)")
     it = 0
     for _ in range(args.warmup):
         it += 1
@@ -1085,6 +1180,8 @@ def main():
 
     if rank == 0:
         K = args.steps
+        prefetching = workload in ("config2", "config3", "config4") and not args.no_sort and not args.no_prefetch
+        prefetch5 = workload == "config5" and not args.no_prefetch
         value = n_adv_all / dt
         # dominant kernel: the land range of the sorted layout (the mixed kernel of a tile-order run); its own event pair per step
         dom_ms = run.class_ms[0] / K
@@ -1124,14 +1221,17 @@ def main():
             desc += ("; sorted on the device by (class, vegetation type, snow-layer count, %s%g-K skin-temperature bin)"
                      % (("%g-degree longitude band, " % args.lon_band) if getattr(run, "band", None) else "", run.tsk_bin)
                      if run.sorted else "; tile order")
+            if prefetch5:
+                desc += "; step n + 1's forcing chain runs on a second stream beside step n's column kernel (two forcing working sets)"
         elif run.sorted:
             desc += ("; state resident in HBM, sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature "
-                     "bin); inside the timed region: the per-step permutation of the forcing (which arrives in tile order) and a staleness "
+                     "bin); inside the timed region: the per-step permutation of the forcing (which arrives in tile order%s) and a staleness "
                      "check every %d steps (a re-sort follows above %g %% stale columns: %d happened).  Forcing: the SURVEY 8d diurnal cycle, "
                      "time step %g s, SPATIALLY UNIFORM in zenith angle / short wave / rain (the whole grid is in day or night together: no "
                      "terminator, no precipitation fronts; per-column air-temperature offsets only) -- config 5's lat/lon-dependent zenith "
                      "angle costs ~25 %% more per column (config5_reference)"
-                     % (run.tsk_bin, args.resort_every, args.resort_frac * 100, run.resorts, args.dt))
+                     % (run.tsk_bin, "; step n + 1's runs on a second stream beside step n's column kernel, two forcing working sets" if prefetching else "",
+                        args.resort_every, args.resort_frac * 100, run.resorts, args.dt))
         else:
             desc += "; state resident in HBM, diurnal forcing (spatially uniform zenith angle / short wave / rain), time step %g s" % args.dt
         out = {

@@ -317,13 +317,13 @@ struct Ctx {
   int isurban;
   TabScalars ts;     // host: tab_scalars(the tables passed to noahmp_hip_set_tables)
   Urc u;
-  // optional cost record of this launch (set_option "record_cost"; NULL = off): two bytes per column, [2 t] = iterations of VEGE_FLUX's
+  // optional cost record of this launch (libraries built with -DNMP_COST_RECORD, set_option "record_cost"; NULL = off): two bytes per column, [2 t] = iterations of VEGE_FLUX's
   // canopy loop (lsm:3234; 0 without a canopy), [2 t + 1] = STOMATA bisection steps of both leaves (lsm:5413) -- the two trip counts
   // that differ from column to column.  Read back by the column sort (NOAHMP_SORT_COST): a wavefront runs as long as its slowest lane.
   unsigned char* cost;
 };
 NMP_DEV void record_cost(const Ctx& c, int which, int n) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(NMP_NO_COST_RECORD)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NMP_COST_RECORD)       // experiment builds only: the stores cost the land kernel 1.2 % (r05)
   if (c.cost) c.cost[2 * (size_t)(blockIdx.x * blockDim.x + threadIdx.x) + which] = (unsigned char)n;
 #else
   (void)c; (void)which; (void)n;

@@ -590,6 +590,7 @@ struct VegLoop {
         laishae, rssun, rssha, rsurf, eair, estg, gammav, air, cir, canliq, canice, latheav, sav, fwet, sfcprs,
         thair, czil;
   double r_rhocp, r_hcan, r_gammav;     // 1 / (RHOAIR*CPAIR), 1 / HCAN, 1 / GAMMAV: divisors of every iteration (div_rc)
+  double r_ur;                          // 1 / UR (OPT_SFC = 2 only)
   // carried from iteration to iteration / read after the loop
   MoState mo;
   float cm, ch, tv, tah, eah, h, hg, fhg, dtv, rahc, rahg, rb, cah, cvh, estv, destv, irc, shc, evc, tr, wstar,
@@ -614,8 +615,8 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
     sfcdif1(L.err, iter, sfctmp, L.r_rhocp, L.h, L.qair, L.zlvl, L.zpd, L.z0m, ur, MPE, L.mo, L.cm, L.ch);
   } else {
     sfcdif2(iter, L.z0m, L.tah, L.thair, ur, L.czil, L.zlvl, L.cm, L.ch, L.mo.moz, L.wstar, L.mo.fv);
-    L.ch = L.ch / ur;
-    L.cm = L.cm / ur;
+    L.ch = div_rc(L.ch, L.r_ur);                      // CH / UR, CM / UR (lsm:3318-3319): UR is fixed over the loop
+    L.cm = div_rc(L.cm, L.r_ur);
   }
   NMP_TIC(16);   // vege loop1: sfcdif
   L.rahc = nmp_max(1.f, 1.f / (L.ch * ur));
@@ -753,6 +754,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f};
     L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
     L.r_rhocp = q.r_rhocp; L.r_gammav = q.r_gammav;
+    if (c.O.sfc != 1) L.r_ur = rc64(ur);
     const double r_fveg = rc64(fveg);
     L.vaie = nmp_min(6.f, div_rc(q.vai, r_fveg));
     L.laisune = nmp_min(6.f, div_rc(q.laisun, r_fveg));
@@ -863,14 +865,15 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   // overwritten by the next iteration before anything reads them, so only the fifth evaluates them
   t = tdc(tgb);
   esat_sel(t, estg, destg);
+  const double r_ur = (c.O.sfc != 1) ? rc64(ur) : 0.0;
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
     if (c.O.sfc == 1) {
       sfcdif1(s.err, iter, sfctmp, q.r_rhocp, h, s.qair, q.zlvl, zpdg, z0m, ur, MPE, mo, cm, ch);
     } else {
       sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
-      ch = ch / ur;
-      cm = cm / ur;
+      ch = div_rc(ch, r_ur);                         // CH / UR, CM / UR (lsm:3776-3777)
+      cm = div_rc(cm, r_ur);
       if (s.snowh > 0.f) { cm = nmp_min(0.01f, cm); ch = nmp_min(0.01f, ch); }
     }
     float rahb = nmp_max(1.f, 1.f / (ch * ur));

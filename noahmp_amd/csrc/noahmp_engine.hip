@@ -136,7 +136,10 @@ int noahmp_hip_memcpy(void* dst, const void* src, size_t bytes, int kind) {
   int rc = ensure_init();
   if (rc) return rc;
   const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, k));
+  if (bytes) {
+    if (k == hipMemcpyDeviceToDevice) HIPCHK(hipMemcpy(dst, src, bytes, k));
+    else { HIPCHK(nmp_host::host_copy_async(dst, src, bytes, k, g.own_stream)); HIPCHK(hipStreamSynchronize(g.own_stream)); }
+  }
   return 0;
 }
 void noahmp_hip_free(void* p) { if (p) hipFree(p); }
@@ -219,8 +222,10 @@ int noahmp_hip_set_option(const char* key, int value) {
     }
   }
   else if (!strcmp(key, "record_cost")) {
+#ifdef NMP_COST_RECORD                            // (an experiment build, tools/build_variants.py cost=-DNMP_COST_RECORD; otherwise -1: unknown option)
     prev = g.record_cost;
     if (value == 0 || value == 1) { g.record_cost = value; if (!value) g.cost_fresh = false; }
+#endif
   }
   else if (!strcmp(key, "exact_libm")) prev = NMP_EXACT_LIBM;   // read-only: how this library was built
   return prev;
@@ -447,8 +452,8 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
       const FieldDesc& fd = kFields[f];
       if (fd.io == 2 && !up_out) continue;
       const char* host = (const char*)*(void* const*)((const char*)a + fd.off);
-      HIPCHK(hipMemcpyAsync((char*)g.mirror[f] + rowbytes[f] * r0, host + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
-                            hipMemcpyHostToDevice, g.s_up));
+      HIPCHK(nmp_host::host_copy_async((char*)g.mirror[f] + rowbytes[f] * r0, host + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
+                                       hipMemcpyHostToDevice, g.s_up));
     }
     HIPCHK(hipEventRecord(g.pipe_events[3 * c], g.s_up));
   }
@@ -473,8 +478,8 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
       char* host = (char*)*(void* const*)((const char*)a + fd.off);
-      HIPCHK(hipMemcpyAsync(host + rowbytes[f] * r0, (char*)g.mirror[f] + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
-                            hipMemcpyDeviceToHost, g.s_dn));
+      HIPCHK(nmp_host::host_copy_async(host + rowbytes[f] * r0, (char*)g.mirror[f] + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
+                                       hipMemcpyDeviceToHost, g.s_dn));
     }
   }
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -597,7 +602,7 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
         const size_t off = (size_t)k.k1 * ni * 4;
         HIPCHK(hipMemcpy2DAsync((char*)target + off, nka * ni * 4, (const char*)host + off, nka * ni * 4, ni * 4, nj, hipMemcpyHostToDevice, up));
       } else {
-        HIPCHK(hipMemcpyAsync(target, host, bytes, hipMemcpyHostToDevice, up));
+        HIPCHK(nmp_host::host_copy_async(target, host, bytes, hipMemcpyHostToDevice, up));
       }
     }
     g.mirror_host[f] = host;
@@ -635,7 +640,7 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
-      HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(nmp_host::host_copy_async(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
     }
   HIPCHK(hipStreamSynchronize(s));
   int code = 0;
@@ -668,7 +673,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];
     if (fd.io == 0) continue;
-    HIPCHK(hipMemcpyAsync(const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4, hipMemcpyDeviceToHost, g.own_stream));
+    HIPCHK(nmp_host::host_copy_async(const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4, hipMemcpyDeviceToHost, g.own_stream));
   }
   HIPCHK(hipStreamSynchronize(g.own_stream));
   g.resident_dirty = false;
@@ -715,7 +720,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
       // OUT arrays are uploaded too: columns the call does not touch (open water, sea ice, cells
       // outside its:ite/jts:jte, a column that raised a fatal) must come back unchanged, exactly
       // as the reference leaves them.
-      HIPCHK(hipMemcpyAsync(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      HIPCHK(nmp_host::host_copy_async(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
       *(void**)((char*)&k.a + fd.off) = g.mirror[f];
     }
   }
@@ -736,7 +741,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
       void* host = *(void* const*)((const char*)a + fd.off);
-      HIPCHK(hipMemcpyAsync(host, g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(nmp_host::host_copy_async(host, g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
     }
   }
   HIPCHK(hipStreamSynchronize(s));
@@ -908,7 +913,7 @@ long noahmp_hip_fetch_cost(uint8_t* host_out, long ncol, void* stream) {
   if (!g.d_cost || !g.cost_fresh || !host_out) return 0;
   const long n = ncol < g.cost_cols ? ncol : g.cost_cols;
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
-  if (hipMemcpyAsync(host_out, g.d_cost, (size_t)n * 2, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+  if (nmp_host::host_copy_async(host_out, g.d_cost, (size_t)n * 2, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
   if (hipStreamSynchronize(s) != hipSuccess) return 0;
   return n;
 }

@@ -178,6 +178,11 @@ class Engine:
             for i, t in enumerate(src):
                 self.src[i] = t.data_ptr()
 
+        def set_dests(self, dst):
+            """other destination tensors of the same shapes (e.g. the second of two forcing working sets)"""
+            for i, t in enumerate(dst):
+                self.dst[i] = t.data_ptr()
+
         def __call__(self, stream=None):
             rc = self.lib.noahmp_hip_gather_fields(self.n, self.dst, self.src, self.nlev, self.perm.data_ptr(), self.ni,
                                                    self.nj, stream)

@@ -3,8 +3,6 @@ BASELINE configs[2] workload at its full size.  north_star: columns sorted by (v
 the snow-layer count changes at lsm:7044 (COMBINE), 7110 (DIVIDE), 7177 (COMBO), 7294-7343 (SNOWH2O), so a run re-sorts."""
 import ctypes as C
 
-import os
-
 import numpy as np
 import pytest
 
@@ -27,23 +25,15 @@ def _cols(v, idx=None):
 
 
 def _up(x):
-    """numpy -> device through page-locked host memory.  (The multi-megabyte copies of the plan test went through pageable memory at
-    first: every few full `-m gpu` runs one of them died with "Memory access fault by GPU ... Write access to a read-only page" on a
-    host-heap address inside torch's own copy -- the runtime page-locks a pageable buffer where it lies.  Nothing of the engine is
-    involved in those copies; page-locked staging keeps the test about the plan.)"""
+    """numpy -> device.  (Round 4 staged these multi-megabyte copies through page-locked tensors because every few full `-m gpu` runs one
+    of torch's pageable copies died with "Memory access fault by GPU ... Write access to a read-only page".  Round 5 found the cause -- the HIP
+    runtime's in-place page-locking of pageable buffers of 128 MiB and more, tests/conftest.py -- and the staging is gone.)"""
     import torch
-    if os.environ.get("NMP_TEST_PAGEABLE_COPIES"):          # the round-4 behaviour, for the fault hunt (tools/experiments.sh faulthunt)
-        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
-    return torch.from_numpy(np.ascontiguousarray(x)).pin_memory().cuda()
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
 def _down(t):
-    import torch
-    if os.environ.get("NMP_TEST_PAGEABLE_COPIES"):
-        return t.cpu().numpy()
-    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-    h.copy_(t)
-    return h.numpy()
+    return t.cpu().numpy()
 
 
 def _host_key(s, tsk_bin=1.0, veg=True, snow=True, snow_first=False, band=None):
@@ -255,7 +245,8 @@ def test_config3_full_size_sorted_sample_bit_identical(engine, port, tables):
 
 
 def test_cost_key_sorts_by_recorded_trip_counts(engine, tables):
-    """set_option record_cost: a device-resident step leaves every land column's canopy-loop iterations and STOMATA bisection steps in an
+    """(Experiment builds only, -DNMP_COST_RECORD: the default library has no cost record -- its stores cost the land kernel 1.2 % and the
+    key does not pay, profiles/r05_experiments.md section 2 -- and this test skips.)  set_option record_cost: a device-resident step leaves every land column's canopy-loop iterations and STOMATA bisection steps in an
     engine-owned plane (tile's current order); noahmp_hip_sort_columns(NOAHMP_SORT_COST) puts a bucket of them into the key, between the
     band and the temperature bin.  The order is the stable sort of that key, staleness ignores the bucket, a permutation invalidates the
     record, and the sorted store advances to the same bits as the tile-order one."""
@@ -265,6 +256,8 @@ def test_cost_key_sorts_by_recorded_trip_counts(engine, tables):
     synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
     d, ref = s.to_device("cuda:0"), s.to_device("cuda:0")
     prev = engine.set_option("record_cost", 1)
+    if prev < 0:
+        pytest.skip("library built without -DNMP_COST_RECORD")
     try:
         engine.noahmplsm(d, 1, 2000, 180.0)
         engine.noahmplsm(ref, 1, 2000, 180.0)

@@ -20,8 +20,8 @@
 #   phase [LIB...]                 phase shares of the profiling build (-DNMP_PHASE_TIMERS: variants/lib_prof.so), after an optional A/B
 #   k2                             the flux solvers as a kernel of their own (variants/lib_k2.so: -DNMP_K2_EXPERIMENT) at 1..4 waves per SIMD, and
 #                                  the land kernel truncated before / behind them (lib_t3.so, lib_t7.so: -DNMP_TRUNC=3 / 7)
-#   faulthunt [N [pageable|- [ENV=VALUE...]]]   the whole -m gpu suite N times (default 10), each in its own process, with the abort shim; `pageable`: the
-#                                  sort tests' large copies through pageable memory (the round-4 condition of the sporadic GPU memory fault)
+#   faulthunt [N [- [ENV=VALUE...]]]   the whole -m gpu suite N times (default 10), each in its own process, with the abort shim;
+#                                  GPU_PINNED_MIN_XFER_SIZE=128 restores the runtime default under which 7 of 10 runs died (round 5)
 #   cost [WORKLOAD...]             the cost sub-key of the column order (bench.py --cost-key: trip counts recorded by the step before the sort),
 #                                  A/B per workload (default config3 config5): off | on after the warm-up | on + a re-sort every 6 / 12 steps
 #   micro NAME                     run tools/micro/NAME.bin (built in the dev container: hipcc --offload-arch=gfx950 -O3 NAME.hip -o NAME.bin)
@@ -193,7 +193,7 @@ k2)
   ;;
 faulthunt)
   n=${1:-10}; bad=0
-  [ "$2" == "pageable" ] && export NMP_TEST_PAGEABLE_COPIES=1
+  # (round 5: the sort tests' copies are pageable again by default; "pageable" is kept as a no-op second argument)
   shift 2 2>/dev/null
   for kv in "$@"; do export "$kv"; echo "faulthunt: $kv"; done          # e.g. GPU_PINNED_MIN_XFER_SIZE=100000 (MiB: never pin a pageable buffer in place)
   O=$O/$(echo "run$*" | tr -c 'A-Za-z0-9=_\n' '_'); mkdir -p $O
@@ -204,9 +204,11 @@ faulthunt)
     echo "run $i rc=$rc $(tail -1 $O/run$i.log | cut -c1-120)"
     [ -f $O/abort$i.txt ] && head -30 $O/abort$i.txt
   done
-  echo "faulthunt: $bad of $n runs failed (NMP_TEST_PAGEABLE_COPIES=${NMP_TEST_PAGEABLE_COPIES:-0})"
+  echo "faulthunt: $bad of $n runs failed (GPU_PINNED_MIN_XFER_SIZE=${GPU_PINNED_MIN_XFER_SIZE:-conftest default})"
   ;;
 cost)
+  # build first (dev container): python tools/build_variants.py cost=-DNMP_COST_RECORD
+  export NMP_LIB=$R/noahmp_amd/csrc/variants/lib_cost.so
   if [ $# -eq 0 ]; then set -- config3 config5; fi
   for w in "$@"; do
     for v in "" "--cost-key" "--cost-key --cost-resort-every 12 --resort-every 12" "--cost-key --cost-resort-every 6 --resort-every 6" ""; do
