@@ -29,10 +29,9 @@ import subprocess
 import sys
 import time
 
-# Set-up copies of whole 7 M-column arrays (up to 200 MB each) go through torch's pageable copies: keep the HIP runtime from page-locking such
-# buffers in place (its cached mappings of heap memory fault later on this stack: tests/conftest.py, profiles/r05_experiments.md section 3).
-# Nothing inside a timed region copies from or to pageable memory except the host_path_reference legs, whose copies the engine cuts into
-# 32-MiB pieces anyway (nmp_engine_host.hpp: host_copy_async).
+# Set-up copies of whole 7 M-column arrays go through torch's pageable copies: keep the HIP runtime from page-locking such buffers in place
+# (its cached mappings of heap memory fault later on this stack: tests/conftest.py, profiles/r05_experiments.md section 3).  Nothing inside a
+# timed region copies from or to pageable memory except the first host_path_reference leg, which says so.
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -362,7 +361,7 @@ class Run:
         # kernel is about to read, write-after-read on the set the previous kernel read).
         self.work2 = None
         self.prefetched = None
-        if not self.args.no_prefetch:
+        if self.args.prefetch:
             torch = self.torch
             self.work2 = ({k: self.work[k] for k in FKEYS}, {k: self.work[k].clone() for k in FKEYS})
             sarg_b = d.step_args(1, 2000, 180.0)
@@ -788,7 +787,8 @@ def timed_leg(run, steps, warmup, barrier):
 # Option sets of the `options_reference` legs: none of them has an ahead-of-time kernel, so they run through the kernels
 # noahmp_jit.hip specialises with hiprtc (loaded from the in-tree cache build() warms), the last leg through the generic kernel
 # (run-time options) that serves a call when hiprtc is not available
-OPTION_LEGS = (("DVEG=2 (dynamic vegetation + CARBON)", dict(idveg=2), True),
+OPTION_LEGS = (("namelist options (the headline's ahead-of-time kernel) in the window of these legs", {}, True),
+               ("DVEG=2 (dynamic vegetation + CARBON)", dict(idveg=2), True),
                ("OPT_SFC=2 (Chen97 surface layer)", dict(iopt_sfc=2), True),
                ("OPT_FRZ=2 x OPT_INF=2 (Koren99 supercooled water and frozen-soil permeability)", dict(iopt_frz=2, iopt_inf=2), True),
                ("OPT_RUN=3 (Schaake96 free drainage)", dict(iopt_run=3), True),
@@ -809,7 +809,7 @@ def options_legs(args, comm, eng, tb, dev, barrier, torch):
             r = Run(a, "config3", comm, eng, tb, dev)
             dt = timed_leg(r, steps, warmup, barrier)
             K = steps
-            out.append({"options": label, "kernel": "run-time specialised (hiprtc)" if specialised else "generic",
+            out.append({"options": label, "kernel": ("ahead-of-time specialised" if not opts else "run-time specialised (hiprtc)") if specialised else "generic",
                         "value": r.n_adv / dt, "unit": "column-steps/s", "ms_per_step": dt / K * 1e3, "steps": K,
                         "land_kernel_ms": r.class_ms[0] / K, "columns_per_launch": int(r.n_land / K),
                         "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_land / K) / (r.class_ms[0] / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -965,8 +965,12 @@ def main():
                     help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true",
-                    help="sorted config 2 / 3: permute each step's forcing in front of its kernel on the run's stream (rounds 1-4) instead of on a "
-                         "second stream beside the previous step's kernel")
+                    help="config 5: run each step's forcing chain (record evaluation, interpolation, preparation) in front of its kernel on the run's "
+                         "stream instead of on a second stream beside the previous step's kernel (-5 %% per step, round 5)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="sorted config 2 / 3 / 4: permute step n + 1's forcing on a second stream beside step n's kernel (two forcing working "
+                         "sets).  Measured in round 5: no gain -- two land waves per SIMD hold the whole register file, a wave of the permutation "
+                         "kernel can only take the place of one -- so it is off by default")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
@@ -1180,7 +1184,7 @@ def main():
 
     if rank == 0:
         K = args.steps
-        prefetching = workload in ("config2", "config3", "config4") and not args.no_sort and not args.no_prefetch
+        prefetching = workload in ("config2", "config3", "config4") and not args.no_sort and args.prefetch
         prefetch5 = workload == "config5" and not args.no_prefetch
         value = n_adv_all / dt
         # dominant kernel: the land range of the sorted layout (the mixed kernel of a tile-order run); its own event pair per step
@@ -1191,7 +1195,7 @@ def main():
         # PMC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this very command,
         # tools/run_profile.sh -> tools/collect_profile.py): the newest committed summary is quoted, and only when workload and
         # columns per launch are those of the profile
-        for tag in ("r04", "r03", "r02"):
+        for tag in ("r05", "r04", "r03", "r02"):
             tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
             if not os.path.exists(tpath):
                 continue

@@ -59,7 +59,13 @@ typedef size_t nmp_ij_t;
 #define G3(f, lev, nk) k.a.f[((size_t)jj * (nk) + (lev)) * k.ni + ii]
 #else
 typedef uint32_t nmp_ij_t;
-template <class T> NMP_DEV T& at32(T* base, uint32_t idx) { return *(T*)((char*)base + (size_t)(idx * (uint32_t)sizeof(T))); }
+template <class T> NMP_DEV T& at32(T* base, uint32_t idx) {
+  uint32_t o = idx * (uint32_t)sizeof(T);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NMP_SADDR_LAUNDER)
+  asm volatile("" : "+v"(o));
+#endif
+  return *(T*)((char*)base + (size_t)o);
+}
 #define G2(f) nmp::at32(k.a.f, ij)
 #define G3(f, lev, nk) nmp::at32(k.a.f, ((uint32_t)jj * (uint32_t)(nk) + (uint32_t)(lev)) * (uint32_t)k.ni + (uint32_t)ii)
 #endif

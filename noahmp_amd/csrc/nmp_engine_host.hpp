@@ -126,21 +126,6 @@ void sort_finalize();     // noahmp_sort.hip
   char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   nmp_host::g.last_error = b_; return -100; } } while (0)
 
-// Copies between CALLER memory and the device go out in pieces of at most kHostCopyPiece bytes.  The HIP runtime page-locks a pageable
-// buffer IN PLACE when one copy reaches GPU_PINNED_MIN_XFER_SIZE (128 MiB by default) and keeps that mapping cached; on this stack those
-// cached mappings of process heap memory later fault ("Memory access fault by GPU ... Write access to a read-only page" on a host heap
-// address: 7 of 10 full test-suite runs, 0 of 6 with the threshold raised out of reach -- profiles/r05_experiments.md section 3).  Smaller
-// copies go through the runtime's own staging buffers.  The engine's explicit registrations ("pin_host_arrays") are not affected.
-constexpr size_t kHostCopyPiece = 32u << 20;
-inline hipError_t host_copy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
-  for (size_t off = 0; off < bytes; off += kHostCopyPiece) {
-    const size_t n = bytes - off < kHostCopyPiece ? bytes - off : kHostCopyPiece;
-    const hipError_t e = hipMemcpyAsync((char*)dst + off, (const char*)src + off, n, kind, s);
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-
 int ensure_init();
 // sum the slots of h_counts into out[0..3]
 void sum_counts(long long* out);

@@ -7,6 +7,7 @@
 // coalesced structure-of-arrays the GPU wants.  No CPU fallback exists in this library.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -106,6 +107,15 @@ void launch(const KArgs& k, long ncol, bool lds, hipStream_t st) {
 
 }  // namespace
 
+// Before the process makes its first HIP call (a Fortran / C host: that call is the engine's): keep the HIP runtime from page-locking
+// pageable host buffers IN PLACE.  It does so for every copy of ~2 MiB and more (GPU_PINNED_MIN_XFER_SIZE; measured: tools/micro/
+// pageable_copy.py) and caches the mapping; on the ROCm 7.0 runtime such cached mappings of heap memory that has since been freed and
+// reused fault in a later copy ("Memory access fault by GPU ... Write access to a read-only page" on a host heap address: 7 of 10 runs of the
+// GPU test suite, 0 of 16 with the threshold out of reach -- profiles/r05_experiments.md section 3).  Copies of pageable memory then go
+// through the runtime's staging buffers (~25 instead of ~48 GB/s up: callers that care page-lock their arrays, "pin_host_arrays", as the
+// Fortran shim does).  An explicit setting of the variable in the environment wins; a process whose HIP runtime is already up is not affected.
+__attribute__((constructor)) static void nmp_runtime_env() { setenv("GPU_PINNED_MIN_XFER_SIZE", "1048576", 0); }
+
 extern "C" {
 
 int noahmp_hip_abi_version(void) { return NOAHMP_HIP_ABI_VERSION; }
@@ -136,10 +146,7 @@ int noahmp_hip_memcpy(void* dst, const void* src, size_t bytes, int kind) {
   int rc = ensure_init();
   if (rc) return rc;
   const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  if (bytes) {
-    if (k == hipMemcpyDeviceToDevice) HIPCHK(hipMemcpy(dst, src, bytes, k));
-    else { HIPCHK(nmp_host::host_copy_async(dst, src, bytes, k, g.own_stream)); HIPCHK(hipStreamSynchronize(g.own_stream)); }
-  }
+  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, k));
   return 0;
 }
 void noahmp_hip_free(void* p) { if (p) hipFree(p); }
@@ -452,7 +459,7 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
       const FieldDesc& fd = kFields[f];
       if (fd.io == 2 && !up_out) continue;
       const char* host = (const char*)*(void* const*)((const char*)a + fd.off);
-      HIPCHK(nmp_host::host_copy_async((char*)g.mirror[f] + rowbytes[f] * r0, host + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
+      HIPCHK(hipMemcpyAsync((char*)g.mirror[f] + rowbytes[f] * r0, host + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
                                        hipMemcpyHostToDevice, g.s_up));
     }
     HIPCHK(hipEventRecord(g.pipe_events[3 * c], g.s_up));
@@ -478,7 +485,7 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
       char* host = (char*)*(void* const*)((const char*)a + fd.off);
-      HIPCHK(nmp_host::host_copy_async(host + rowbytes[f] * r0, (char*)g.mirror[f] + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
+      HIPCHK(hipMemcpyAsync(host + rowbytes[f] * r0, (char*)g.mirror[f] + rowbytes[f] * r0, rowbytes[f] * (r1 - r0),
                                        hipMemcpyDeviceToHost, g.s_dn));
     }
   }
@@ -602,7 +609,7 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
         const size_t off = (size_t)k.k1 * ni * 4;
         HIPCHK(hipMemcpy2DAsync((char*)target + off, nka * ni * 4, (const char*)host + off, nka * ni * 4, ni * 4, nj, hipMemcpyHostToDevice, up));
       } else {
-        HIPCHK(nmp_host::host_copy_async(target, host, bytes, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpyAsync(target, host, bytes, hipMemcpyHostToDevice, up));
       }
     }
     g.mirror_host[f] = host;
@@ -640,7 +647,7 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
-      HIPCHK(nmp_host::host_copy_async(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
     }
   HIPCHK(hipStreamSynchronize(s));
   int code = 0;
@@ -673,7 +680,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];
     if (fd.io == 0) continue;
-    HIPCHK(nmp_host::host_copy_async(const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4, hipMemcpyDeviceToHost, g.own_stream));
+    HIPCHK(hipMemcpyAsync(const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4, hipMemcpyDeviceToHost, g.own_stream));
   }
   HIPCHK(hipStreamSynchronize(g.own_stream));
   g.resident_dirty = false;
@@ -720,7 +727,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
       // OUT arrays are uploaded too: columns the call does not touch (open water, sea ice, cells
       // outside its:ite/jts:jte, a column that raised a fatal) must come back unchanged, exactly
       // as the reference leaves them.
-      HIPCHK(nmp_host::host_copy_async(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
       *(void**)((char*)&k.a + fd.off) = g.mirror[f];
     }
   }
@@ -741,7 +748,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
       void* host = *(void* const*)((const char*)a + fd.off);
-      HIPCHK(nmp_host::host_copy_async(host, g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(host, g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
     }
   }
   HIPCHK(hipStreamSynchronize(s));
@@ -913,7 +920,7 @@ long noahmp_hip_fetch_cost(uint8_t* host_out, long ncol, void* stream) {
   if (!g.d_cost || !g.cost_fresh || !host_out) return 0;
   const long n = ncol < g.cost_cols ? ncol : g.cost_cols;
   hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
-  if (nmp_host::host_copy_async(host_out, g.d_cost, (size_t)n * 2, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
+  if (hipMemcpyAsync(host_out, g.d_cost, (size_t)n * 2, hipMemcpyDeviceToHost, s) != hipSuccess) return 0;
   if (hipStreamSynchronize(s) != hipSuccess) return 0;
   return n;
 }

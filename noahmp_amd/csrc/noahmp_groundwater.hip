@@ -203,7 +203,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
       rc = nmp_host::ensure_bytes(&g.gw_mirror[f], &g.gw_mirror_bytes[f], bytes);
       if (rc) return rc;
       void* host = *(void* const*)((const char*)a + kW[f].off);
-      HIPCHK(nmp_host::host_copy_async(g.gw_mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(g.gw_mirror[f], host, bytes, hipMemcpyHostToDevice, s));
       *(void**)((char*)&k.a + kW[f].off) = g.gw_mirror[f];
     }
   }
@@ -236,7 +236,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
       if (kW[f].io == 0 && !(init && !strcmp(kW[f].name, "smoiseq"))) continue;   // GROUNDWATER_INIT writes SMOISEQ
       const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);
       void* host = *(void* const*)((const char*)a + kW[f].off);
-      HIPCHK(nmp_host::host_copy_async(host, g.gw_mirror[f], bytes, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(host, g.gw_mirror[f], bytes, hipMemcpyDeviceToHost, s));
     }
   }
   HIPCHK(hipStreamSynchronize(s));

@@ -72,7 +72,7 @@ extern "C" int noahmp_hip_init(const noahmp_step_args* a, int iswater, int fndsn
       rc = nmp_host::ensure_bytes(&mir[f], &g.init_mirror_bytes[f], bytes);
       if (rc) return rc;
       void* host = *(void* const*)((const char*)a + kI[f].off);
-      HIPCHK(nmp_host::host_copy_async(mir[f], host, bytes, hipMemcpyHostToDevice, s));      // outputs too: untouched cells survive
+      HIPCHK(hipMemcpyAsync(mir[f], host, bytes, hipMemcpyHostToDevice, s));      // outputs too: untouched cells survive
       *(void**)((char*)&k.a + kI[f].off) = mir[f];
     }
   }
@@ -92,7 +92,7 @@ extern "C" int noahmp_hip_init(const noahmp_step_args* a, int iswater, int fndsn
       if (!kI[f].out) continue;
       const size_t nk = kI[f].lev == 2 ? NOAHMP_NSOIL : kI[f].lev == 3 ? 3 : kI[f].lev == 4 ? NOAHMP_NSOIL + 3 : 1;
       void* host = *(void* const*)((const char*)a + kI[f].off);
-      HIPCHK(nmp_host::host_copy_async(host, mir[f], (size_t)k.ni * nj * nk * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(host, mir[f], (size_t)k.ni * nj * nk * 4, hipMemcpyDeviceToHost, s));
     }
   }
   HIPCHK(hipStreamSynchronize(s));

@@ -4,12 +4,13 @@ import sys
 import numpy as np
 import pytest
 
-# Before anything initialises HIP.  The test suite moves arrays of up to 200 MB between numpy and the device through torch's pageable copies;
-# at 128 MiB (GPU_PINNED_MIN_XFER_SIZE's default) the HIP runtime page-locks such a buffer in place and caches the mapping, and on this stack
-# those cached mappings of heap memory later fault ("Memory access fault by GPU ... Write access to a read-only page" on a host heap address,
-# in whatever copy comes next): 7 of 10 full `-m gpu` runs died that way, 0 of 6 with the threshold out of reach, independently of the copy
-# engine (HSA_ENABLE_SDMA=0: 4 of 6) and with no page-locked registration of the engine alive (the fixture below) --
-# profiles/r05_experiments.md section 3.  [MiB]; an explicit setting in the environment wins (tools/experiments.sh faulthunt).
+# Before anything initialises HIP.  The test suite moves arrays of up to 200 MB between numpy and the device through torch's pageable copies.
+# For every pageable copy of ~2 MiB and more the HIP runtime page-locks the buffer in place and caches the mapping (GPU_PINNED_MIN_XFER_SIZE;
+# tools/micro/pageable_copy.py), and on this stack those cached mappings of heap memory later fault ("Memory access fault by GPU ... Write
+# access to a read-only page" on a host heap address, in whatever copy comes next): 7 of 10 full `-m gpu` runs died that way, 0 of 16 with
+# the threshold out of reach, independently of the copy engine (HSA_ENABLE_SDMA=0: 4 of 6) and with no page-locked registration of the
+# engine alive (the fixture below) -- profiles/r05_experiments.md section 3.  [MiB]; an explicit setting in the environment wins
+# (tools/experiments.sh faulthunt 10 - GPU_PINNED_MIN_XFER_SIZE=1).
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

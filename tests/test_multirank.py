@@ -559,7 +559,7 @@ def test_bench_config4_sorted_equals_tile_order(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["config4", "config3", "config4-dt900"])
+@pytest.mark.parametrize("workload", ["config4", "config3", "config4-dt900", "config3-prefetch", "config4-prefetch"])
 def test_bench_run_equals_the_oracle(workload, tmp_path, port, tables):
     """The run bench.py times (small grid: column step on the sorted layout with the per-step forcing permutation; config 4: plus
     WTABLE_mmf_noahmp every STEPWTD steps on planes returned to (i,j) order) against the oracle advancing the same global grid in
@@ -569,8 +569,9 @@ def test_bench_run_equals_the_oracle(workload, tmp_path, port, tables):
     import bench
     gx, gy = 96, 130
     dt = 900.0 if workload.endswith("dt900") else 3600.0
+    extra = ["--prefetch"] if workload.endswith("prefetch") else []      # step n + 1's forcing permuted on a second stream beside step n's kernel
     workload = workload.split("-")[0]
-    res, dump = _run_bench(["--gpus", "1", "--workload", workload, "--dt", str(dt)], str(tmp_path), "gpu")
+    res, dump = _run_bench(["--gpus", "1", "--workload", workload, "--dt", str(dt)] + extra, str(tmp_path), "gpu")
     lateral = workload == "config4"
     stepwtd = max(int(30.0 * 60.0 / dt + 0.5), 1)
     if lateral:

@@ -27,7 +27,7 @@ def _cols(v, idx=None):
 def _up(x):
     """numpy -> device.  (Round 4 staged these multi-megabyte copies through page-locked tensors because every few full `-m gpu` runs one
     of torch's pageable copies died with "Memory access fault by GPU ... Write access to a read-only page".  Round 5 found the cause -- the HIP
-    runtime's in-place page-locking of pageable buffers of 128 MiB and more, tests/conftest.py -- and the staging is gone.)"""
+    runtime's in-place page-locking of pageable buffers, tests/conftest.py -- and the staging is gone.)"""
     import torch
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 

@@ -194,7 +194,7 @@ k2)
 faulthunt)
   n=${1:-10}; bad=0
   # (round 5: the sort tests' copies are pageable again by default; "pageable" is kept as a no-op second argument)
-  shift 2 2>/dev/null
+  shift; shift
   for kv in "$@"; do export "$kv"; echo "faulthunt: $kv"; done          # e.g. GPU_PINNED_MIN_XFER_SIZE=100000 (MiB: never pin a pageable buffer in place)
   O=$O/$(echo "run$*" | tr -c 'A-Za-z0-9=_\n' '_'); mkdir -p $O
   for i in $(seq 1 $n); do
