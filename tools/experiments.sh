@@ -271,7 +271,7 @@ except Exception as e: print('FAILED', '$o', e)" | tee -a $O/fuzzopts5.log
   done < $O/sets.txt
   ;;
 profile)
-  TAG=${1:-r04}
+  TAG=${1:-r05}
   P=$R/gpurun_out/prof; rm -rf $P; mkdir -p $P
   python3 $R/bench.py --no-cpu-baseline 2> $P/bench_plain.err | tail -1 > $P/bench_plain.json
   cd /tmp && export TMPDIR=/tmp
