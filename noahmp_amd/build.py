@@ -20,7 +20,10 @@ def _headers():
 
 
 # -ffp-contract=off: keep the reference's a*b+c rounding (no FMA contraction); no fast-math.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
+# -amdgpu-sched-strategy=max-ilp: the column kernel is bound by its waves' own instruction streams; this scheduler fills the gfx950 hazard
+# slots (v_cmp -> v_cndmask, v_div_scale -> v_div_fmas) with independent work instead of s_nop: 584 -> 376 static s_nop, land kernel -0.45 %
+# (A/B, profiles/r05_experiments.md section 6).  Scheduling only: same instructions, same results.  noahmp_jit.hip passes the same flag.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-Wno-unused-value", "-I" + os.path.join(_HERE, "..", "include")]
 
 

@@ -88,7 +88,9 @@ const char* kWrapper =
     "  column_kernel_body<256, true, 1>(k); }\n"
     "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m2(const nmp::KArgs k) {\n"
     "  column_kernel_body<256, true, 2>(k); }\n";
-const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+// (the scheduler strategy: as noahmp_amd/build.py -- fewer hazard s_nop in the issue-bound column kernel, round 5)
+const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+constexpr int kNumCompileFlags = sizeof(kCompileFlags) / sizeof(kCompileFlags[0]);
 
 uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
   const unsigned char* c = (const unsigned char*)p;
@@ -216,8 +218,9 @@ bool compile(const int* o, JitKernels& out, std::string& log) {
   if (hiprtcCreateProgram(&prog, src.c_str(), "nmp_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram"; return false; }
   const std::string dir = source_dir();
   const std::string i1 = "-I" + dir, i2 = "-I" + dir + "/../../include";
-  const char* opts[] = {kCompileFlags[0], kCompileFlags[1], kCompileFlags[2], kCompileFlags[3], i1.c_str(), i2.c_str()};
-  const hiprtcResult r = hiprtcCompileProgram(prog, 6, opts);
+  std::vector<const char*> opts(kCompileFlags, kCompileFlags + kNumCompileFlags);
+  opts.push_back(i1.c_str()); opts.push_back(i2.c_str());
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
   if (r != HIPRTC_SUCCESS) {
     size_t n = 0;
     hiprtcGetProgramLogSize(prog, &n);
