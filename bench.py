@@ -617,7 +617,9 @@ class Run5:
         self.prefetched = None
         self.rec_idx = None
         if not hasattr(self, "ts2"):
-            self.ts2 = torch.cuda.Stream(device=self.dev)
+            # high priority: the chain is a dozen small dependent launches; behind the land kernel's ~110 000 pending workgroups each of them
+            # would wait for the dispatcher, and the next step's kernel for the last of them
+            self.ts2 = torch.cuda.Stream(device=self.dev, priority=-1)
             self.ev_forc = (torch.cuda.Event(), torch.cuda.Event())
             self.ev_kern = (torch.cuda.Event(), torch.cuda.Event())
         torch.cuda.current_stream().synchronize()

@@ -7,6 +7,10 @@
 #include <vector>
 #include "noahmp_hip.h"
 
+#ifndef NMP_FIXED_BLOCK
+#define NMP_FIXED_BLOCK 64        // workgroup size of the option-specialised kernels (nmp_kernel.hpp)
+#endif
+
 namespace nmp_host {
 
 // Tally counters (land / glacier / skipped columns) are spread over kCountSlots cache lines, indexed by

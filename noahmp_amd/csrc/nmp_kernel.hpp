@@ -20,6 +20,14 @@ using namespace nmp;
 #ifndef NMP_WAVES_PER_EU
 #define NMP_WAVES_PER_EU 2
 #endif
+// Workgroup size of the option-specialised kernels (ahead-of-time units and hiprtc units).  One wave per workgroup: a workgroup's LDS
+// (the layer slots of its columns) is released when its LAST wave ends, and with 256-thread workgroups (59 KB each, two per CU) a
+// SIMD whose wave has finished idles until the three other waves of that workgroup have -- their trip counts differ.  Round 5, A/B on one
+// box: config 3 land kernel 3.278 (256) / 3.229 (128) / **3.186 ms (64)**; config 5 3.338 / 3.113 / **3.042**.  (Round 4 measured -0.4 % for
+// 128 on a kernel that still waited more than it computed.)
+#ifndef NMP_FIXED_BLOCK
+#define NMP_FIXED_BLOCK 64
+#endif
 
 // One thread = one column-step (the ILOOP body, drv:424-837).
 // MODE 0: the tile as it is (any mix of classes).  MODE 1 / 2 / 3: a range of a class-sorted layout that holds only land /

@@ -63,6 +63,7 @@ const char* kBuildMacros =
     "#define NMP_EXACT_LIBM " NMP_STR(NMP_EXACT_LIBM) "\n"
     "#define NMP_WAVES_PER_EU " NMP_STR(NMP_WAVES_PER_EU) "\n"
     "#define NMP_LIBM_LDS " NMP_STR(NMP_LIBM_LDS) "\n"
+    "#define NMP_FIXED_BLOCK " NMP_STR(NMP_FIXED_BLOCK) "\n"
 #ifdef NMP_TRUNC
     "#define NMP_TRUNC " NMP_STR(NMP_TRUNC) "\n"
 #endif
@@ -82,12 +83,12 @@ const char* kBuildMacros =
 // the wrapper around the headers (kernel names, launch bounds): part of the cache key like the headers themselves
 const char* kWrapper =
     "#include \"nmp_kernel.hpp\"\n"
-    "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m0(const nmp::KArgs k) {\n"
-    "  column_kernel_body<256, true, 0>(k); }\n"
-    "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m1(const nmp::KArgs k) {\n"
-    "  column_kernel_body<256, true, 1>(k); }\n"
-    "extern \"C\" __global__ void __launch_bounds__(256, NMP_WAVES_PER_EU) nmp_jit_m2(const nmp::KArgs k) {\n"
-    "  column_kernel_body<256, true, 2>(k); }\n";
+    "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m0(const nmp::KArgs k) {\n"
+    "  column_kernel_body<NMP_FIXED_BLOCK, true, 0>(k); }\n"
+    "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m1(const nmp::KArgs k) {\n"
+    "  column_kernel_body<NMP_FIXED_BLOCK, true, 1>(k); }\n"
+    "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m2(const nmp::KArgs k) {\n"
+    "  column_kernel_body<NMP_FIXED_BLOCK, true, 2>(k); }\n";
 // (the scheduler strategy: as noahmp_amd/build.py -- fewer hazard s_nop in the issue-bound column kernel, round 5)
 const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
 constexpr int kNumCompileFlags = sizeof(kCompileFlags) / sizeof(kCompileFlags[0]);
@@ -268,7 +269,7 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
   const long n = mode == 0 ? (long)d.nti * d.ntj : d.t_count;
   if (n <= 0) return true;
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const hipError_t e = hipModuleLaunchKernel(it->second.fn[(mode == 1 || mode == 2) ? mode : 0], (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, s,
+  const hipError_t e = hipModuleLaunchKernel(it->second.fn[(mode == 1 || mode == 2) ? mode : 0], (unsigned)((n + NMP_FIXED_BLOCK - 1) / NMP_FIXED_BLOCK), 1, 1, NMP_FIXED_BLOCK, 1, 1, 0, s,
                                              nullptr, extra);
   if (e != hipSuccess) { (void)hipGetLastError(); it->second.failed = true; g.last_error = "launch of a run-time compiled kernel failed: generic kernel used"; return false; }
   return true;

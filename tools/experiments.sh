@@ -34,7 +34,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R" || exit 1
 CMD=$1; shift
 O=$R/gpurun_out/exp_$CMD; mkdir -p "$O"
-LAND='noahmp_column_kernel<256, true, 1>'
+LAND='noahmp_column_kernel<64, true, 1>'
 
 summarise() {      # summarise FILE TAG: one line of a bench JSON
   python3 - "$1" "$2" <<'PY'
