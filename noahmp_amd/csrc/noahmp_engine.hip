@@ -350,12 +350,7 @@ static void launch_any(const KArgs& k_in, hipStream_t s, bool class_ranges = fal
     const bool fork = g.overlap_class_kernels && g.sorted_land > 0 && n_rest > 0;
     g.last_launch_kind = fork ? 2 : 1;
     if (fork && !g.aux_stream) {
-      // high priority: the few hundred workgroups of the land-ice / skipped ranges go out ahead of the land kernel's ~110 000 pending ones
-      // instead of trickling in behind them (their end would then be the end of the step, and their reported time with it)
-      int least = 0, greatest = 0;
-      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-          hipStreamCreateWithPriority(&g.aux_stream, hipStreamNonBlocking, greatest) != hipSuccess)
-        hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);
+      hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);       // (a high-priority stream: no gain, profiles/r05_experiments.md section 7)
       hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming);
       hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming);
     }
