@@ -602,37 +602,70 @@ class Run5:
 
     F5 = ("t3d", "qv3d", "u_phy", "v_phy", "p8w3d", "glw", "swdown", "rainbl", "dz8w", "coszin")    # what the forcing chain writes every step
 
+    DEPTH = 3          # how many steps ahead the forcing chain runs (one more working set than that)
+
     def _forcing_sets(self):
-        """Two working sets of the forcing arrays (views of the store that share its state arrays), so that the forcing chain of step
-        n + 1 -- record evaluation, interpolation, preparation -- runs on a second stream beside step n's column kernel."""
+        """DEPTH + 1 working sets of the forcing arrays (views of the store that share its state arrays), so that the forcing chain of step
+        n + DEPTH -- record evaluation, interpolation, preparation -- is enqueued on a second stream while step n's column kernel runs.
+        Depth 1 was not enough: beside the land kernel the chain's kernels only get a share of the wave slots that come free, so the last of
+        them ends ~70 us after the land kernel -- and the ~45 small launches of a record evaluation (every third step) were still running,
+        one after the other on an idle GPU, 0.55 ms after it (kernel trace, profiles/r05_experiments.md section 4).  Three steps of slack
+        let all of that overlap later kernels instead of standing in front of the next one."""
         import copy
         torch = self.torch
-        d2 = copy.copy(self.d)
-        d2.a = dict(self.d.a)
-        for k in self.F5:
-            d2.a[k] = self.d.a[k].clone()
-        self.dv = (self.d, d2)
-        self.rain2 = (self.rain, torch.zeros_like(self.rain))
-        self.jul2 = [0.0, 0.0]
-        self.prefetched = None
+        self.dv, self.rain2 = [self.d], [self.rain]
+        for _ in range(self.DEPTH):
+            d2 = copy.copy(self.d)
+            d2.a = dict(self.d.a)
+            for k in self.F5:
+                d2.a[k] = self.d.a[k].clone()
+            self.dv.append(d2)
+            self.rain2.append(torch.zeros_like(self.rain))
+        self.jul2 = [0.0] * (self.DEPTH + 1)
+        self.prefetched_to = None                 # chains are in their working sets for steps < prefetched_to
         self.rec_idx = None
+        self.rec_staged = None                    # staged records are in the column order they were evaluated in
         if not hasattr(self, "ts2"):
-            # high priority: the chain is a dozen small dependent launches; behind the land kernel's ~110 000 pending workgroups each of them
-            # would wait for the dispatcher, and the next step's kernel for the last of them
-            self.ts2 = torch.cuda.Stream(device=self.dev, priority=-1)
-            self.ev_forc = (torch.cuda.Event(), torch.cuda.Event())
-            self.ev_kern = (torch.cuda.Event(), torch.cuda.Event())
+            # One stream PER WORKING SET.  On this runtime a stream that waits for an event of another stream waits for everything that
+            # stream has queued by then, not for the event's own position: with ONE prefetch stream every land kernel waited for the chain
+            # enqueued during the previous step (which, starved beside that step's land kernel, ends ~90 us after it) however many steps
+            # ahead the chain ran (kernel traces, profiles/r05_experiments.md section 4).  (Normal priority: while a HIGH-priority queue
+            # has work pending the command processor starts nothing new from the run's queue.)
+            self.tsk = [torch.cuda.Stream(device=self.dev) for _ in range(self.DEPTH + 1)]
+            self.ts2 = self.tsk[0]
+            self.ev_forc = [torch.cuda.Event() for _ in range(self.DEPTH + 1)]
+            self.ev_kern = [torch.cuda.Event() for _ in range(self.DEPTH + 1)]
         torch.cuda.current_stream().synchronize()
 
+    def stage_records(self, first_it, nsteps):
+        """Evaluate the 3-hourly forcing records the steps first_it .. first_it + nsteps - 1 (+ the prefetch depth) interpolate between,
+        before a timed region: they stand for forcing files a driver has read and uploaded, resident in HBM like config 3's hourly sets.
+        (Their evaluation is ~45 torch elementwise launches of 6.5 M elements each per record -- a workload GENERATOR, not the product.)
+        A re-sort drops them (they are in the store's column order); records that are not staged are evaluated when first needed."""
+        s5 = self.synth5
+        lo = (first_it - 1) // s5.RECORD_HOURS
+        hi = (first_it - 1 + nsteps + self.DEPTH) // s5.RECORD_HOURS + 1
+        with self.torch.cuda.stream(self.ts2 if hasattr(self, "ts2") else self.ts):
+            self.rec_staged = {ri: self.recs.at(ri) for ri in range(lo, hi + 1)}
+        self.torch.cuda.synchronize()
+
+    def _record(self, ri):
+        st = getattr(self, "rec_staged", None)
+        return st[ri] if st and ri in st else self.recs.at(ri)
+
     def _chain(self, n, b, stream):
-        """the forcing of 0-based step n into working set b, enqueued on `stream` (a torch stream)"""
+        """the forcing of 0-based step n into working set b, enqueued on `stream` (a torch stream); steps come in increasing order"""
         s5, eng = self.synth5, self.eng
         ri, k = divmod(n, s5.RECORD_HOURS)
         with self.torch.cuda.stream(stream):                                # record evaluation (torch) and the engine's kernels share one stream
             if self.rec_idx != ri:
-                self.rec_a = self.rec_b if (self.rec_idx is not None and self.rec_idx == ri - 1) else self.recs.at(ri)
-                self.rec_b = self.recs.at(ri + 1)
+                self.rec_a = self.rec_b if (self.rec_idx is not None and self.rec_idx == ri - 1) else self._record(ri)
+                self.rec_b = self._record(ri + 1)
                 self.rec_idx = ri
+            for rec in (self.rec_a, self.rec_b):                            # (allocated on one stream, read on this one)
+                for v in rec.values():
+                    if v is not None and hasattr(v, "record_stream"):
+                        v.record_stream(stream)
             eng.forcing_interpolate(self.dv[b], self.rec_a, self.rec_b if k else None, 3600 * k, 3600 * s5.RECORD_HOURS, self.rain2[b],
                                     stream=stream.cuda_stream, wait=False)
             iday, ihour = s5.step_time(n)
@@ -642,25 +675,34 @@ class Run5:
         n = it - 1
         if not hasattr(self, "dv"):
             self._forcing_sets()
-        prefetch = not self.args.no_prefetch
-        b = (it & 1) if prefetch else 0
         ihour = self.synth5.step_time(n)[1]
         if not hasattr(self, "first_hour"):
             self.first_hour = ihour
         self.step_hours.append(ihour)
-        if self.prefetched != it:                                           # the first step, the first one after a re-sort, or no prefetch
-            self._chain(n, b, self.ts if not prefetch else self.ts2)
-            if prefetch:
-                self.ev_forc[b].record(self.ts2)
-        if prefetch:
-            self.ts.wait_event(self.ev_forc[b])
-        self.eng.noahmplsm_async(self.dv[b].step_args(it, 2000, self.jul2[b]), stream=self.sp)
-        if prefetch:
+        if not self.args.prefetch:                                          # the chain in front of its kernel, one stream (default)
+            self._chain(n, 0, self.ts)
+            self.eng.noahmplsm_async(self.dv[0].step_args(it, 2000, self.jul2[0]), stream=self.sp)
+        else:
+            nb = self.DEPTH + 1
+            if self.prefetched_to is None or self.prefetched_to <= it:      # the first step, or the first one after a re-sort: fill the pipeline
+                # (step 1's chain writes the first-step guesses into STATE arrays: it must be complete before anything else starts)
+                for j in range(it, it + self.DEPTH):
+                    if j > it:
+                        self.tsk[j % nb].wait_stream(self.tsk[(j - 1) % nb])   # the chains share the record tensors and the first-step writes
+                    self._chain(j - 1, j % nb, self.tsk[j % nb])
+                    self.ev_forc[j % nb].record(self.tsk[j % nb])
+                self.prefetched_to = it + self.DEPTH
+            b = it % nb
+            self.ts.wait_event(self.ev_forc[b])                             # this step's forcing has arrived in set b
+            self.eng.noahmplsm_async(self.dv[b].step_args(it, 2000, self.jul2[b]), stream=self.sp)
             self.ev_kern[b].record(self.ts)
-            self.ts2.wait_event(self.ev_kern[1 - b])                        # the previous step's kernel read that working set
-            self._chain(n + 1, 1 - b, self.ts2)
-            self.ev_forc[1 - b].record(self.ts2)
-            self.prefetched = it + 1
+            j = self.prefetched_to                                          # the chain of step j = it + DEPTH into the set step it - 1 read
+            sj = self.tsk[j % nb]
+            sj.wait_event(self.ev_kern[j % nb])
+            sj.wait_stream(self.tsk[(j - 1) % nb])                          # chains run one after the other (they share the record tensors)
+            self._chain(j - 1, j % nb, sj)
+            self.ev_forc[j % nb].record(sj)
+            self.prefetched_to = j + 1
         self.steps_since_sort = getattr(self, "steps_since_sort", 0) + 1
         if self.sorted and self.args.resort_every and it % self.args.resort_every == 0:
             self.maybe_resort(it)
@@ -676,8 +718,8 @@ class Run5:
         """`it` = the step just enqueued (the forcing records of the next one are evaluated again in the new column order)"""
         self.collect()
         self.ts.synchronize()
-        if hasattr(self, "ts2"):
-            self.ts2.synchronize()
+        for q in getattr(self, "tsk", []):
+            q.synchronize()
         if self.args.cost_key:
             self.sort_kw["cost"] = True
         self.perm = self.eng.sort_store(self.d, **self.sort_kw)
@@ -775,6 +817,8 @@ def timed_leg(run, steps, warmup, barrier):
     if run.args.cost_key and run.sorted and warmup:
         run.resort(it)
     run.collect()
+    if hasattr(run, "stage_records") and not run.args.no_stage_records:
+        run.stage_records(it + 1, steps)
     run.reset_counters()
     barrier()
     t0 = time.perf_counter()
@@ -966,13 +1010,15 @@ def main():
     ap.add_argument("--lon-band", type=float, default=15.0,
                     help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
     ap.add_argument("--no-sort", action="store_true")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="config 5: run each step's forcing chain (record evaluation, interpolation, preparation) in front of its kernel on the run's "
-                         "stream instead of on a second stream beside the previous step's kernel (-5 %% per step, round 5)")
+    ap.add_argument("--no-stage-records", action="store_true",
+                    help="config 5: evaluate the synthetic 3-hourly forcing records inside the timed region, when a step first needs them "
+                         "(rounds 1-4), instead of before it")
     ap.add_argument("--prefetch", action="store_true",
-                    help="sorted config 2 / 3 / 4: permute step n + 1's forcing on a second stream beside step n's kernel (two forcing working "
-                         "sets).  Measured in round 5: no gain -- two land waves per SIMD hold the whole register file, a wave of the permutation "
-                         "kernel can only take the place of one -- so it is off by default")
+                    help="enqueue the forcing work of LATER steps on other streams beside the running column kernel: configs 2 / 3 / 4 the "
+                         "permutation of step n + 1's forcing (two working sets), config 5 the interpolation + preparation three steps ahead (four "
+                         "working sets, one stream each).  Measured in round 5: no gain for configs 3 / 4 (two land waves per SIMD hold the whole "
+                         "register file: a wave of another kernel only ever takes the place of one), 0-2 %% for config 5 depending on how the "
+                         "runtime maps streams to hardware queues -- off by default")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
@@ -1061,6 +1107,8 @@ def main():
     if args.cost_key and run.sorted and args.warmup:
         run.resort(it)                                  # outside the timed region, like the first sort
     run.collect()
+    if hasattr(run, "stage_records") and not args.no_stage_records:
+        run.stage_records(it + 1, args.steps)           # config 5: the window's forcing records resident in HBM, as config 3's hourly sets are
     run.reset_counters()
 
     barrier()
@@ -1187,7 +1235,7 @@ def main():
     if rank == 0:
         K = args.steps
         prefetching = workload in ("config2", "config3", "config4") and not args.no_sort and args.prefetch
-        prefetch5 = workload == "config5" and not args.no_prefetch
+        prefetch5 = workload == "config5" and args.prefetch
         value = n_adv_all / dt
         # dominant kernel: the land range of the sorted layout (the mixed kernel of a tile-order run); its own event pair per step
         dom_ms = run.class_ms[0] / K
@@ -1228,7 +1276,9 @@ def main():
                      % (("%g-degree longitude band, " % args.lon_band) if getattr(run, "band", None) else "", run.tsk_bin)
                      if run.sorted else "; tile order")
             if prefetch5:
-                desc += "; step n + 1's forcing chain runs on a second stream beside step n's column kernel (two forcing working sets)"
+                desc += "; the forcing chain (interpolation + preparation) runs three steps ahead on a second stream beside the column kernels (four forcing working sets)"
+            desc += ("; the 3-hourly forcing records of the timed window are resident in HBM when it starts (evaluated before it, as config 3's hourly sets are)"
+                     if not args.no_stage_records else "; the synthetic 3-hourly forcing records are evaluated inside the timed region (torch elementwise kernels)")
         elif run.sorted:
             desc += ("; state resident in HBM, sorted on the device by (class, vegetation type, snow-layer count, %g-K skin-temperature "
                      "bin); inside the timed region: the per-step permutation of the forcing (which arrives in tile order%s) and a staleness "

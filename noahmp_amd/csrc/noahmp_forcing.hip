@@ -13,17 +13,25 @@ using namespace nmp;
 using nmp_host::g;
 
 namespace {
+// Grid-stride loops over a CAPPED grid (kForcingBlocks workgroups): a driver enqueues these kernels for a LATER step on a second stream
+// while a column kernel runs (bench.py, config 5).  Beside the land kernel's ~110 000 waves a second queue gets about every other wave
+// slot that comes free, so a kernel of 100 000 short waves (one cell per thread at 6.5 M cells) lasts as long as the land kernel itself
+// and ends behind it -- and the command processor does not start the next land kernel before that (kernel trace, profiles/r05_experiments.md
+// section 4).  16 384 longer waves are through in the first tenth of the land kernel.  Alone on the GPU the kernels take the same time.
+constexpr unsigned kForcingBlocks = 4096;
 __global__ void __launch_bounds__(256) noahmp_forcing_kernel(const ForcingArgs k, int nti, int ntj) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)nti * ntj) return;
-  const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
-  forcing_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
+  const long n = (long)nti * ntj, stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
+    forcing_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
+  }
 }
 __global__ void __launch_bounds__(256) noahmp_interp_kernel(const InterpArgs k, int nti, int ntj) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long)nti * ntj) return;
-  const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
-  interp_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
+  const long n = (long)nti * ntj, stride = (long)gridDim.x * blockDim.x;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+    const int tj = (int)(t / nti), ti = (int)(t - (long)tj * nti);
+    interp_cell(k, k.a.its - k.a.ims + ti, k.a.jts - k.a.jms + tj);
+  }
 }
 }  // namespace
 
@@ -379,7 +387,8 @@ int noahmp_hip_forcing_prep(const noahmp_step_args* a, const float* lon2d, const
   if (st) HIPCHK(hipEventRecord(g.ev0, s));
   if (nti > 0 && ntj > 0) {
     const long n = (long)nti * ntj;
-    hipLaunchKernelGGL(noahmp_forcing_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(noahmp_forcing_kernel, dim3(nb < kForcingBlocks ? nb : kForcingBlocks), dim3(256), 0, s, k, nti, ntj);
   }
   HIPCHK(hipGetLastError());
   if (st) {                                   // st == NULL: enqueue only (ordered on `stream`), no host wait
@@ -433,7 +442,8 @@ int noahmp_hip_forcing_interpolate(const noahmp_step_args* a, const noahmp_forci
   if (st) HIPCHK(hipEventRecord(g.ev0, s));
   if (nti > 0 && ntj > 0) {
     const long n = (long)nti * ntj;
-    hipLaunchKernelGGL(noahmp_interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, k, nti, ntj);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(noahmp_interp_kernel, dim3(nb < kForcingBlocks ? nb : kForcingBlocks), dim3(256), 0, s, k, nti, ntj);
   }
   HIPCHK(hipGetLastError());
   if (st) {                                   // st == NULL: enqueue only (ordered on `stream`), no host wait

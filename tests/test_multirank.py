@@ -601,8 +601,9 @@ def test_bench_config5_ranks_and_oracle(tmp_path, port, tables):
     gx, gy = 120, 66
     common = ["--workload", "config5", "--ni", str(gx), "--nj", str(gy)]
     one, d1 = _run_bench(["--gpus", "1"] + common, str(tmp_path), "one5")
-    two, d2 = _run_bench(["--gpus", "2"] + common, str(tmp_path), "two5")
+    two, d2 = _run_bench(["--gpus", "2"] + common + ["--prefetch"], str(tmp_path), "two5")      # (the ranks: forcing chain three steps ahead on other streams)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and "no collective" in two["config"]["parallelism"]
+    assert "three steps ahead" in two["config"]["workload"] and "three steps ahead" not in one["config"]["workload"]
     assert "configs[4]" in one["config"]["workload"] and one["cold_start_s"] > 0
     whole = np.load(d1 + ".rank0.npz")
     seen = 0
