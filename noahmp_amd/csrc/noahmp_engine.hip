@@ -319,7 +319,9 @@ static void launch_range(KArgs k, long first, long count, hipStream_t s) {
   if (k.c.cost) k.c.cost += 2 * first;                 // the kernel indexes it by its own thread number
   const int fx = (MODE != 3) ? fixed_level(k) : 0;      // skipped cells do not depend on the options
   if (fx && launch_fixed(k, fx, MODE, s)) return;
-  hipLaunchKernelGGL((noahmp_column_kernel<256, true, MODE>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, k);
+  // the generic (run-time options) class-range kernels: one wave per workgroup like the specialised ones (nmp_kernel.hpp: NMP_FIXED_BLOCK)
+  hipLaunchKernelGGL((noahmp_column_kernel<NMP_FIXED_BLOCK, true, MODE>), dim3((unsigned)((count + NMP_FIXED_BLOCK - 1) / NMP_FIXED_BLOCK)),
+                     dim3(NMP_FIXED_BLOCK), 0, s, k);
 }
 
 // class_ranges: the call is a whole device-resident tile, the only kind of call the declared class ranges can describe
