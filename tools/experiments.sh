@@ -181,6 +181,7 @@ phase)
   grep "^phase" $O/prof.err; grep -v "^phase" $O/prof.err | tail -3
   ;;
 k2)
+  # build first (dev container): python tools/build_variants.py k2=-DNMP_K2_EXPERIMENT t3=-DNMP_TRUNC=3 t7=-DNMP_TRUNC=7
   NMP_K2_EXP=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_k2.so timeout 900 python bench.py --steps 24 --warmup 2 $QUIET --no-options-reference --no-host-path-reference > $O/k2.json 2> $O/k2.err
   grep "^K2EXP" $O/k2.err; grep -v "^K2EXP" $O/k2.err | tail -3
   for v in t3 t7; do
