@@ -33,6 +33,10 @@ import time
 # (its cached mappings of heap memory fault later on this stack: tests/conftest.py, profiles/r05_experiments.md section 3).  Nothing inside a
 # timed region copies from or to pageable memory except the first host_path_reference leg, which says so.
 os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+# torch's and the engine's streams share the runtime's hardware queues (4 by default, in-order each): with 8 the run's stream, the engine's
+# second stream (land-ice / skipped-cell kernels beside the land kernel) and the optional prefetch streams never sit behind one another
+# (profiles/r05_experiments.md section 4; no effect on the default config-3 / 4 / 5 runs, 0.2 ms per step in one --prefetch mapping)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
