@@ -670,10 +670,10 @@ class Run5:
                 for v in rec.values():
                     if v is not None and hasattr(v, "record_stream"):
                         v.record_stream(stream)
-            eng.forcing_interpolate(self.dv[b], self.rec_a, self.rec_b if k else None, 3600 * k, 3600 * s5.RECORD_HOURS, self.rain2[b],
-                                    stream=stream.cuda_stream, wait=False)
-            iday, ihour = s5.step_time(n)
-            self.jul2[b] = eng.forcing_prep(self.dv[b], self.lon_d, self.rain2[b], iday, ihour, first_step=(n == 0), stream=stream.cuda_stream, wait=False)
+            iday, ihour = s5.step_time(n)              # interpolation + preparation in one launch (noahmp_hip_forcing_interpolate_prep)
+            self.jul2[b] = eng.forcing_interpolate_prep(self.dv[b], self.rec_a, self.rec_b if k else None, 3600 * k, 3600 * s5.RECORD_HOURS,
+                                                        self.rain2[b], self.lon_d, iday, ihour, first_step=(n == 0),
+                                                        stream=stream.cuda_stream, wait=False)
 
     def step(self, it):
         n = it - 1

@@ -162,6 +162,32 @@ class Engine:
             raise RuntimeError("noahmp_hip_forcing_interpolate: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
         return st
 
+    def forcing_interpolate_prep(self, store, rec_a, rec_b, idts, idts2, rain_rate, lon, iday, ihour, iminute=0, isecond=0,
+                                 scale_vegfra=False, first_step=False, stream=None, wait=True):
+        """forcing_interpolate followed by forcing_prep in one launch (noahmp_hip_forcing_interpolate_prep): same arguments, same
+        results.  Returns JULIAN."""
+        assert isinstance(store, DeviceColumnStore), "forcing_interpolate_prep works on device-resident arrays"
+        a = store.step_args(1, 2000, 1.0)
+
+        def rec(d):
+            r = abi.ForcingRecord()
+            for n in abi.FORCING_RECORD_FIELDS:
+                if d.get(n) is not None:
+                    setattr(r, n, d[n].data_ptr())
+            return r
+        ra = rec(rec_a)
+        rb = rec(rec_b) if rec_b is not None else None
+        jul = C.c_float(0)
+        st = abi.Status()
+        rc = self.lib.noahmp_hip_forcing_interpolate_prep(C.byref(a), C.byref(ra), C.byref(rb) if rb is not None else None, idts, idts2,
+                                                          rain_rate.data_ptr(), lon.data_ptr(), iday, ihour, iminute, isecond, store.cfg.zlvl,
+                                                          (1 if scale_vegfra else 0) | (2 if first_step else 0), C.byref(jul), abi.MEM_DEVICE,
+                                                          stream, C.byref(st) if wait else None)
+        self.last_status = st
+        if rc:
+            raise RuntimeError("noahmp_hip_forcing_interpolate_prep: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
+        return jul.value
+
     # ---- sorted device-resident layout (DESIGN.md section 3)
     class Gather:
         """A prepared noahmp_hip_gather_fields call: dst tensors <- src tensors through a column permutation."""

@@ -248,3 +248,31 @@ def test_gpu_forcing_interpolate_bit_identical(engine, port, idts, idts2):
     np.testing.assert_array_equal(rain, raind.cpu().numpy())
     with pytest.raises(RuntimeError):                                   # target outside the bracket is refused
         engine.forcing_interpolate(d, dev(ra), dev(ra), 7200, 3600, raind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idts,idts2,first", [(1800, 10800, False), (3599, 3600, True), (None, None, False)])
+def test_gpu_forcing_interpolate_prep_is_the_two_calls(engine, port, idts, idts2, first):
+    """noahmp_hip_forcing_interpolate_prep (one launch) = the oracle's hrldas_input_interpolate followed by its forcing preparation, bit for
+    bit: every array either call writes, the rain-rate scratch plane and JULIAN."""
+    import torch
+    ni, nj = 512, 64
+    ra, rb = records(ni, nj, 15)
+    if idts is None:
+        rb, idts, idts2 = None, 0, 0
+    _, lon, _ = case(ni=ni, nj=nj, seed=9)
+    a, s = icase(ni, nj, 8), icase(ni, nj, 8)
+    rain = np.zeros((nj, ni), np.float32)
+    iday, h, m, sec = 171, 14, 30, 0
+    port.forcing_interpolate(a, ra, rb, idts, idts2, rain)
+    ja = port.forcing_prep(a, lon, rain, iday, h, m, sec, scale_vegfra=True, first_step=first)
+    d = s.to_device("cuda:0")
+    dev = lambda r: None if r is None else {k: torch.from_numpy(v).cuda() for k, v in r.items()}
+    raind = torch.zeros((nj, ni), dtype=torch.float32, device="cuda:0")
+    jd = engine.forcing_interpolate_prep(d, dev(ra), dev(rb), idts, idts2, raind, torch.from_numpy(lon).cuda(), iday, h, m, sec,
+                                         scale_vegfra=True, first_step=first)
+    assert ja == jd
+    hst = d.to_host()
+    for k in sorted(set(IOUT) | set(OUT)):
+        np.testing.assert_array_equal(a.a[k], hst.a[k], err_msg=k)
+    np.testing.assert_array_equal(rain, raind.cpu().numpy())
