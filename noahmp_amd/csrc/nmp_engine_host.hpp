@@ -71,6 +71,7 @@ struct Engine {
   int pin_host_arrays = 0;      // hipHostRegister arrays seen twice at the same address (caller guarantees their lifetime)
   int trust_out_mirror = 0;     // do not re-upload OUT arrays after the first call (caller leaves them alone between calls)
   bool out_mirror_valid = false;
+  std::vector<const void*> pipe_host;      // the caller's arrays at the last row-chunk call: other arrays = the OUT mirrors say nothing about them
   // resident host path: the device mirrors ARE the state between calls; only IN arrays are uploaded, INOUT / OUT arrays come back
   // on request (noahmp_hip_fetch) unless lazy_download is off
   int resident_state = 0, lazy_download = 0;

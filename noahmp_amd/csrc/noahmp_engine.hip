@@ -435,6 +435,11 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
   if (!g.s_up) { HIPCHK(hipStreamCreateWithFlags(&g.s_up, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&g.s_dn, hipStreamNonBlocking)); }
   const int nchunk = g.host_chunks < nj_mem ? g.host_chunks : nj_mem;
   while ((int)g.pipe_events.size() < 3 * nchunk) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); g.pipe_events.push_back(e); }
+  if (g.pipe_host.size() != (size_t)kNumFields) { g.pipe_host.assign(kNumFields, nullptr); g.out_mirror_valid = false; }
+  for (int f = 0; f < kNumFields; f++) {       // "trust_out_mirror" speaks about the arrays of the previous call only
+    const void* host = *(void* const*)((const char*)a + kFields[f].off);
+    if (g.pipe_host[f] != host) { g.pipe_host[f] = host; g.out_mirror_valid = false; }
+  }
   const bool upload_out = !(g.trust_out_mirror && g.out_mirror_valid);
   size_t rowbytes[kNumFields];
   for (int f = 0; f < kNumFields; f++) {

@@ -94,6 +94,7 @@ def test_fortran_shim_end_to_end(engine, tables):
     a = via_f.step_args(1, 2000, 180.0)
     lib.shim_noahmplsm(C.byref(a))                  # Fortran: noahmplsm(...) -> noahmp_hip_step
     engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))   # the shim uploaded ITS table image; restore the fixture's
+    engine.set_option("trust_out_mirror", 0)
     engine.set_option("pin_host_arrays", 0)         # the shim switched page-locking on (HRLDAS arrays live for the run;
     #                                                 the numpy arrays of these tests do not)
     for k in via_c.a:
@@ -130,6 +131,7 @@ def test_fortran_groundwater_shim_end_to_end(engine, tables):
     w = via_f.wtable_args()
     lib.shim_wtable_mmf(C.byref(w))
     engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))
+    engine.set_option("trust_out_mirror", 0)
     engine.set_option("pin_host_arrays", 0)
     for k in GW_OUT:
         np.testing.assert_array_equal(via_c.a[k], via_f.a[k], err_msg=k)
@@ -205,7 +207,8 @@ def test_fortran_shim_resident_mode(engine, tables, fast):
         engine.set_option("static_inputs", 0)
         engine.set_option("lazy_download", 0)
         engine.set_option("resident_state", 0)
-        engine.set_option("pin_host_arrays", 0)
+        engine.set_option("trust_out_mirror", 0)
+    engine.set_option("pin_host_arrays", 0)
         engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))
     for k in plain.a:
         if FIELD_INFO[k][2] != "in":
