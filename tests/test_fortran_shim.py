@@ -208,7 +208,7 @@ def test_fortran_shim_resident_mode(engine, tables, fast):
         engine.set_option("lazy_download", 0)
         engine.set_option("resident_state", 0)
         engine.set_option("trust_out_mirror", 0)
-    engine.set_option("pin_host_arrays", 0)
+        engine.set_option("pin_host_arrays", 0)
         engine.lib.noahmp_hip_set_tables(C.byref(tables[0]))
     for k in plain.a:
         if FIELD_INFO[k][2] != "in":
