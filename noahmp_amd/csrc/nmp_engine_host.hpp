@@ -81,6 +81,17 @@ struct Engine {
   unsigned resident_calls = 0;
   std::vector<void*> mirror_b;                           // second buffer of the IN arrays (deferred_status)
   std::vector<size_t> mirror_b_bytes;
+  // "resident_sorted": the resident state additionally lives in a second set of mirrors in the north-star column order (class, vegetation
+  // type, snow-layer count, TSK bin), the set the kernels run on (class-range kernels instead of the mixed tile-order one); the tile-order
+  // mirrors stay the landing place of uploads and the source of downloads
+  int resident_sorted = 0;
+  std::vector<void*> smirror; std::vector<size_t> smirror_bytes;
+  int* s_perm = nullptr; unsigned* s_keys = nullptr; unsigned short* s_order = nullptr; int* s_dpos = nullptr; size_t s_cols = 0;
+  long s_land = -1, s_glacier = -1;
+  bool sorted_ok = false;          // smirror + plan describe the resident state
+  bool sorted_newer = false;       // the INOUT / OUT arrays are newer in smirror than in the tile-order mirrors
+  bool last_step_sorted = false;   // the error word of the step in flight counts SORTED positions
+  unsigned calls_since_sort = 0;
   hipEvent_t ev_up = nullptr, ev_kdone = nullptr;
   bool resident_valid = false, resident_dirty = false;   // dirty: the mirrors hold results the host arrays do not have yet
   std::vector<const void*> mirror_host;                  // the caller's array behind each mirror at the last resident call

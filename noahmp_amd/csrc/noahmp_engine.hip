@@ -212,6 +212,13 @@ int noahmp_hip_set_option(const char* key, int value) {
       g.resident_state = value; g.resident_valid = false;
     }
   }
+  else if (!strcmp(key, "resident_sorted")) {
+    prev = g.resident_sorted;
+    if (value == 0 || value == 1) {
+      if (value != g.resident_sorted && (g.resident_dirty || g.deferred_pending)) note_fetch(noahmp_hip_fetch(nullptr));
+      if (value != g.resident_sorted) { g.resident_sorted = value; g.sorted_ok = false; g.resident_valid = false; }
+    }
+  }
   else if (!strcmp(key, "lazy_download")) {
     prev = g.lazy_download;
     if (value == 0 || value == 1) {
@@ -545,11 +552,82 @@ static void fill_status(const noahmp_step_args* a, int nti, noahmp_status* st, i
   }
   if (*g.h_err != ~0ULL) {
     code = (int)(*g.h_err & 0xFF);
-    const long t = (long)(*g.h_err >> 8) - 1;
+    long t = (long)(*g.h_err >> 8) - 1;
+    if (g.last_step_sorted && g.s_perm && t >= 0 && (size_t)t < g.s_cols) {     // "resident_sorted": a sorted position -> the tile column
+      int p = 0;
+      if (hipMemcpy(&p, g.s_perm + t, sizeof p, hipMemcpyDeviceToHost) == hipSuccess) t = p;
+    }
     if (st) { st->code = code; st->i = a->its + (int)(t % nti); st->j = a->jts + (int)(t / nti); }
   }
   *code_out = code;
 }
+
+// ---- "resident_sorted": helpers.  `tile` / `sorted`: the per-field device pointers of the two mirror sets.
+static int nlev_of(const FieldDesc& fd, const noahmp_step_args* a) {
+  const size_t plane = (size_t)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
+  return (int)(field_elems(fd, a) / plane);
+}
+// (and "static_inputs": XLAND / XICE / IVGTYP decide a column's class range; a caller that may rewrite them between calls keeps tile order)
+static bool resident_sorted_possible(const noahmp_step_args* a) {      // the column sort needs memory block == tile, 32-bit offsets
+  return g.resident_sorted && g.static_inputs && a->ims == a->its && a->ime == a->ite && a->jms == a->jts && a->jme == a->jte &&
+         (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) > 0 && (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) < 0x7FFFFFFFL &&
+         a->jme - a->jms + 1 <= 65535;
+}
+// INOUT / OUT arrays: sorted set -> tile-order mirrors (before a download)
+static int sorted_to_tile(const noahmp_step_args* a, hipStream_t s) {
+  const int ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1;
+  void* sp[32]; void* tp[32]; int nl[32];
+  int n = 0;
+  for (int f = 0; f < kNumFields; f++) {
+    const FieldDesc& fd = kFields[f];
+    if (fd.io != 0) { sp[n] = g.smirror[f]; tp[n] = g.mirror[f]; nl[n] = nlev_of(fd, a); n++; }
+    if (n == 32 || (f == kNumFields - 1 && n)) {
+      int rc = noahmp_hip_sorted_exchange(n, sp, tp, nl, g.s_order, g.s_dpos, ni, nj, ni, 0, 0, 1, s);
+      if (rc) return rc;
+      n = 0;
+    }
+  }
+  g.sorted_newer = false;
+  return 0;
+}
+// (re)build the sorted set from the tile-order set `tile_args` (device pointers of every field, the IN arrays at their current targets)
+static int build_sorted(const noahmp_step_args* a, const noahmp_step_args& tile_args, hipStream_t s) {
+  const int ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1;
+  const size_t ncol = (size_t)ni * nj;
+  if (g.smirror.empty()) { g.smirror.assign(kNumFields, nullptr); g.smirror_bytes.assign(kNumFields, 0); }
+  for (int f = 0; f < kNumFields; f++) {
+    const size_t bytes = field_elems(kFields[f], a) * 4;
+    if (g.smirror_bytes[f] != bytes) {
+      if (g.smirror[f]) HIPCHK(hipFree(g.smirror[f]));
+      g.smirror[f] = nullptr; g.smirror_bytes[f] = 0;
+      HIPCHK(hipMalloc(&g.smirror[f], bytes));
+      g.smirror_bytes[f] = bytes;
+    }
+  }
+  if (g.s_cols != ncol) {
+    if (g.s_perm) hipFree(g.s_perm);
+    if (g.s_keys) hipFree(g.s_keys);
+    if (g.s_order) hipFree(g.s_order);
+    if (g.s_dpos) hipFree(g.s_dpos);
+    g.s_perm = nullptr; g.s_keys = nullptr; g.s_order = nullptr; g.s_dpos = nullptr; g.s_cols = 0;
+    HIPCHK(hipMalloc((void**)&g.s_perm, ncol * 4));
+    HIPCHK(hipMalloc((void**)&g.s_keys, ncol * 4));
+    HIPCHK(hipMalloc((void**)&g.s_order, ncol * 2));
+    HIPCHK(hipMalloc((void**)&g.s_dpos, ncol * 4));
+    g.s_cols = ncol;
+  }
+  noahmp_step_args sorted_args = tile_args;
+  for (int f = 0; f < kNumFields; f++) *(void**)((char*)&sorted_args + kFields[f].off) = g.smirror[f];
+  int64_t counts[3] = {0, 0, 0};
+  int rc = noahmp_hip_sort_columns(&tile_args, NOAHMP_SORT_VEG | NOAHMP_SORT_SNOW, 1000, g.s_perm, g.s_keys, counts, s);   // waits for `s`
+  if (rc) return rc;
+  if ((rc = noahmp_hip_permute_step_arrays(&tile_args, &sorted_args, g.s_perm, s))) return rc;
+  if ((rc = noahmp_hip_scatter_plan(g.s_perm, ni, nj, g.s_order, g.s_dpos, s))) return rc;
+  g.s_land = (long)counts[0]; g.s_glacier = (long)counts[1];
+  g.sorted_ok = true; g.sorted_newer = false; g.calls_since_sort = 0;
+  return 0;
+}
+
 
 // "deferred_status": wait for the step the previous resident call left running and report it
 // The code is also kept in g.deferred_code until a call has RETURNED it to the caller (take_deferred_code): paths that collect a
@@ -630,12 +708,48 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
     if (rc) return rc;
     HIPCHK(hipStreamWaitEvent(s, g.ev_up, 0));
   }
+  // "resident_sorted": the kernels run on a second set of mirrors in the north-star column order.  The tile-order set above stays the landing
+  // place of the uploads; what this call uploaded is permuted into the sorted set (one launch), the whole state when it is (re)built
+  // or has not been sorted for 24 calls (snow layers appear and vanish).
+  const bool run_sorted = resident_sorted_possible(a);
+  if (run_sorted) {
+    const noahmp_step_args tile_args = k.a;                   // device pointers of the tile-order set, the IN arrays at this call's targets
+    if (!valid || !g.sorted_ok || g.calls_since_sort >= 24) {
+      if (valid && g.sorted_ok && g.sorted_newer) { int rc = sorted_to_tile(a, s); if (rc) return rc; }
+      int rc = build_sorted(a, tile_args, s);
+      if (rc) return rc;
+    } else {
+      void* sp[32]; void* tp[32]; int nl[32];
+      int n = 0;
+      for (int f = 0; f < kNumFields; f++) {
+        const FieldDesc& fd = kFields[f];
+        if (fd.io == 0 && !(g.static_inputs && is_static_in(fd))) {
+          sp[n] = g.smirror[f]; tp[n] = *(void* const*)((const char*)&tile_args + fd.off);
+          nl[n] = nlev_of(fd, a);
+          if (fd.lev == 1 && nka > 1 && level1_only(fd)) nl[n] = -nl[n];      // only the level that was uploaded (and that the kernel reads)
+          n++;
+        }
+        if (n == 32 || (f == kNumFields - 1 && n)) {
+          int rc = noahmp_hip_sorted_exchange(n, sp, tp, nl, g.s_order, g.s_dpos, (int)ni, (int)nj, (int)ni, 0, 0, 0, s);
+          if (rc) return rc;
+          n = 0;
+        }
+      }
+    }
+    for (int f = 0; f < kNumFields; f++) *(void**)((char*)&k.a + kFields[f].off) = g.smirror[f];
+  }
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
   HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
   g.ev_timed = (long)k.nti * k.ntj > 0;                // (an empty tile records no events: see noahmp_hip_step)
   if (g.ev_timed) HIPCHK(hipEventRecord(g.ev0, s));
-  launch_any(k, s);
+  {
+    const long sl = g.sorted_land, sg = g.sorted_glacier;     // the caller's own declaration (device-resident calls) is not touched
+    if (run_sorted) { g.sorted_land = g.s_land; g.sorted_glacier = g.s_glacier; }
+    launch_any(k, s, run_sorted);
+    if (run_sorted) { g.sorted_land = sl; g.sorted_glacier = sg; g.sorted_newer = true; g.calls_since_sort++; }
+    g.last_step_sorted = run_sorted;
+  }
   HIPCHK(hipGetLastError());
   if (g.ev_timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -650,12 +764,14 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
     HIPCHK(hipEventSynchronize(g.ev_up));
     return take_deferred_code(prev_code);
   }
-  if (!g.lazy_download)
+  if (!g.lazy_download) {
+    if (run_sorted) { int rc = sorted_to_tile(a, s); if (rc) return rc; }
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
       HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
     }
+  }
   HIPCHK(hipStreamSynchronize(s));
   int code = 0;
   fill_status(a, k.nti, st, &code);
@@ -684,6 +800,7 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
         return -108;
       }
   if (!g.resident_dirty) return take_deferred_code(pending_code);
+  if (g.sorted_ok && g.sorted_newer) { rc = sorted_to_tile(r, g.own_stream); if (rc) return rc; }    // "resident_sorted": results back to tile order
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];
     if (fd.io == 0) continue;
@@ -1016,6 +1133,14 @@ void noahmp_hip_finalize(void) {
   if (g.d_tables) hipFree(g.d_tables);
   if (g.d_err) hipFree(g.d_err);
   if (g.d_counts) hipFree(g.d_counts);
+  for (auto& q : g.smirror) { if (q) hipFree(q); q = nullptr; }
+  for (auto& b : g.smirror_bytes) b = 0;
+  if (g.s_perm) hipFree(g.s_perm);
+  if (g.s_keys) hipFree(g.s_keys);
+  if (g.s_order) hipFree(g.s_order);
+  if (g.s_dpos) hipFree(g.s_dpos);
+  g.s_perm = nullptr; g.s_keys = nullptr; g.s_order = nullptr; g.s_dpos = nullptr; g.s_cols = 0;
+  g.sorted_ok = false; g.sorted_newer = false; g.last_step_sorted = false;
   if (g.d_cost) hipFree(g.d_cost);
   g.d_cost = nullptr; g.d_cost_bytes = 0; g.cost_cols = 0; g.cost_fresh = false;
   if (g.d_gw_counts) hipFree(g.d_gw_counts);

@@ -650,6 +650,54 @@ def test_resident_host_path_static_inputs_and_deferred_status(engine, tables):
             engine.set_option(k, 0)
 
 
+@pytest.mark.parametrize("deferred", [0, 1], ids=["sync", "deferred"])
+def test_resident_host_path_sorted_mirrors(engine, tables, deferred):
+    """"resident_sorted" (+ resident_state, lazy_download, static_inputs): the state additionally lives in device mirrors sorted by (class,
+    vegetation type, snow-layer count, TSK bin) and the class-range kernels run on them -- host arrays in tile order in, the bits of the
+    ordinary host path out: over 30 steps (the state is sorted again after 24), with a fetch in the middle, with open water, sea ice and
+    land ice in the tile, with and without deferred status; a fatal column is reported at its TILE position."""
+    from noahmp_amd.driver import NoahMPFatal
+    s = synth.mixed_small(tables[1], ni=192, nj=24, glacier_frac=0.06, seed=77)
+    r = np.random.default_rng(5)
+    s["xland"][r.random(size=(24, 192)) < 0.04] = 2.0
+    s["xice"][3, 10:17] = 1.0
+    synth.first_step_fixups(s)
+    plain, res = s.copy(), s.copy()
+    nsteps = 30
+    for it in range(1, nsteps + 1):
+        synth.diurnal_forcing(plain, (it + 5) % 24, t_offset=s.t_offset)
+        engine.noahmplsm(plain, it, 2000, 180.0)
+        if it == 10:
+            mid = plain.copy()
+    opts = (("resident_state", 1), ("lazy_download", 1), ("static_inputs", 1), ("resident_sorted", 1), ("deferred_status", deferred))
+    try:
+        for k, v in opts:
+            engine.set_option(k, v)
+        kernel_ms = []
+        for it in range(1, nsteps + 1):
+            synth.diurnal_forcing(res, (it + 5) % 24, t_offset=s.t_offset)
+            st = engine.noahmplsm(res, it, 2000, 180.0)
+            assert st.code == 0
+            kernel_ms.append(st.kernel_ms)
+            if it == 10:
+                engine.fetch()
+                _check(mid, res, engine, steps=10, fields=_outs(plain))
+        engine.fetch()
+        _check(plain, res, engine, steps=nsteps, fields=_outs(plain))
+        # a fatal column: reported at its (i, j) of the TILE although the kernel saw it at a sorted position
+        bad = res.copy()
+        synth.diurnal_forcing(bad, 14, t_offset=s.t_offset)
+        bad["isltyp"][17, 101] = 99                         # other arrays: the state is rebuilt and sorted again, the soil type is seen
+        st = engine.noahmplsm(bad, nsteps + 1, 2000, 180.0, check=False)
+        rc = engine.lib.noahmp_hip_fetch(None) if deferred else st.code
+        assert rc == 1, rc                                  # NOAHMP_ERR_SOILTYP_RANGE
+        if not deferred:
+            assert (st.i, st.j) == (102, 18), (st.code, st.i, st.j)
+    finally:
+        for k, _ in reversed(opts):
+            engine.set_option(k, 0)
+
+
 def test_resident_host_path_alternating_tiles_of_different_size(engine, tables):
     """Two tiles (nests) of different extents advanced alternately with "resident_state" + "lazy_download": a call with other
     arrays first brings the previous tile's host arrays up to date from the still intact mirrors, and only then re-sizes the
