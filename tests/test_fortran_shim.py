@@ -171,11 +171,11 @@ def test_fortran_device_resident_time_loop(engine, port, tables):
 
 @pytest.mark.gpu
 @needs_flang
-@pytest.mark.parametrize("fast", [False, True], ids=["resident", "resident_static_deferred"])
+@pytest.mark.parametrize("fast", [0, 1, 2], ids=["resident", "resident_static_deferred", "resident_static_deferred_sorted"])
 def test_fortran_shim_resident_mode(engine, tables, fast):
     """The unchanged Fortran call pattern with resident_state + lazy_download, noahmp_hip_fetch_state() before reading; `fast`
     adds static_inputs (static IN arrays uploaded once) and deferred_status (a call returns when its forcing is up, the step
-    runs under the next call's upload)."""
+    runs under the next call's upload); 2: also resident_sorted (the engine's own sorted mirrors behind the tile-order arrays)."""
     from oracle.reflib import RefLib
     ref = RefLib("O0")
     ref.set_tables(tables[0])
@@ -194,6 +194,7 @@ def test_fortran_shim_resident_mode(engine, tables, fast):
         engine.set_option("lazy_download", 1)
         engine.set_option("static_inputs", 1 if fast else 0)
         engine.set_option("deferred_status", 1 if fast else 0)
+        engine.set_option("resident_sorted", 1 if fast == 2 else 0)
         for it in range(1, 7):
             synth.diurnal_forcing(res, (it + 8) % 24, t_offset=s.t_offset)
             a = res.step_args(it, 2000, 180.0)
@@ -203,6 +204,7 @@ def test_fortran_shim_resident_mode(engine, tables, fast):
         assert not np.array_equal(res["tslb"], plain["tslb"])          # still the start values on the host
         fetch_state()
     finally:
+        engine.set_option("resident_sorted", 0)
         engine.set_option("deferred_status", 0)
         engine.set_option("static_inputs", 0)
         engine.set_option("lazy_download", 0)
