@@ -45,12 +45,14 @@ def needs_build():
 def build(force=False, verbose=False, extra_flags=(), lib=None, jobs=None):
     """extra_flags / lib: experiment builds (e.g. -DNMP_TRUNC=3 into another .so); they get their own object directory."""
     lib = lib or LIB
-    if not force and not extra_flags and not needs_build():
+    if not force and not extra_flags and not os.environ.get("NMP_NSOIL") and not needs_build():
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = OBJ if lib == LIB else lib + ".obj"
     os.makedirs(objdir, exist_ok=True)
     flags = FLAGS + list(extra_flags)
+    if os.environ.get("NMP_NSOIL") and not any(f.startswith("-DNOAHMP_NSOIL") for f in flags):
+        flags.append("-DNOAHMP_NSOIL=%d" % int(os.environ["NMP_NSOIL"]))       # soil layers: a build-time choice (include/noahmp_hip.h); default 4
     stamp = os.path.join(objdir, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     hdrs = _headers()

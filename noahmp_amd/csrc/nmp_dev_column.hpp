@@ -25,25 +25,25 @@ struct KArgs {
   long t_first, t_count;         // class-range launches (sorted layout): this launch covers tile indices [t_first, t_first + t_count)
 };
 
-constexpr int LAY_SLOTS = 4 * 7 + 5 * 4 + 3 * 3;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold
+constexpr int LAY_SLOTS = 4 * NL + 5 * NSOIL + 3 * NSNOW;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold
 
 template <int STRIDE>
 NMP_DEV Lay<LArr<STRIDE>> make_lay(float* base) {
   Lay<LArr<STRIDE>> y;
   int o = 0;
-  y.stc.p = base + o * STRIDE; o += 7;
-  y.zsnso.p = base + o * STRIDE; o += 7;
-  y.dzsnso.p = base + o * STRIDE; o += 7;
-  y.imelt.p = base + o * STRIDE; o += 7;
-  // soil-only arrays keep slots L(1)..L(4): bias the base pointer by -L(1) slots
-  y.smc.p = base + (o - L(1)) * STRIDE; o += 4;
-  y.sh2o.p = base + (o - L(1)) * STRIDE; o += 4;
-  y.sice.p = base + (o - L(1)) * STRIDE; o += 4;
-  y.smceq.p = base + (o - L(1)) * STRIDE; o += 4;
-  y.btrani.p = base + (o - L(1)) * STRIDE; o += 4;
-  y.snice.p = base + o * STRIDE; o += 3;
-  y.snliq.p = base + o * STRIDE; o += 3;
-  y.ficeold.p = base + o * STRIDE; o += 3;
+  y.stc.p = base + o * STRIDE; o += NL;
+  y.zsnso.p = base + o * STRIDE; o += NL;
+  y.dzsnso.p = base + o * STRIDE; o += NL;
+  y.imelt.p = base + o * STRIDE; o += NL;
+  // soil-only arrays keep slots L(1)..L(NSOIL): bias the base pointer by -L(1) slots
+  y.smc.p = base + (o - L(1)) * STRIDE; o += NSOIL;
+  y.sh2o.p = base + (o - L(1)) * STRIDE; o += NSOIL;
+  y.sice.p = base + (o - L(1)) * STRIDE; o += NSOIL;
+  y.smceq.p = base + (o - L(1)) * STRIDE; o += NSOIL;
+  y.btrani.p = base + (o - L(1)) * STRIDE; o += NSOIL;
+  y.snice.p = base + o * STRIDE; o += NSNOW;
+  y.snliq.p = base + o * STRIDE; o += NSNOW;
+  y.ficeold.p = base + o * STRIDE; o += NSNOW;
   return y;
 }
 

@@ -17,15 +17,16 @@ namespace nmp {
 
 // __host__ too: tests/host_emul compiles the same source for the CPU to debug it without a GPU
 #define NMP_DEV __host__ __device__ __forceinline__
-#define L(i) ((i) + 2)   // layer -2..4 -> slot 0..6
+#define L(i) ((i) + 2)   // layer -2..NSOIL -> slot 0..NL-1
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NMP_ASSUME(c) __builtin_assume(c)
 #else
 #define NMP_ASSUME(c) ((void)0)
 #endif
-constexpr int NL = 7;
-constexpr int NSOIL = NOAHMP_NSOIL;
+constexpr int NSOIL = NOAHMP_NSOIL;     // a build-time choice (include/noahmp_hip.h): 4 unless the library is built with -DNOAHMP_NSOIL=n
 constexpr int NSNOW = NOAHMP_NSNOW;
+constexpr int NL = NSNOW + NSOIL;
+static_assert(NSNOW == 3 && NSOIL >= 2 && NSOIL <= 12, "layer slots: three snow layers, 2..12 soil layers");
 
 // physical constants, lsm:12-28 and lsm:180-188
 constexpr float GRAV = 9.80616f, SB = 5.67E-08f, VKC = 0.40f, TFRZ = 273.16f, HSUB = 2.8440E06f,
@@ -347,13 +348,28 @@ NMP_DEV float uniform_value(float x) { return x; }
 NMP_DEV double uniform_value(double x) { return x; }
 #endif
 template <class T> NMP_DEV T pick_layer(const T* a, int k) {
-  const T a0 = uniform_value(a[L(0)]), a1 = uniform_value(a[L(1)]), a2 = uniform_value(a[L(2)]), a3 = uniform_value(a[L(3)]),
-          a4 = uniform_value(a[L(4)]);
-  T r = a0;
-  r = (k == 1) ? a1 : r;
-  r = (k == 2) ? a2 : r;
-  r = (k == 3) ? a3 : r;
-  r = (k >= 4) ? a4 : r;
+  T v[NSOIL + 1];
+#pragma unroll
+  for (int j = 0; j <= NSOIL; j++) v[j] = uniform_value(a[L(j)]);
+  T r = v[0];
+#pragma unroll
+  for (int j = 1; j < NSOIL; j++) r = (k == j) ? v[j] : r;
+  r = (k >= NSOIL) ? v[NSOIL] : r;
+  return r;
+}
+
+// a[L(k)] of a per-column soil array, 1 <= k <= NSOIL, as a select chain (no run-time indexing: the arrays live in registers / LDS slots)
+template <class A> NMP_DEV float pick_soil(const A& a, int k) {
+  float r = a[L(NSOIL)];
+#pragma unroll
+  for (int j = NSOIL - 1; j >= 1; j--) r = (k == j) ? a[L(j)] : r;
+  return r;
+}
+// ANY(X(1:4) ...) of PHASECHANGE_GLACIER (gla:1804, 1829, 1854, 1883): the reference tests layers 1..4 whatever NSOIL is
+template <class A, class P> NMP_DEV bool any_of_layers_1_to_4(const A& a, P pred) {
+  bool r = false;
+#pragma unroll
+  for (int j = 1; j <= (NSOIL < 4 ? NSOIL : 4); j++) r = r || pred(a[L(j)]);
   return r;
 }
 

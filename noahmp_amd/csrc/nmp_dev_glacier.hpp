@@ -80,8 +80,8 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
 #pragma unroll
   for (int j = -2; j <= NSOIL; j++) { heatr[L(j)] = 0.f; xm[L(j)] = 0.f; }
   // four residual-redistribution passes between the ice layers, gla:1804-1908
-  auto any_gt = [&]() { return stc[L(1)] > TFRZ || stc[L(2)] > TFRZ || stc[L(3)] > TFRZ || stc[L(4)] > TFRZ; };
-  auto any_lt = [&]() { return stc[L(1)] < TFRZ || stc[L(2)] < TFRZ || stc[L(3)] < TFRZ || stc[L(4)] < TFRZ; };
+  auto any_gt = [&]() { return any_of_layers_1_to_4(stc, [](float t) { return t > TFRZ; }); };
+  auto any_lt = [&]() { return any_of_layers_1_to_4(stc, [](float t) { return t < TFRZ; }); };
   if (any_gt() && any_lt()) {
 #pragma unroll
     for (int j = 1; j <= NSOIL; j++) {
@@ -130,7 +130,7 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
       }
     }
   }
-  if (any_gt() && (mice[L(1)] > 0.f || mice[L(2)] > 0.f || mice[L(3)] > 0.f || mice[L(4)] > 0.f)) {
+  if (any_gt() && any_of_layers_1_to_4(mice, [](float m) { return m > 0.f; })) {
 #pragma unroll
     for (int j = 1; j <= NSOIL; j++) {
       if (stc[L(j)] > TFRZ) {
@@ -156,7 +156,7 @@ NMP_DEV void phasechange_glacier(const Ctx& c, Col& s, const Lay<A>& y, const fl
       }
     }
   }
-  if (any_lt() && (mliq[L(1)] > 0.f || mliq[L(2)] > 0.f || mliq[L(3)] > 0.f || mliq[L(4)] > 0.f)) {
+  if (any_lt() && any_of_layers_1_to_4(mliq, [](float m) { return m > 0.f; })) {
 #pragma unroll
     for (int j = 1; j <= NSOIL; j++) {
       if (stc[L(j)] < TFRZ) {
@@ -249,9 +249,9 @@ NMP_DEV void glacier(const Ctx& c, Col& s, const Lay<A>& y) {
       float dz = y.dzsnso[L(iz)];
       float zmid = 0.5f * dz;
       // ZMID = 0.5*DZ(IZ) + DZ(1) + ... + DZ(IZ-1), summed in the reference's order (gla:622-625)
-      if (iz == 2) zmid = zmid + y.dzsnso[L(1)];
-      if (iz == 3) zmid = (zmid + y.dzsnso[L(1)]) + y.dzsnso[L(2)];
-      if (iz == 4) zmid = ((zmid + y.dzsnso[L(1)]) + y.dzsnso[L(2)]) + y.dzsnso[L(3)];
+#pragma unroll
+      for (int m = 1; m < NSOIL; m++)
+        if (m < iz) zmid = zmid + y.dzsnso[L(m)];
       hcpct[L(iz)] = 1.E6f * (0.8194f + 0.1309f * zmid);
       df[L(iz)] = 0.32333f + (0.10073f * zmid);
     }

@@ -775,9 +775,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
       if (!found && s.zwt <= -c.zsoil[L(iz)]) { iwt = iz - 1; found = true; }
   }
   qdis = (1.0f - fcrmax) * 5.0f * nmp_expf_const(-TIMEAN) * nmp_expf(-6.0f * (s.zwt - 2.0f));
-  float smc_iwt = (iwt == 1) ? smc[L(1)] : (iwt == 2) ? smc[L(2)] : (iwt == 3) ? smc[L(3)] : smc[L(4)];
-  float hk_iwt = (iwt == 1) ? hk[L(1)] : (iwt == 2) ? hk[L(2)] : (iwt == 3) ? hk[L(3)] : hk[L(4)];
-  float zn_iwt = (iwt == 1) ? znode[L(1)] : (iwt == 2) ? znode[L(2)] : (iwt == 3) ? znode[L(3)] : znode[L(4)];
+  float smc_iwt = pick_soil(smc, iwt), hk_iwt = pick_soil(hk, iwt), zn_iwt = pick_soil(znode, iwt);
   double s_node = nmp_min(1.0f, smc_iwt / P.smcmax);
   s_node = (s_node > (double)0.01f) ? s_node : (double)0.01f;
   float smpfz = (float)(-((double)(P.psisat * 1000.f) * pow(s_node, (double)(-P.bexp))));
@@ -802,8 +800,9 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
 #pragma unroll
       for (int iz = 3; iz <= NSOIL; iz++)
         if (iz >= iwt + 2) ws = ws + epore[L(iz)] * dzmm[L(iz)];
-      float ep = (iwt == 1) ? epore[L(2)] : epore[L(3)];
-      float zs = (iwt == 1) ? c.zsoil[L(2)] : c.zsoil[L(3)];
+      float ep = epore[L(NSOIL - 1)], zs = c.zsoil[L(NSOIL - 1)];             // layer IWT+1, IWT <= NSOIL-2 here
+#pragma unroll
+      for (int j = NSOIL - 3; j >= 1; j--) { ep = (iwt == j) ? epore[L(j + 1)] : ep; zs = (iwt == j) ? c.zsoil[L(j + 1)] : zs; }
       s.zwt = -zs - div_rc((s.wt - ROUS * 1000.f * 25.f - ws) / (ep), NMP_RCC(1000.f));
     }
     float wtsub = 0.f;

@@ -112,7 +112,7 @@ struct LaunchDesc {
   noahmp_step_args a;            // array members = device pointers
   const noahmp_tables* tables;
   int ts_i[6]; float ts_f[15];   // the tables' scalars (TabScalars of the physics headers: tab_scalars_pack / _unpack)
-  float dt, zsoil[8];
+  float dt, zsoil[NOAHMP_NSNOW + NOAHMP_NSOIL + 1];
   int isurban, ni, nka, nti, ntj, k1, kp_lo, kp_hi, yearlen;
   unsigned long long* err;
   int* counts;

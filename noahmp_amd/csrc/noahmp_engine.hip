@@ -119,6 +119,7 @@ __attribute__((constructor)) static void nmp_runtime_env() { setenv("GPU_PINNED_
 extern "C" {
 
 int noahmp_hip_abi_version(void) { return NOAHMP_HIP_ABI_VERSION; }
+int noahmp_hip_nsoil(void) { return NOAHMP_NSOIL; }
 size_t noahmp_hip_sizeof_step_args(void) { return sizeof(noahmp_step_args); }
 size_t noahmp_hip_sizeof_tables(void) { return sizeof(noahmp_tables); }
 
@@ -1073,7 +1074,7 @@ const char* noahmp_hip_error_string(int code) {
     case NOAHMP_ERR_GLACIER_ENERGY_BALANCE: return "glacier: energy budget (gla:2948)";
     case NOAHMP_ERR_GLACIER_WATER_BALANCE: return "glacier: water budget (gla:2968)";
     case NOAHMP_ERR_GLACIER_FIRE_NONPOSITIVE: return "glacier: emitted longwave <0 (gla:541)";
-    case NOAHMP_ERR_NSOIL_UNSUPPORTED: return "engine is compiled for NSOIL=4, NSNOW=3";
+    case NOAHMP_ERR_NSOIL_UNSUPPORTED: return "the library is built for another NSOIL (default 4; -DNOAHMP_NSOIL=n), NSNOW=3";
     case NOAHMP_ERR_CLASS_RANGE: return "a column is not of the class its range was declared to hold (sorted_land_columns / sorted_glacier_columns)";
     case NOAHMP_ERR_ISNOW_RANGE: return "ISNOWXY outside -NSNOW..0";
   }

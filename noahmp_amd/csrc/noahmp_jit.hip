@@ -64,6 +64,7 @@ const char* kBuildMacros =
     "#define NMP_WAVES_PER_EU " NMP_STR(NMP_WAVES_PER_EU) "\n"
     "#define NMP_LIBM_LDS " NMP_STR(NMP_LIBM_LDS) "\n"
     "#define NMP_FIXED_BLOCK " NMP_STR(NMP_FIXED_BLOCK) "\n"
+    "#define NOAHMP_NSOIL " NMP_STR(NOAHMP_NSOIL) "\n"
 #ifdef NMP_TRUNC
     "#define NMP_TRUNC " NMP_STR(NMP_TRUNC) "\n"
 #endif

@@ -98,7 +98,8 @@ def config2(tables, ni=1024, nj=1024, seed=2, cfg=None):
     toff = np.clip(r.normal(0.0, 5.0, size=shp), -7.5, 15.0).astype(F)     # keep T > 275 K: no snow
     s.t_offset = toff
     a["tsk"][...] = F(283.0) + toff
-    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+    for k in range(s.cfg.nsoil):            # layers below the fourth (NSOIL > 4 builds) continue the profile
+        dt_, sm = 0.5 * k, (0.25, 0.27, 0.30, 0.31)[min(k, 3)]
         a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
         a["smois"][:, k, :] = F(sm) + r.uniform(-0.05, 0.05, size=shp).astype(F)
     a["snow"][...] = 0.0
@@ -135,7 +136,8 @@ def config3(tables, ni=4608, nj=1536, seed=3, cfg=None, snow_frac=0.30, urban_fr
     rho = r.uniform(100.0, 350.0, size=shp).astype(F)
     a["snow"][...] = np.where(has_snow, swe, F(0.0))
     a["snowh"][...] = np.where(has_snow, swe / rho, F(0.0))
-    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+    for k in range(s.cfg.nsoil):            # layers below the fourth (NSOIL > 4 builds) continue the profile
+        dt_, sm = 0.5 * k, (0.25, 0.27, 0.30, 0.31)[min(k, 3)]
         a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
         a["smois"][:, k, :] = F(sm) + r.uniform(-0.05, 0.05, size=shp).astype(F)
     diurnal_forcing(s, 0, t_offset=s.t_offset)
@@ -254,7 +256,8 @@ def veg_snow_matrix(tables, cfg=None, seed=21):
     a["tsk"][...] = tair
     a["snowh"][...] = depth
     a["snow"][...] = depth * F(200.0)
-    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+    for k in range(s.cfg.nsoil):            # layers below the fourth (NSOIL > 4 builds) continue the profile
+        dt_, sm = 0.5 * k, (0.25, 0.27, 0.30, 0.31)[min(k, 3)]
         a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
         a["smois"][:, k, :] = F(sm) + r.uniform(-0.04, 0.04, size=shp).astype(F)
     diurnal_forcing(s, 0, t_offset=s.t_offset)
@@ -289,7 +292,8 @@ def scalar_tile(tables, cfg=None, seed=23):
     a["tsk"][...] = tair
     a["snowh"][...] = depth
     a["snow"][...] = depth * F(200.0)
-    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+    for k in range(s.cfg.nsoil):            # layers below the fourth (NSOIL > 4 builds) continue the profile
+        dt_, sm = 0.5 * k, (0.25, 0.27, 0.30, 0.31)[min(k, 3)]
         a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
         a["smois"][:, k, :] = F(sm) + r.uniform(-0.04, 0.04, size=shp).astype(F)
     diurnal_forcing(s, 0, t_offset=s.t_offset)
@@ -324,7 +328,8 @@ def snow_edges(tables, cfg=None, seed=22):
     a["tsk"][...] = tair
     a["snowh"][...] = edges[None, :]
     a["snow"][...] = edges[None, :] * r.uniform(120.0, 300.0, size=shp).astype(F)
-    for k, (dt_, sm) in enumerate(zip((0.0, 0.5, 1.0, 1.5), (0.25, 0.27, 0.30, 0.31))):
+    for k in range(s.cfg.nsoil):            # layers below the fourth (NSOIL > 4 builds) continue the profile
+        dt_, sm = 0.5 * k, (0.25, 0.27, 0.30, 0.31)[min(k, 3)]
         a["tslb"][:, k, :] = np.minimum(a["tsk"], F(273.0)) + F(dt_)
         a["smois"][:, k, :] = F(sm)
     diurnal_forcing(s, 0, t_offset=s.t_offset)

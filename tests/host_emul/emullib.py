@@ -10,21 +10,23 @@ ROOT = os.path.dirname(os.path.dirname(_HERE))
 LIB = os.path.join(_HERE, "libnmp_emul.so")
 
 
-def build():
+def build(nsoil=4):
+    """nsoil != 4: the device source compiled with -DNOAHMP_NSOIL=n (a library of its own beside the default one)."""
+    lib = LIB if nsoil == 4 else LIB.replace(".so", "_nsoil%d.so" % nsoil)
     src = os.path.join(_HERE, "emul.hip")
     csrc = os.path.join(ROOT, "noahmp_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
-    if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
-        return
+    deps = [src, os.path.join(ROOT, "include", "noahmp_hip.h")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    if os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
+        return lib
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-fPIC", "-shared", "-std=c++17",
-                           "-ffp-contract=off", "-mfma", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + csrc, src, "-o", LIB])
+                           "-ffp-contract=off", "-mfma", "-Wno-unused-value", "-DNOAHMP_NSOIL=%d" % nsoil,
+                           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, src, "-o", lib])
+    return lib
 
 
 class EmulLib:
-    def __init__(self):
-        build()
-        self.lib = C.CDLL(LIB)
+    def __init__(self, nsoil=4):
+        self.lib = C.CDLL(build(nsoil))
         self.lib.emul_set_tables.argtypes = [C.POINTER(Tables)]
         self.lib.emul_step.argtypes = [C.POINTER(StepArgs), C.POINTER(Status)]
         self.lib.emul_init.argtypes = [C.POINTER(StepArgs), C.c_int, C.c_int, C.POINTER(Status)]
