@@ -26,6 +26,26 @@ def cfg_of(ns, **kw):
     return ModelConfig(nsoil=ns, dzs=DZS[ns], **kw)
 
 
+FIXTURE_STEPS, FIXTURE_HOUR0 = 12, 6
+
+
+def fixture_store(tables):
+    """The seeded 6-layer tile of tests/golden/golden_nsoil6.npz (make_golden_nsoil6.py: the compiled reference's outputs after 12 steps)."""
+    s = synth.mixed_small(tables[1], ni=64, nj=6, cfg=cfg_of(6), glacier_frac=0.08, seed=23)
+    synth.first_step_fixups(s)
+    return s
+
+
+def fixture_check(store, what):
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_nsoil6.npz"))
+    assert len(z.files) > 90
+    for k in z.files:
+        x, y = z[k], np.asarray(store.a[k])
+        if x.dtype == np.float32:
+            x, y = x.view(np.uint32), y.view(np.uint32)
+        assert np.array_equal(x, y), "%s: %s differs from the committed reference output at %s" % (what, k, np.argwhere(x != y)[:3].tolist())
+
+
 def same_bits(a, b, what, names=None, skip=()):
     for k in (names or a.a):
         if k in skip or (FIELD_INFO.get(k, (0, 0, "inout"))[2] == "in" and names is None):
@@ -69,6 +89,20 @@ def test_device_source_free_run_vs_reference(ref, emul, tables):
     synth.first_step_fixups(s)
     sr, se = free_run(ref, lambda x, it: emul.noahmplsm(x, it, 2000, 180.0), s, 24)
     same_bits(sr, se, "NSOIL=%d free run, 24 steps" % emul.nsoil)
+
+
+def test_device_source_six_layers_vs_committed_reference_output(tables):
+    """No compiled reference needed: the fixture holds its outputs."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    from host_emul.emullib import EmulLib
+    e = EmulLib(nsoil=6)
+    e.set_tables(tables[0])
+    s = fixture_store(tables)
+    for it in range(1, FIXTURE_STEPS + 1):
+        synth.diurnal_forcing(s, (FIXTURE_HOUR0 + it - 1) % 24, t_offset=s.t_offset)
+        assert e.noahmplsm(s, it, 2000, 180.0).code == 0
+    fixture_check(s, "device source on the host, NSOIL=6")
 
 
 @pytest.mark.parametrize("kw", [dict(idveg=2), dict(iopt_run=2), dict(iopt_run=3), dict(iopt_run=4), dict(iopt_frz=2, iopt_inf=2),
@@ -149,6 +183,16 @@ def test_gpu_six_layer_library_host_arrays_vs_reference(ref, engine6, tables, kw
     synth.first_step_fixups(s)
     sr, sg = free_run(ref, lambda x, it: engine6.noahmplsm(x, it, 2000, 180.0), s, 12, first_hour=6)
     same_bits(sr, sg, "6-layer library %r, 12 steps" % kw)
+
+
+@pytest.mark.gpu
+def test_gpu_six_layer_library_vs_committed_reference_output(engine6, tables):
+    """The 6-layer library against tests/golden/golden_nsoil6.npz (outputs of the compiled reference): no oracle/_ref needed."""
+    s = fixture_store(tables)
+    for it in range(1, FIXTURE_STEPS + 1):
+        synth.diurnal_forcing(s, (FIXTURE_HOUR0 + it - 1) % 24, t_offset=s.t_offset)
+        assert engine6.noahmplsm(s, it, 2000, 180.0).code == 0
+    fixture_check(s, "6-layer library")
 
 
 @pytest.mark.gpu
