@@ -23,7 +23,10 @@ def _headers():
 # -amdgpu-sched-strategy=max-ilp: the column kernel is bound by its waves' own instruction streams; this scheduler fills the gfx950 hazard
 # slots (v_cmp -> v_cndmask, v_div_scale -> v_div_fmas) with independent work instead of s_nop: 584 -> 376 static s_nop, land kernel -0.45 %
 # (A/B, profiles/r05_experiments.md section 6).  Scheduling only: same instructions, same results.  noahmp_jit.hip passes the same flag.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+# -fno-slp-vectorize: packed float32 (v_pk_*) is no throughput lever on this chip (a v_pk_mul_f32 occupies the SIMD as long as two v_mul_f32) and
+# pairing the operands costs moves and registers: without the SLP vectorizer the land kernel has 242 fewer static v_mov, 231 instead of 243
+# VGPRs and runs 0.6 % faster (A/B twice on one box: 3.210 / 3.215 -> 3.193 / 3.193 ms).  Same IEEE operations, same results.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
          "-Wno-unused-value", "-I" + os.path.join(_HERE, "..", "include")]
 
 

@@ -91,7 +91,7 @@ const char* kWrapper =
     "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m2(const nmp::KArgs k) {\n"
     "  column_kernel_body<NMP_FIXED_BLOCK, true, 2>(k); }\n";
 // (the scheduler strategy: as noahmp_amd/build.py -- fewer hazard s_nop in the issue-bound column kernel, round 5)
-const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
 constexpr int kNumCompileFlags = sizeof(kCompileFlags) / sizeof(kCompileFlags[0]);
 
 uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
