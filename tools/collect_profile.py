@@ -82,7 +82,7 @@ for r in csv.DictReader(open(stats)):
     L.append("| %s | %s | %.0f | %s | %s | %s |" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"], r["Percentage"]))
 L += ["", "Launch: grid %(Grid_Size)s, workgroup %(Workgroup_Size)s, LDS %(LDS_Block_Size)s B/block, scratch %(Scratch_Size)s B/lane, "
       "VGPR %(VGPR_Count)s, AGPR %(Accum_VGPR_Count)s, SGPR %(SGPR_Count)s (rocprofv3's fields; the compiler's "
-      "`-Rpass-analysis=kernel-resource-usage` report for this kernel is 245 unified VGPRs, none spilled, no scratch (option-specialised land-only kernel), 2 waves/SIMD)." % meta, "",
+      "`-Rpass-analysis=kernel-resource-usage` report for this kernel is 231 unified VGPRs, none spilled, no scratch (option-specialised land-only kernel), 2 waves/SIMD)." % meta, "",
       "## PMC (separate `--pmc` passes, mean per launch of the column kernel)", "", "| counter | mean per launch |", "|---|---|"]
 for k in sorted(pmc):
     L.append("| %s | %.4g |" % (k, pmc[k]))
