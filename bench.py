@@ -920,12 +920,17 @@ def host_path_leg(args, eng, tb, torch):
         for k in FKEYS:
             np.copyto(s.a[k], hours[h][k])
 
+    call_s = [0.0]                                # time inside noahmp_hip_step alone (the rest of a loop pass is this caller's forcing rewrite)
+
     def loop(n, first_it):
         km, adv = 0.0, 0
+        call_s[0] = 0.0
         t0 = time.perf_counter()
         for i in range(n):
             write_forcing(6 + (first_it + i - 1) % 12)
+            tc = time.perf_counter()
             st = eng.noahmplsm(s, first_it + i, 2000, 180.0)
+            call_s[0] += time.perf_counter() - tc
             km += st.kernel_ms
             adv += st.n_land + st.n_glacier
         return time.perf_counter() - t0, km, adv
@@ -976,10 +981,13 @@ def host_path_leg(args, eng, tb, torch):
         eng.fetch()                               # waits for the last step, brings INOUT + OUT arrays back
         t1 = time.perf_counter()
         res["resident"] = {"value": s.ncol * n / (t1 - t0), "ms_per_step": (tf - t0) / n * 1e3, "fetch_ms": (t1 - tf) * 1e3, "steps": n,
-                           "kernel_ms": km / n,
+                           "kernel_ms": km / n, "engine_ms_per_call": call_s[0] / n * 1e3,
+                           "engine_column_steps_per_s": s.ncol * n / call_s[0],
                            "ms_per_step_with_one_fetch_per_%d_steps" % n: (t1 - t0) / n * 1e3,
                            "options": sorted(opts), "note": "value = all cells of the tile x steps / wall time incl. the final fetch (the "
-                           "deferred status of a call reports the PREVIOUS step, so tallies lag by one)"}
+                           "deferred status of a call reports the PREVIOUS step, so tallies lag by one); ms_per_step = this caller's rewrite of "
+                           "its five forcing arrays (host_forcing_write_ms) + engine_ms_per_call, the time inside noahmp_hip_step: the upload of "
+                           "the call's forcing (PCIe), under which the previous step's kernel runs"}
         # (3) the same with "resident_sorted": the engine keeps a second, sorted set of mirrors and runs the class-range kernels on it
         prev["resident_sorted"] = eng.set_option("resident_sorted", 1)
         km = []
@@ -987,14 +995,18 @@ def host_path_leg(args, eng, tb, torch):
             write_forcing(6 + (it - 1) % 12)
             eng.noahmplsm(s, it, 2000, 180.0)
         t0 = time.perf_counter()
+        call_s[0] = 0.0
         for i in range(n):
             write_forcing(6 + (33 + i - 1) % 12)
+            tc = time.perf_counter()
             km.append(eng.noahmplsm(s, 33 + i, 2000, 180.0).kernel_ms)
+            call_s[0] += time.perf_counter() - tc
         tf = time.perf_counter()
         eng.fetch()
         t1 = time.perf_counter()
         res["resident_sorted"] = {"value": s.ncol * n / (t1 - t0), "ms_per_step": (tf - t0) / n * 1e3, "fetch_ms": (t1 - tf) * 1e3, "steps": n,
-                                  "kernel_ms": sum(km[1:]) / max(len(km) - 1, 1),
+                                  "kernel_ms": sum(km[1:]) / max(len(km) - 1, 1), "engine_ms_per_call": call_s[0] / n * 1e3,
+                                  "engine_column_steps_per_s": s.ncol * n / call_s[0],
                                   "note": "resident + set_option(resident_sorted, 1): host arrays in tile order, device mirrors sorted by (class, "
                                           "vegetation type, snow-layer count, TSK bin); kernel_ms = the class-range kernels of a call (under deferred "
                                           "status a call reports the previous step)"}
