@@ -953,7 +953,8 @@ def host_path_leg(args, eng, tb, torch):
         eng.noahmplsm(s, it, 2000, 180.0)
     dt, km, adv = loop(3, 6)
     res["pinned_row_chunks"] = {"value": adv / dt, "ms_per_step": dt / 3 * 1e3, "kernel_ms": km / 3, "steps": 3,
-                                "host_chunks": eng.set_option("host_chunks", prev["host_chunks"]),
+                                "host_chunks": (lambda v: "chosen by the engine from the tile size (3..8: %d here)" % max(3, min(8, (s.ncol + 600000) // 1200000))
+                                                if v == -1 else v)(eng.set_option("host_chunks", prev["host_chunks"])),
                                 "page_locked_arrays": int(eng.lib.noahmp_hip_debug_live_host_registrations()),
                                 "note": "caller arrays page-locked in place, the tile advanced in row chunks (H2D | kernel | D2H on three "
                                         "streams); every array H2D and INOUT + OUT D2H per call"}

@@ -68,6 +68,8 @@ struct Engine {
   struct HostReg { size_t bytes; int seen; int state; };     // state 0 pageable, 1 registered, -1 registration refused
   std::unordered_map<const void*, HostReg> host_regs;
   int host_chunks = 3;          // 0/1: single-shot staging (3 measured best at 1 M columns: fewer, larger copies)
+  bool host_chunks_auto = true; // until set_option("host_chunks") names a count: 3 up to ~2.4 M columns, then one chunk per ~1.2 M, at most 8
+                                // (7 M columns: 90.0 ms with 3, 85.1 with 6, 87.6 with 12, 97.3 with 24 -- tools/host_chunks_exp.py)
   int pin_host_arrays = 0;      // hipHostRegister arrays seen twice at the same address (caller guarantees their lifetime)
   int trust_out_mirror = 0;     // do not re-upload OUT arrays after the first call (caller leaves them alone between calls)
   bool out_mirror_valid = false;

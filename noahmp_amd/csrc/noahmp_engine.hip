@@ -189,7 +189,11 @@ int noahmp_hip_set_option(const char* key, int value) {
   int prev = -1;
   if (!strcmp(key, "block")) { prev = g.block; if (value == 64 || value == 128 || value == 256) g.block = value; }
   else if (!strcmp(key, "lds")) { prev = g.use_lds; g.use_lds = value ? 1 : 0; }
-  else if (!strcmp(key, "host_chunks")) { prev = g.host_chunks; if (value >= 0 && value <= 32) g.host_chunks = value; }
+  else if (!strcmp(key, "host_chunks")) {        // -1: the engine picks by tile size (the default, and what a query returns then)
+    prev = g.host_chunks_auto ? -1 : g.host_chunks;
+    if (value == -1) g.host_chunks_auto = true;
+    else if (value >= 0 && value <= 32) { g.host_chunks = value; g.host_chunks_auto = false; }
+  }
   else if (!strcmp(key, "pin_host_arrays")) {
     prev = g.pin_host_arrays;
     if (value == 0 || value == 1) {
@@ -436,12 +440,19 @@ static void maybe_pin(const void* host, size_t bytes) {
 // Host-memory path for large tiles: the tile is advanced in row chunks, chunk c+1 uploading while chunk c computes and
 // chunk c-1 downloads (three streams).  Results are those of the single launch: columns are independent, the tallies
 // accumulate, and the error word orders columns by their index in the whole tile (KArgs::t_offset).
+static int pipeline_chunks(const noahmp_step_args* a) {
+  if (!g.host_chunks_auto) return g.host_chunks;
+  const long ncol = (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1);
+  const long n = (ncol + 600000) / 1200000;
+  return (int)(n < 3 ? 3 : (n > 8 ? 8 : n));
+}
 static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_status* st) {
   KArgs k;
   fill_kargs(k, a);
   const int nj_mem = a->jme - a->jms + 1;
   if (!g.s_up) { HIPCHK(hipStreamCreateWithFlags(&g.s_up, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&g.s_dn, hipStreamNonBlocking)); }
-  const int nchunk = g.host_chunks < nj_mem ? g.host_chunks : nj_mem;
+  const int want = pipeline_chunks(a);
+  const int nchunk = want < nj_mem ? want : nj_mem;
   while ((int)g.pipe_events.size() < 3 * nchunk) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); g.pipe_events.push_back(e); }
   if (g.pipe_host.size() != (size_t)kNumFields) { g.pipe_host.assign(kNumFields, nullptr); g.out_mirror_valid = false; }
   for (int f = 0; f < kNumFields; f++) {       // "trust_out_mirror" speaks about the arrays of the previous call only
@@ -828,9 +839,9 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   }
   if (mem == NOAHMP_MEM_HOST) g.resident_valid = false;
   // the row-chunk pipeline only pays with pinned arrays (pageable asynchronous copies are staged and serialise)
-  if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && g.host_chunks > 1 &&
+  if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && pipeline_chunks(a) > 1 &&
       (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) >= 32768 &&
-      a->jme - a->jms + 1 >= 2 * g.host_chunks)
+      a->jme - a->jms + 1 >= 2 * pipeline_chunks(a))
     return step_host_pipelined(a, s, st);
 
   KArgs k;
