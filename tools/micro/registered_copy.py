@@ -44,3 +44,34 @@ assert int(rt.cudaHostRegister(big.ctypes.data, big.nbytes, 0)) == 0
 sl = [torch.from_numpy(big[i * PLANE:(i + 1) * PLANE]) for i in range(NPL)]
 for n in (1, 2, 4):
     run(sl, n, "one registered block, slices")
+
+
+def run2(host_up, host_dn, tag, reps=5):
+    """H2D of NPL planes and D2H of NPL planes at the same time on two streams (what the row-chunk pipeline of the host path does)."""
+    su, sd = torch.cuda.Stream(), torch.cuda.Stream()
+    dev2 = [torch.empty(PLANE, dtype=torch.uint8, device="cuda") for _ in range(NPL)]
+    for mode in ("D2H alone", "H2D + D2H together"):
+        best = 1e9
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(NPL):
+                if mode != "D2H alone":
+                    with torch.cuda.stream(su):
+                        dev[i].copy_(host_up[i], non_blocking=True)
+                with torch.cuda.stream(sd):
+                    host_dn[i].copy_(dev2[i], non_blocking=True)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        nb = NPL * PLANE * (2 if mode != "D2H alone" else 1)
+        print("%-34s %-20s %6.2f ms  %5.1f GB/s (sum of both directions)" % (tag, mode, best * 1e3, nb / best / 1e9))
+
+
+raw2 = [np.ones(PLANE, dtype=np.uint8) for _ in range(NPL)]
+reg2 = []
+for a in raw2:
+    assert int(rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)) == 0
+    reg2.append(torch.from_numpy(a))
+run2(reg, reg2, "hipHostRegister in place")
+pinned2 = [torch.empty(PLANE, dtype=torch.uint8).pin_memory() for _ in range(NPL)]
+run2(pinned, pinned2, "hipHostMalloc (torch pin_memory)")
