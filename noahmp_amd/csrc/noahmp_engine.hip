@@ -452,7 +452,17 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
   const int nj_mem = a->jme - a->jms + 1;
   if (!g.s_up) { HIPCHK(hipStreamCreateWithFlags(&g.s_up, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&g.s_dn, hipStreamNonBlocking)); }
   const int want = pipeline_chunks(a);
-  const int nchunk = want < nj_mem ? want : nj_mem;
+  const int nreg = want < nj_mem ? want : nj_mem;
+  // row boundaries of the chunks.  The download side is the longer one (119 words per column down, 87 up) and cannot start before the first
+  // chunk is up and computed: the first regular chunk is split 1 : 3, so that the downloads start four times earlier
+  std::vector<int> rows;
+  rows.push_back(0);
+  for (int c = 0; c < nreg; c++) {
+    const int r0 = (int)((long)nj_mem * c / nreg), r1 = (int)((long)nj_mem * (c + 1) / nreg);
+    if (c == 0 && g.host_chunks_auto && r1 - r0 >= 8) rows.push_back(r0 + (r1 - r0) / 4);
+    rows.push_back(r1);
+  }
+  const int nchunk = (int)rows.size() - 1;
   while ((int)g.pipe_events.size() < 3 * nchunk) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); g.pipe_events.push_back(e); }
   if (g.pipe_host.size() != (size_t)kNumFields) { g.pipe_host.assign(kNumFields, nullptr); g.out_mirror_valid = false; }
   for (int f = 0; f < kNumFields; f++) {       // "trust_out_mirror" speaks about the arrays of the previous call only
@@ -480,7 +490,7 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
   HIPCHK(hipMemsetAsync(g.d_counts, 0, kCountSlots * kCountStride * sizeof(int), s));
   // uploads, in row order
   for (int c = 0; c < nchunk; c++) {
-    const int r0 = (int)((long)nj_mem * c / nchunk), r1 = (int)((long)nj_mem * (c + 1) / nchunk);
+    const int r0 = rows[c], r1 = rows[c + 1];
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       if (fd.io == 2 && !up_out) continue;
@@ -492,7 +502,7 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
   }
   // kernels and downloads
   for (int c = 0; c < nchunk; c++) {
-    const int r0 = (int)((long)nj_mem * c / nchunk), r1 = (int)((long)nj_mem * (c + 1) / nchunk);
+    const int r0 = rows[c], r1 = rows[c + 1];
     HIPCHK(hipStreamWaitEvent(s, g.pipe_events[3 * c], 0));
     KArgs kc = k;
     const int j0 = a->jms + r0 > a->jts ? a->jms + r0 : a->jts;
