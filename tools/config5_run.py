@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from noahmp_amd import synth5  # noqa: E402
-from noahmp_amd.driver import Engine  # noqa: E402
+from noahmp_amd.driver import Engine, NoahMPFatal  # noqa: E402
 from noahmp_amd.state import ColumnStore  # noqa: E402
 from noahmp_amd.tables import load_tables  # noqa: E402
 from oracle.portlib import PortLib  # noqa: E402
@@ -46,6 +46,35 @@ def extract(store, flat, n=None):
             col = v.reshape(-1)[flat]
         out.a[k][...] = col.T[None] if col.ndim == 2 else col[None]
     return out
+
+
+def fatal_column_vs_oracle(port, raw, lon, recs_tile, tcol, fail_step, e, cfgkw, ni, nj, verbose):
+    """The oracle on the one tile column the device run stopped at, from the same raw state through the same chain up to the failing step."""
+    osamp = extract(raw, [tcol])
+    lon_s = lon.reshape(-1)[[tcol]][None].copy()
+    nrec = (fail_step + synth5.RECORD_HOURS - 1) // synth5.RECORD_HOURS + 1
+    rec_s = []
+    for i in range(nrec):
+        rec_s.append({k: (v.reshape(-1)[tcol:tcol + 1].cpu().numpy()[None].copy() if v is not None else None) for k, v in recs_tile.at(i).items()})
+    port.noahmp_init(osamp, fndsnowh=True)
+    rain_s = np.zeros((1, 1), np.float32)
+    codes = []
+    for n in range(fail_step):
+        ri, k = divmod(n, synth5.RECORD_HOURS)
+        port.forcing_interpolate(osamp, rec_s[ri], rec_s[ri + 1] if k else None, 3600 * k, 3600 * synth5.RECORD_HOURS, rain_s)
+        iday, ihour = synth5.step_time(n)
+        jul = port.forcing_prep(osamp, lon_s, rain_s, iday, ihour, first_step=(n == 0))
+        codes.append(int(port.noahmplsm(osamp, n + 1, 2000, jul).code))
+        if codes[-1]:
+            break
+    res = dict(options=cfgkw or {}, grid=[ni, nj], device_fatal=dict(code=int(e.code), step=fail_step, sorted_i=int(e.i), sorted_j=int(e.j), tile_column=tcol,
+                                                                  vegtyp=int(raw.a["ivgtyp"].reshape(-1)[tcol]), soiltyp=int(raw.a["isltyp"].reshape(-1)[tcol])),
+               oracle_codes_of_that_column=[c for c in codes if c] or [0], oracle_stopped_at_step=(len(codes) if codes and codes[-1] else None),
+               oracle_same_fatal=bool(codes and codes[-1] == int(e.code) and len(codes) == fail_step),
+               sample_bit_identical=None, checkpoints=[], device_status_max=int(e.code))
+    if verbose:
+        print(json.dumps(res))
+    return res
 
 
 def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkpoints=(1, 24, 240), restart_path=None, cfgkw=None,
@@ -103,6 +132,8 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
     t0 = time.perf_counter()
     kernel_ms = 0.0
     rec_a = rec_b = None
+    last_sync = 0
+    recs_tile = synth5.Records(torch.from_numpy(np.ascontiguousarray(raw.a["xlatin"])).to(dev).reshape(-1), lon_t, static_t)   # tile order (fatal_column_vs_oracle)
     with torch.cuda.stream(ts):
         for n in range(nsteps):
             ri, k = divmod(n, synth5.RECORD_HOURS)
@@ -115,7 +146,16 @@ def run(ni=3600, nj=1800, nsteps=720, nsample=4096, seed=5, verbose=True, checkp
             eng.noahmplsm_async(d.step_args(n + 1, 2000, jul), stream=sp)
             resort_due = bool(resort_every) and (n + 1) % resort_every == 0 and n + 1 < nsteps
             if n + 1 in checkpoints or (n + 1) % 24 == 0 or resort_due:
-                st, _ = eng.sync()
+                try:
+                    st, _ = eng.sync()
+                except NoahMPFatal as e:
+                    # A column stopped the model (the reference would STOP in wrf_error_fatal): is it the model or the engine?  The oracle takes
+                    # the very column through the same chain; the same code at the same step means the synthetic state ran into the model's own check.
+                    ts.synchronize()
+                    fail_step = last_sync + int(str(e).split("step +")[1].split(":")[0]) + 1
+                    tcol = int(perm[(e.j - 1) * ni + (e.i - 1)].item())
+                    return fatal_column_vs_oracle(port, raw, lon, recs_tile, tcol, fail_step, e, cfgkw, ni, nj, verbose)
+                last_sync = n + 1
                 kernel_ms += st.kernel_ms
                 dev_codes.append(int(st.code))                           # 0 = every column passed the model's own balance checks
                 n_done += sum(eng.sync_counts())

@@ -267,7 +267,9 @@ PY
   while read o; do
     timeout 900 python tools/config5_run.py 720 360 72 8192 $o 2>&1 | tail -1 | python3 -c "import sys,json
 try:
-    d=json.loads(sys.stdin.read()); print(d['options'], 'sample_bit_identical', d['sample_bit_identical'], d['checkpoints'], 'status_max', d.get('device_status_max'))
+    d=json.loads(sys.stdin.read())
+    if d.get('device_fatal'): print(d['options'], 'STOPPED BY THE MODEL', d['device_fatal'], 'oracle stops at the same column, step and code:', d['oracle_same_fatal'])
+    else: print(d['options'], 'sample_bit_identical', d['sample_bit_identical'], d['checkpoints'], 'status_max', d.get('device_status_max'))
 except Exception as e: print('FAILED', '$o', e)" | tee -a $O/fuzzopts5.log
   done < $O/sets.txt
   ;;
