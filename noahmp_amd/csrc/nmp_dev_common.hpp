@@ -348,23 +348,29 @@ NMP_DEV float uniform_value(float x) { return x; }
 NMP_DEV double uniform_value(double x) { return x; }
 #endif
 template <class T> NMP_DEV T pick_layer(const T* a, int k) {
-  T v[NSOIL + 1];
+  // (no local array of the values: the float64 instantiation's one stayed in scratch memory -- three 16-byte stores and loads per lane)
+  T r = uniform_value(a[L(0)]);
 #pragma unroll
-  for (int j = 0; j <= NSOIL; j++) v[j] = uniform_value(a[L(j)]);
-  T r = v[0];
-#pragma unroll
-  for (int j = 1; j < NSOIL; j++) r = (k == j) ? v[j] : r;
-  r = (k >= NSOIL) ? v[NSOIL] : r;
+  for (int j = 1; j < NSOIL; j++) { const T vj = uniform_value(a[L(j)]); r = (k == j) ? vj : r; }
+  const T vn = uniform_value(a[L(NSOIL)]);
+  r = (k >= NSOIL) ? vn : r;
   return r;
 }
 
-// a[L(k)] of a per-column soil array, 1 <= k <= NSOIL, as a select chain (no run-time indexing: the arrays live in registers / LDS slots)
-template <class A> NMP_DEV float pick_soil(const A& a, int k) {
-  float r = a[L(NSOIL)];
-#pragma unroll
-  for (int j = NSOIL - 1; j >= 1; j--) r = (k == j) ? a[L(j)] : r;
-  return r;
+// a[L(k)] of a per-column soil array, 1 <= k <= NSOIL, as nested selects (k == 1) ? a1 : (k == 2) ? a2 : ... : aN -- no run-time indexing: the
+// arrays are registers.  (Written as a loop that starts from aN and overrides it, the compiler folded the selects of loads into one load at a
+// selected address: three arrays went to scratch memory, 48 bytes of stores per column -- found in the write counters, round 5.)
+template <int J, class A> NMP_DEV float pick_soil_from(const A& a, int k) {
+  if constexpr (J >= NSOIL) return a[L(NSOIL)];
+  else return (k == J) ? a[L(J)] : pick_soil_from<J + 1>(a, k);
 }
+template <class A> NMP_DEV float pick_soil(const A& a, int k) { return pick_soil_from<1>(a, k); }
+// a[L(k + 1)] for 1 <= k <= NSOIL - 2, the same way: (k == 1) ? a2 : (k == 2) ? a3 : ... : a(NSOIL-1)
+template <int J, class A> NMP_DEV float pick_soil_below_from(const A& a, int k) {
+  if constexpr (J >= NSOIL - 2) return a[L(NSOIL - 1)];
+  else return (k == J) ? a[L(J + 1)] : pick_soil_below_from<J + 1>(a, k);
+}
+template <class A> NMP_DEV float pick_soil_below(const A& a, int k) { return pick_soil_below_from<1>(a, k); }
 // ANY(X(1:4) ...) of PHASECHANGE_GLACIER (gla:1804, 1829, 1854, 1883): the reference tests layers 1..4 whatever NSOIL is
 template <class A, class P> NMP_DEV bool any_of_layers_1_to_4(const A& a, P pred) {
   bool r = false;

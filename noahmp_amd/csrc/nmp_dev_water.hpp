@@ -800,9 +800,7 @@ NMP_DEV void groundwater(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, c
 #pragma unroll
       for (int iz = 3; iz <= NSOIL; iz++)
         if (iz >= iwt + 2) ws = ws + epore[L(iz)] * dzmm[L(iz)];
-      float ep = epore[L(NSOIL - 1)], zs = c.zsoil[L(NSOIL - 1)];             // layer IWT+1, IWT <= NSOIL-2 here
-#pragma unroll
-      for (int j = NSOIL - 3; j >= 1; j--) { ep = (iwt == j) ? epore[L(j + 1)] : ep; zs = (iwt == j) ? c.zsoil[L(j + 1)] : zs; }
+      const float ep = pick_soil_below(epore, iwt), zs = pick_soil_below(c.zsoil, iwt);       // layer IWT+1, IWT <= NSOIL-2 here
       s.zwt = -zs - div_rc((s.wt - ROUS * 1000.f * 25.f - ws) / (ep), NMP_RCC(1000.f));
     }
     float wtsub = 0.f;
