@@ -351,8 +351,17 @@ class Run:
 
     def _bind_sorted(self):
         d, eng = self.d, self.eng
+        self.mirror = None
         if self.gw is not None:
             self.wargs_col = d.wtable_args()                  # the per-column half works on the sorted store itself
+            if not self.args.plane_moves:
+                # Round 6: no permutation launch around WTABLE_mmf_noahmp.  The column kernels store every advanced column's ZWTXY also
+                # at its cell of the tile-order block (noahmp_hip_step_async_mirror), the per-column half reads QLAT from the block through
+                # the same index plane and writes the new water table to both places (noahmp_hip_wtable_columns_gather_async).  The block's
+                # ZWTXY is current from the start (it was cut from the same grid) and stays so across re-sorts (tile order does not change).
+                nti, ntj = self.geom["ite"] - self.geom["its"] + 1, self.geom["jte"] - self.geom["jts"] + 1
+                self.block_pos = eng.sorted_block_positions(self.perm, nti, ntj, self.gw.ni, self.i_off, self.j_off)
+                self.mirror = (self.block_pos, self.gw.a["zwtxy"])
         self.work = {k: d.a[k] for k in FKEYS}
         src0 = [self.work[k] for k in FKEYS] if self.block_forcing else [self.forcing[0][k] for k in FKEYS]   # (plan only; sources are set per step)
         # T3D has two levels in memory (HRLDAS passes kms:kme = 1:2) and noahmplsm reads level 1: only that level is permuted
@@ -413,7 +422,7 @@ class Run:
         elif self.sorted and self.gw is not None:
             self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
-            self.eng.noahmplsm_async(self.sarg, self.sp)
+            self.eng.noahmplsm_async(self.sarg, self.sp, mirror=self.mirror)
         elif self.sorted:
             self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
@@ -431,7 +440,7 @@ class Run:
         """WTABLE_mmf_noahmp (gw:14) after the ZWTXY ring exchange (gw:231-252), enqueued on the run's stream."""
         torch = self.torch
         halo_store = self.gw if self.gw is not None else self.d
-        if self.gw is not None:                                                      # ZWTXY: sorted -> (i,j) order, into the ring-carrying block
+        if self.gw is not None and self.mirror is None:                              # ZWTXY: sorted -> (i,j) order, into the ring-carrying block
             self.scat.exchange([self.d.a["zwtxy"]], [self.gw.a["zwtxy"]], True, self.gw.ni, self.i_off, self.j_off, self.sp)
         if self.comm.world > 1:                # (one rank: nothing to exchange -- and two events are ~10 us between two kernels)
             with torch.cuda.stream(self.ts):
@@ -441,9 +450,12 @@ class Run:
                 e1.record()
             self.halo_events.append((e0, e1))
         if self.gw is not None:
-            self.eng.wtable_lateral_async(self.wargs, self.gw.a["qlat"], self.sp)     # KCELL / HEAD + QLAT stencil, (i,j) order
-            self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order
-            self.eng.wtable_columns_async(self.wargs_col, self.d.a["qlat"], self.sp)  # everything else, on the sorted store
+            self.eng.wtable_lateral_async(self.wargs, self.gw.a["qlat"], self.sp)     # KCELL / HEAD + QLAT stencil, (i,j) order, one launch
+            if self.mirror is not None:                                              # everything else, on the sorted store; QLAT through the index plane
+                self.eng.wtable_columns_gather_async(self.wargs_col, self.gw.a["qlat"], self.block_pos, self.gw.a["zwtxy"], self.sp)
+            else:
+                self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order
+                self.eng.wtable_columns_async(self.wargs_col, self.d.a["qlat"], self.sp)
         else:
             self.eng.wtable_mmf_async(self.wargs, self.sp)
         self.gw_calls += 1
@@ -563,7 +575,7 @@ class Run5:
         geom = tile_geometry(gx, gy, comm.world, comm.rank, halo=0)
         self.geom = geom
         nx, ny = geom["ite"] - geom["its"] + 1, geom["jte"] - geom["jts"] + 1
-        raw, lon, static = synth5.config5_tile(gx, gy, geom["its"] - 1, geom["jts"] - 1, nx, ny, cfg=cfg)
+        raw, lon, static = synth5.config5_tile(gx, gy, geom["its"] - 1, geom["jts"] - 1, nx, ny, cfg=cfg, smooth=bool(getattr(args, "config5_smooth", False)))
         self.ni, self.nj, self.tile_cells = nx, ny, nx * ny
         self.raw_host = (raw, lon, static) if args.dump else None
         self.d = d = raw.to_device(dev)
@@ -954,7 +966,7 @@ def host_path_leg(args, eng, tb, torch):
     dt, km, adv = loop(3, 6)
     res["pinned_row_chunks"] = {"value": adv / dt, "ms_per_step": dt / 3 * 1e3, "kernel_ms": km / 3, "steps": 3,
                                 "host_chunks": (lambda v: "chosen by the engine from the tile size (3..8: %d here)" % max(3, min(8, (s.ncol + 600000) // 1200000))
-                                                if v == -1 else v)(eng.set_option("host_chunks", prev["host_chunks"])),
+                                                if v in (-1, -2) else v)(eng.set_option("host_chunks", prev["host_chunks"])),
                                 "page_locked_arrays": int(eng.lib.noahmp_hip_debug_live_host_registrations()),
                                 "note": "caller arrays page-locked in place, the tile advanced in row chunks (H2D | kernel | D2H on three "
                                         "streams); every array H2D and INOUT + OUT D2H per call"}
@@ -1046,6 +1058,10 @@ def main():
                          "checked at the --resort-every cadence (0 = only at the end of the warm-up and when stale)")
     ap.add_argument("--lon-band", type=float, default=15.0,
                     help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
+    ap.add_argument("--config5-smooth", action="store_true",
+                    help="config 5: the per-column forcing factors (cloud, humidity, pressure, wind, rain timing) are spatially smooth random "
+                         "fields (synth5.smooth_uniform: correlation length a few hundred km) instead of i.i.d. draws per cell; same marginals, "
+                         "same state.  The i.i.d. generator stays the quoted config-5 number (the conservative one)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-stage-records", action="store_true",
                     help="config 5: evaluate the synthetic 3-hourly forcing records inside the timed region, when a step first needs them "
@@ -1056,6 +1072,12 @@ def main():
                          "working sets, one stream each).  Measured in round 5: no gain for configs 3 / 4 (two land waves per SIMD hold the whole "
                          "register file: a wave of another kernel only ever takes the place of one), 0-2 %% for config 5 depending on how the "
                          "runtime maps streams to hardware queues -- off by default")
+    ap.add_argument("--veg-order", default=None,
+                    help="vegetation categories in the order their columns run inside the sorted land range, comma-separated (the rest follow in "
+                         "numeric order); default: the categories' own numbers")
+    ap.add_argument("--plane-moves", action="store_true",
+                    help="config 4, sorted: rounds 3-5's data flow around WTABLE_mmf_noahmp -- ZWTXY permuted to (i,j) order before the stencil and "
+                         "QLAT permuted back behind it (two launches per call) instead of the index-plane accesses of round 6; same results (A/B)")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
@@ -1105,6 +1127,8 @@ def main():
     eng = Engine(T, device=dev_index, lib_path=os.environ.get("NMP_LIB"))
     if os.environ.get("NMP_BLOCK"):
         eng.set_option("block", int(os.environ["NMP_BLOCK"]))
+    if args.veg_order:
+        eng.set_veg_order([int(v) for v in args.veg_order.split(",")])
 
     def barrier():
         comm.barrier()
@@ -1218,11 +1242,11 @@ def main():
     # The default N > 1 workload is config 4 (the same grid with the groundwater exchange).  So that a scaling curve over
     # N = 1, 2, 4, 8 has its N = 1 point on the SAME workload, the default N = 1 run measures it too, after the headline (a second,
     # separately timed region of the same length; reported beside the headline, never as `value`).
-    scaling_ref = config5_ref = options_ref = host_ref = None
+    scaling_ref = config2_ref = config5_ref = config5_smooth_ref = options_ref = host_ref = None
     if world == 1 and workload == "config3" and args.workload is None and not args.no_scaling_reference:
         summary = dict(tsk_bin=run.tsk_bin, class_ms=list(run.class_ms), n_land=run.n_land, n_adv=run.n_adv, resorts=run.resorts, stale=list(run.stale_seen),
                        sorted=run.sorted, lateral=run.lateral, tile_cells=run.tile_cells, stepwtd=run.stepwtd, kernel_ms=run.kernel_ms,
-                       hour_ms=dict(run.hour_ms), hour_ms_warm=dict(getattr(run, "hour_ms_warm", {})))
+                       hour_ms=dict(run.hour_ms), hour_ms_warm=dict(getattr(run, "hour_ms_warm", {})), step_hours=list(run.step_hours))
         del run
         torch.cuda.empty_cache()
         r4 = Run(args, "config4", comm, eng, tb, dev)
@@ -1231,6 +1255,20 @@ def main():
                        "value": r4.n_adv / dt4, "unit": "column-steps/s", "ms_per_step": dt4 / args.steps * 1e3, "steps": args.steps,
                        "groundwater_calls": r4.gw_calls, "column_kernels_ms_per_step": r4.kernel_ms / args.steps}
         del r4
+        torch.cuda.empty_cache()
+        # BASELINE configs[1]: 1 M synthetic land columns, 0 snow layers, DVEG = 1 (round 1's headline; no number on any later build until round 6)
+        a2 = argparse.Namespace(**vars(args))
+        a2.ni, a2.nj, a2.dump = 1024, 1024, None
+        r2 = Run(a2, "config2", comm, eng, tb, dev)
+        dt2 = timed_leg(r2, args.steps, args.warmup, barrier)
+        K2 = args.steps
+        config2_ref = {"workload": WORKLOAD_TEXT["config2"] % dict(cols=1024 * 1024, ni=1024, nj=1024) + " (`--workload config2`), sorted on the device, "
+                                   "forcing permutation inside the timed region",
+                       "value": r2.n_adv / dt2, "unit": "column-steps/s", "ms_per_step": dt2 / K2 * 1e3, "steps": K2,
+                       "land_kernel_ms": r2.class_ms[0] / K2, "columns_per_launch": int(r2.n_land / K2),
+                       "roofline_frac": ALG_BYTES_PER_COLSTEP * (r2.n_land / K2) / (r2.class_ms[0] / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "first_forcing_hour": forcing_hour(args.warmup + 1, args.dt)}
+        del r2
         torch.cuda.empty_cache()
         if not args.no_config5_reference:
             # BASELINE configs[4] on one GPU: a short leg of the 30-day spin-up (cold start outside the timed region, reported)
@@ -1246,6 +1284,19 @@ def main():
                            "cold_start_s": r5.cold_start_s}
             del r5
             torch.cuda.empty_cache()
+            # the same leg with spatially smooth forcing factors: how much of config 5's divergence is white noise in the generator
+            a5.config5_smooth = True
+            r5 = Run5(a5, comm, eng, tb, dev)
+            dt5 = timed_leg(r5, args.steps, args.warmup, barrier)
+            config5_smooth_ref = {"workload": "config5_reference with spatially smooth forcing factors (`--workload config5 --config5-smooth`: cloud, humidity, "
+                                              "pressure, wind and rain timing are smooth random fields with a correlation length of a few hundred km "
+                                              "instead of i.i.d. draws per cell; same marginal distributions, same state).  The i.i.d. leg stays the quoted "
+                                              "config-5 number",
+                                  "value": r5.n_adv / dt5, "unit": "column-steps/s", "ms_per_step": dt5 / args.steps * 1e3, "steps": args.steps,
+                                  "columns_advanced_per_step": r5.n_adv // args.steps, "column_kernels_ms_per_step": r5.kernel_ms / args.steps,
+                                  "land_kernel_ms": r5.class_ms[0] / args.steps, "land_ice_kernel_ms": r5.class_ms[1] / args.steps}
+            del r5
+            torch.cuda.empty_cache()
         if not args.no_options_reference:
             options_ref = options_legs(args, comm, eng, tb, dev, barrier, torch)
         if not args.no_host_path_reference:
@@ -1259,7 +1310,7 @@ def main():
         run.sorted, run.lateral, run.tile_cells, run.stepwtd, run.kernel_ms = summary["sorted"], summary["lateral"], summary["tile_cells"], summary["stepwtd"], summary["kernel_ms"]
         run.gw_calls = 0
         run.tsk_bin = summary["tsk_bin"]
-        run.hour_ms, run.hour_ms_warm = summary["hour_ms"], summary["hour_ms_warm"]
+        run.hour_ms, run.hour_ms_warm, run.step_hours = summary["hour_ms"], summary["hour_ms_warm"], summary["step_hours"]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1306,6 +1357,18 @@ def main():
         day = [hours[h] for h in hours if 6 < h < 18] if workload != "config5" else []
         night = [hours[h] for h in hours if not 6 < h < 18] if workload != "config5" else []
         ms_24h = sum(hours.values()) / 24.0 if len(hours) == 24 else None
+        # Round 6: the roofline is quoted from the 24-HOUR-WEIGHTED kernel mean whenever every hour of the cycle was sampled -- a window that is
+        # not a multiple of 24 steps holds day and night steps in another proportion than a day does (--steps 20 --warmup 5: 7 day + 13
+        # night steps = 35 % day, a day has 11 of 24 = 46 %), which moved the headline fraction by 4 % between window lengths.  The raw window
+        # figures stay beside it (window_*); value / ms_per_step are wall-clock figures of the window, value_24h_weighted replaces the
+        # window's kernel mean by the 24-hour one inside the wall-clock step (everything else of a step does not depend on the hour).
+        window_ms, window_achieved = dom_ms, achieved
+        timed_hours = [h for h in getattr(run, "step_hours", [])][-K:] if getattr(run, "step_hours", None) else []
+        n_day = len([h for h in timed_hours if 6 < h < 18])
+        if ms_24h:
+            dom_ms = ms_24h
+            achieved = ALG_BYTES_PER_COLSTEP * dom_cols / (dom_ms * 1e-3) / 1e9
+        ms_step_24h = (dt / K * 1e3 - window_ms + ms_24h) if ms_24h else None
         desc = WORKLOAD_TEXT[workload] % dict(cols=args.ni * args.nj, ni=args.ni, nj=args.nj, dveg=args.dveg, world=world,
                                               stepwtd=run.stepwtd, steps=K)
         if workload == "config5":
@@ -1314,6 +1377,8 @@ def main():
                      if run.sorted else "; tile order")
             if prefetch5:
                 desc += "; the forcing chain (interpolation + preparation) runs three steps ahead on a second stream beside the column kernels (four forcing working sets)"
+            if getattr(args, "config5_smooth", False):
+                desc += "; forcing factors (cloud, humidity, pressure, wind, rain timing) spatially smooth (--config5-smooth) instead of i.i.d. per cell"
             desc += ("; the 3-hourly forcing records of the timed window are resident in HBM when it starts (evaluated before it, as config 3's hourly sets are)"
                      if not args.no_stage_records else "; the synthetic 3-hourly forcing records are evaluated inside the timed region (torch elementwise kernels)")
         elif run.sorted:
@@ -1325,12 +1390,16 @@ def main():
                      "angle costs ~25 %% more per column (config5_reference)"
                      % (run.tsk_bin, "; step n + 1's runs on a second stream beside step n's column kernel, two forcing working sets" if prefetching else "",
                         args.resort_every, args.resort_frac * 100, run.resorts, args.dt))
+            if timed_hours and workload != "config5":
+                desc += ("; the timed window holds %d day + %d night steps (a day of this forcing: 11 + 13); roofline figures are the 24-hour-weighted "
+                         "kernel mean%s" % (n_day, len(timed_hours) - n_day, "" if ms_24h else " -- NOT available here (not every hour sampled): window mean"))
         else:
             desc += "; state resident in HBM, diurnal forcing (spatially uniform zenith angle / short wave / rain), time step %g s" % args.dt
         out = {
             "metric": "column-steps/sec", "value": value, "unit": "column-steps/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "host_enqueue_ms_per_step": t_enqueued / K * 1e3, "higher_is_better": True, "scaling": "strong",
+            "value_24h_weighted": (n_adv_all / K / (ms_step_24h * 1e-3)) if ms_step_24h else None, "ms_per_step_24h_weighted": ms_step_24h,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "grid": [args.ni, args.nj], "columns_per_gpu": run.tile_cells,
                        "parallelism": ("1 GPU" if world == 1 else "%d tiles (mpp_land_partition_calc), one rank per GPU%s"
@@ -1343,6 +1412,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "noahmp_column_kernel (%s)" % ("land range of the sorted layout" if run.sorted else "mixed tile"),
                          "kernel_ms_avg": dom_ms, "columns_per_launch": int(dom_cols),
+                         "weighting": ("24-hour-weighted: mean over the 24 forcing hours of the per-hour kernel means (timed steps; warm-up steps only "
+                                       "for hours the timed window does not reach)") if ms_24h else "mean over the timed window",
+                         "window_kernel_ms_avg": window_ms, "window_achieved": window_achieved, "window_frac": window_achieved / HBM_PEAK_GBS,
+                         "window_day_steps": n_day if timed_hours else None, "window_night_steps": (len(timed_hours) - n_day) if timed_hours else None,
                          "kernel_ms_day": (sum(day) / len(day)) if day else None, "kernel_ms_night": (sum(night) / len(night)) if night else None,
                          "kernel_ms_24h_mean": ms_24h, "hours_sampled": len(hours),
                          "frac_24h_mean": (ALG_BYTES_PER_COLSTEP * dom_cols / (ms_24h * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_24h else None,
@@ -1373,8 +1446,12 @@ def main():
                                   "halo": comm.halo, "halo_note": comm.halo_note}
         if scaling_ref is not None:
             out["scaling_reference"] = scaling_ref
+        if config2_ref is not None:
+            out["config2_reference"] = config2_ref
         if config5_ref is not None:
             out["config5_reference"] = config5_ref
+        if config5_smooth_ref is not None:
+            out["config5_smooth_reference"] = config5_smooth_ref
         if options_ref is not None:
             out["options_reference"] = options_ref
         if host_ref is not None:

@@ -12,7 +12,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libnoahmp_hip.so")
 SOURCES = ["noahmp_engine.hip", "noahmp_groundwater.hip", "noahmp_init.hip", "noahmp_forcing.hip", "noahmp_engine_d1_r1.hip",
            "noahmp_engine_d3_r1.hip", "noahmp_engine_d3_r5.hip", "noahmp_engine_d4_r1.hip", "noahmp_engine_d4_r3.hip",
-           "noahmp_jit.hip", "noahmp_sort.hip", "noahmp_halo.hip"]
+           "noahmp_jit.hip", "noahmp_sort.hip", "noahmp_halo.hip", "noahmp_stage.hip"]
 
 
 def _headers():
@@ -41,21 +41,34 @@ def _stale(target, deps):
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in deps)
 
 
+def _flags_stamp(objdir):
+    p = os.path.join(objdir, "flags.txt")
+    return open(p).read() if os.path.exists(p) else None
+
+
 def needs_build():
-    return _stale(LIB, _sources() + _headers())
+    """The default library is missing, older than a source / header, or was last built with other flags than the default ones (e.g. an
+    NSOIL experiment that overwrote it: every nsoil = 4 call would fail with NOAHMP_ERR_NSOIL_UNSUPPORTED until a forced rebuild)."""
+    return _stale(LIB, _sources() + _headers()) or _flags_stamp(OBJ) != " ".join(FLAGS)
 
 
 def build(force=False, verbose=False, extra_flags=(), lib=None, jobs=None):
     """extra_flags / lib: experiment builds (e.g. -DNMP_TRUNC=3 into another .so); they get their own object directory."""
+    nsoil_env = os.environ.get("NMP_NSOIL")
+    if nsoil_env and lib is None and not any(f.startswith("-DNOAHMP_NSOIL") for f in extra_flags) and int(nsoil_env) != 4:
+        # another layer count is a library of its own (variants/lib_nsoil<n>.so; NMP_LIB=... or Engine(lib_path=...) loads it): the default
+        # library stays the 4-layer build every BASELINE config uses
+        lib = os.path.join(CSRC, "variants", "lib_nsoil%d.so" % int(nsoil_env))
     lib = lib or LIB
-    if not force and not extra_flags and not os.environ.get("NMP_NSOIL") and not needs_build():
+    if not force and not extra_flags and not nsoil_env and not needs_build():
         return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = OBJ if lib == LIB else lib + ".obj"
     os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     flags = FLAGS + list(extra_flags)
-    if os.environ.get("NMP_NSOIL") and not any(f.startswith("-DNOAHMP_NSOIL") for f in flags):
-        flags.append("-DNOAHMP_NSOIL=%d" % int(os.environ["NMP_NSOIL"]))       # soil layers: a build-time choice (include/noahmp_hip.h); default 4
+    if nsoil_env and int(nsoil_env) != 4 and not any(f.startswith("-DNOAHMP_NSOIL") for f in flags):
+        flags.append("-DNOAHMP_NSOIL=%d" % int(nsoil_env))       # soil layers: a build-time choice (include/noahmp_hip.h); default 4
     stamp = os.path.join(objdir, "flags.txt")
     same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
     hdrs = _headers()

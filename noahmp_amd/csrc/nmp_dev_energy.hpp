@@ -409,8 +409,12 @@ NMP_DEV float pspmu(float xx) {
 }
 NMP_DEV float psphu(float xx) { return -2.f * nmp_logf((xx * xx + 1.f) * 0.5f); }
 
+// rlogu_in = LOG((ZLM + Z0) / Z0) (RLOGU, lsm:4336): ZU = Z0 and ZLM are fixed over the caller's iteration loop, so the callers evaluate it once
+// (sfcdif2_rlogu).  Nothing else of the routine is loop-invariant: ZT follows USTAR (lsm:4334, 4395) and XLU / XLT / XU / XT follow RLMO, which every
+// call relaxes (lsm:4417-4420) -- the eight square roots, seven LOGs and two ATANs of the unstable branch are the scheme's own arithmetic.
+NMP_DEV float sfcdif2_rlogu(float z0, float zlm) { return nmp_logf((zlm + z0) / z0); }
 NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, float czil, float zlm,
-                     float& akms, float& akhs, float& rlmo, float& wstar2, float& ustar) {
+                     float& akms, float& akhs, float& rlmo, float& wstar2, float& ustar, const float rlogu_in) {
   const float WWST2 = 1.2f * 1.2f, VKRM = 0.40f, EXCM = 0.001f, BTG = (1.0f / 270.0f) * GRAV,
               ELFC = VKRM * BTG, WOLD = 0.15f, WNEW = 1.0f - WOLD, EPSU2 = 1.E-4f, EPSUST = 0.07f,
               ZTMIN = -5.0f, ZTMAX = 1.0f, HPBL = 1000.0f, SQVISC = 258.2f;
@@ -430,10 +434,11 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
   float zt = nmp_max(1.E-6f, nmp_expf(zilfc * sqrtf(ustar * z0)) * z0);
   float zslu = zlm + zu;
   float zslt = zlm + zt;
-  // RLOGU = LOG(ZSLU / ZU) and RLOGT = LOG(ZSLT / ZT) (lsm:4336-4337) feed only SIMM / SIMH at the end: they join the batch of the branch
-  // that follows (eight independent LOGs in the unstable branch: one round of table look-ups instead of two dependent ones)
-  const float rlu_arg = zslu / zu, rlt_arg = zslt / zt;
-  float rlogu, rlogt;
+  // RLOGT = LOG(ZSLT / ZT) (lsm:4337) feeds only SIMH at the end: it joins the batch of the branch that follows (seven independent LOGs in
+  // the unstable branch: one round of table look-ups instead of two dependent ones)
+  const float rlt_arg = zslt / zt;
+  const float rlogu = rlogu_in;
+  float rlogt;
   float zetalt = nmp_max(zslt * rlmo, ZTMIN);
   rlmo = zetalt / zslt;
   float zetalu = zslu * rlmo;
@@ -445,18 +450,18 @@ NMP_DEV void sfcdif2(int iter, float z0, float thz0, float thlm, float sfcspd, f
           xu = sqrtf(sqrtf(1.f - 16.f * zetau)), xt = sqrtf(sqrtf(1.f - 16.f * zetat));
     // PSPMU(xu), PSPMU(xlu), PSPHU(xt), PSPHU(xlt) (lsm:4290-4299 statement functions): their six LOGs are independent -- one batch of
     // table look-ups instead of six dependent LDS round trips per iteration; the arithmetic of pspmu / psphu is unchanged
-    const float la[8] = {(xu + 1.f) * 0.5f, (xu * xu + 1.f) * 0.5f, (xlu + 1.f) * 0.5f, (xlu * xlu + 1.f) * 0.5f,
-                         (xt * xt + 1.f) * 0.5f, (xlt * xlt + 1.f) * 0.5f, rlu_arg, rlt_arg};
-    float lg[8];
-    nmp_logfN<8>(la, lg);
-    rlogu = lg[6]; rlogt = lg[7];
+    const float la[7] = {(xu + 1.f) * 0.5f, (xu * xu + 1.f) * 0.5f, (xlu + 1.f) * 0.5f, (xlu * xlu + 1.f) * 0.5f,
+                         (xt * xt + 1.f) * 0.5f, (xlt * xlt + 1.f) * 0.5f, rlt_arg};
+    float lg[7];
+    nmp_logfN<7>(la, lg);
+    rlogt = lg[6];
     psmz = -2.f * lg[0] - lg[1] + 2.f * nmp_atanf(xu) - (3.14159265f / 2.f);
     const float pspmu_xlu = -2.f * lg[2] - lg[3] + 2.f * nmp_atanf(xlu) - (3.14159265f / 2.f);
     simm = pspmu_xlu - psmz + rlogu;
     pshz = -2.f * lg[4];
     simh = -2.f * lg[5] - pshz + rlogt;
   } else {
-    { const float la[2] = {rlu_arg, rlt_arg}; float lg[2]; nmp_logfN<2>(la, lg); rlogu = lg[0]; rlogt = lg[1]; }
+    rlogt = nmp_logf(rlt_arg);
     zetalu = nmp_min(zetalu, ZTMAX);
     zetalt = nmp_min(zetalt, ZTMAX);
     psmz = 5.f * zetau;
@@ -588,7 +593,7 @@ struct VegLoop {
   // fixed during the loop
   float sfctmp, rhoair, qair, zlvl, zpd, z0m, ur, z0mg, hcan, cwp, vaie, sqrt_dleaf_uc, fveg, tg, laisune,
         laishae, rssun, rssha, rsurf, eair, estg, gammav, air, cir, canliq, canice, latheav, sav, fwet, sfcprs,
-        thair, czil;
+        thair, czil, rlogu;
   double r_rhocp, r_hcan, r_gammav;     // 1 / (RHOAIR*CPAIR), 1 / HCAN, 1 / GAMMAV: divisors of every iteration (div_rc)
   double r_ur;                          // 1 / UR (OPT_SFC = 2 only)
   // carried from iteration to iteration / read after the loop
@@ -614,7 +619,7 @@ NMP_DEV void vege_iter(const Ctx& c, VegLoop& L, const int iter, VegFirst* f) {
   if (c.O.sfc == 1) {
     sfcdif1(L.err, iter, sfctmp, L.r_rhocp, L.h, L.qair, L.zlvl, L.zpd, L.z0m, ur, MPE, L.mo, L.cm, L.ch);
   } else {
-    sfcdif2(iter, L.z0m, L.tah, L.thair, ur, L.czil, L.zlvl, L.cm, L.ch, L.mo.moz, L.wstar, L.mo.fv);
+    sfcdif2(iter, L.z0m, L.tah, L.thair, ur, L.czil, L.zlvl, L.cm, L.ch, L.mo.moz, L.wstar, L.mo.fv, L.rlogu);
     L.ch = div_rc(L.ch, L.r_ur);                      // CH / UR, CM / UR (lsm:3318-3319): UR is fixed over the loop
     L.cm = div_rc(L.cm, L.r_ur);
   }
@@ -754,7 +759,7 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
     L.mo = MoState{0.f, 0.f, 0.f, 0.f, 0.1f, 0, 0.f, 0.f};
     L.tv = s.tv; L.tg = s.tgv; L.tah = s.tah; L.eah = s.eah; L.ch = s.chv; L.cm = cmv;
     L.r_rhocp = q.r_rhocp; L.r_gammav = q.r_gammav;
-    if (c.O.sfc != 1) L.r_ur = rc64(ur);
+    if (c.O.sfc != 1) { L.r_ur = rc64(ur); L.rlogu = sfcdif2_rlogu(L.z0m, L.zlvl); }
     const double r_fveg = rc64(fveg);
     L.vaie = nmp_min(6.f, div_rc(q.vai, r_fveg));
     L.laisune = nmp_min(6.f, div_rc(q.laisun, r_fveg));
@@ -866,12 +871,13 @@ NMP_DEV void bare_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   t = tdc(tgb);
   esat_sel(t, estg, destg);
   const double r_ur = (c.O.sfc != 1) ? rc64(ur) : 0.0;
+  const float rlogu2 = (c.O.sfc != 1) ? sfcdif2_rlogu(z0m, q.zlvl) : 0.f;       // SFCDIF2's RLOGU: Z0M and ZLVL are fixed over loop3
 #pragma unroll 1
   for (int iter = 1; iter <= 5; iter++) {               // loop3, NITERB = 5 (lsm:3749)
     if (c.O.sfc == 1) {
       sfcdif1(s.err, iter, sfctmp, q.r_rhocp, h, s.qair, q.zlvl, zpdg, z0m, ur, MPE, mo, cm, ch);
     } else {
-      sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv);
+      sfcdif2(iter, z0m, tgb, s.thair, ur, P.czil, q.zlvl, cm, ch, mo.moz, wstar, mo.fv, rlogu2);
       ch = div_rc(ch, r_ur);                         // CH / UR, CM / UR (lsm:3776-3777)
       cm = div_rc(cm, r_ur);
       if (s.snowh > 0.f) { cm = nmp_min(0.01f, cm); ch = nmp_min(0.01f, ch); }

@@ -8,7 +8,8 @@
 //                     UPDATEWTD and the accumulators (gw:186-195), one thread per cell.
 // The split is a correctness requirement, not a convenience: kernel 2 overwrites WTD in place while its
 // neighbours' stencils need the OLD water table, so the old head has to be frozen first (the reference
-// freezes it in the KCELL/HEAD locals for the same reason).
+// freezes it in the KCELL/HEAD locals for the same reason).  The lateral half of the split form (sorted
+// runs: gw_qlat_fused_kernel) writes QLAT into a plane of its own and no WTD, so it keeps KCELL / HEAD in LDS.
 //
 // The four soil layers stay in registers: UPDATEWTD's runtime layer indices (IWTD/KWTD) are resolved by
 // fully unrolled, predicated sweeps instead of dynamically indexed arrays (which would go to scratch).
@@ -30,7 +31,12 @@ struct GwArgs {
   int qi0, qi1, qj0, qj1;          // QLAT rectangle, gw:254-257
   unsigned long long* err;
   int* counts;
-  float* qlat;                     // split form (sorted layout): QLAT plane written by gw_qlat_cell / read by gw_column_t<false>
+  float* qlat;                     // split form (sorted layout): QLAT plane written by gw_qlat_fused_kernel / read by gw_column_t<false>
+  // split form, per-column half on a SORTED store beside a tile-order block (noahmp_hip_wtable_columns_gather_async): cell of column x
+  // inside the block (`qlat` is then that block's plane: the (i,j) -> sorted move is this one indexed load), and the block's ZWTXY plane,
+  // which receives the new water table too (so that no sorted -> (i,j) move precedes the next stencil).  NULL: qlat is in column order.
+  const int* __restrict__ lat_pos;
+  float* zwt_block;
 };
 
 // KLATFACTOR, gw:224-225 (indexed by soil category 1..19)
@@ -237,16 +243,9 @@ NMP_DEV void gw_updatewtd(GwCol& c, const Soil4& smceq, const float* zsoil, cons
 // chain of dependent ones behind the land-mask and regime branches), and nothing is stored until the end,
 // so the compiler never has to order a load behind a possibly aliasing store.
 // the 9-point stencil of LATERALFLOW (gw:259-292) for one cell: QLAT [m] over DELTAT; zero outside the QLAT rectangle (gw:254-257)
-NMP_DEV float gw_qlat_stencil(const GwArgs& g, size_t x, bool inq, float area) {
-  const int ni = g.ni;
-  // outside the QLAT rectangle the offsets collapse onto the cell itself so that the loads stay inside the caller's memory
-  const size_t up = inq ? x + ni : x, dn = inq ? x - ni : x, e = inq ? 1 : 0;
-  const float kc = g.kcell[x], hd = g.head[x];
-  const float k_ul = g.kcell[up - e], k_l = g.kcell[x - e], k_dl = g.kcell[dn - e], k_u = g.kcell[up],
-              k_d = g.kcell[dn], k_ur = g.kcell[up + e], k_r = g.kcell[x + e], k_dr = g.kcell[dn + e];
-  const float h_ul = g.head[up - e], h_l = g.head[x - e], h_dl = g.head[dn - e], h_u = g.head[up],
-              h_d = g.head[dn], h_ur = g.head[up + e], h_r = g.head[x + e], h_dr = g.head[dn + e];
-  if (!inq) return 0.f;
+// the sum of gw:259-292 in the reference's order (ul, l, dl, u, d, ur, r, dr), times FANGLE * DELTAT / AREA
+NMP_DEV float gw_qlat_sum(float kc, float hd, float k_ul, float k_l, float k_dl, float k_u, float k_d, float k_ur, float k_r, float k_dr,
+                          float h_ul, float h_l, float h_dl, float h_u, float h_d, float h_ur, float h_r, float h_dr, float deltat, float area) {
   const float SQRT2 = 1.41421354f;          // SQRT(2.) in float32
   float q = 0.f;
   q = q + (k_ul + kc) * (h_ul - hd) / SQRT2;
@@ -257,21 +256,23 @@ NMP_DEV float gw_qlat_stencil(const GwArgs& g, size_t x, bool inq, float area) {
   q = q + (k_ur + kc) * (h_ur - hd) / SQRT2;
   q = q + (k_r + kc) * (h_r - hd);
   q = q + (k_dr + kc) * (h_dr - hd) / SQRT2;
-  return 0.45508986056f * q * g.deltat / area;                                  // FANGLE, gw:229
+  return 0.45508986056f * q * deltat / area;                                    // FANGLE, gw:229
+}
+NMP_DEV float gw_qlat_stencil(const GwArgs& g, size_t x, bool inq, float area) {
+  const int ni = g.ni;
+  // outside the QLAT rectangle the offsets collapse onto the cell itself so that the loads stay inside the caller's memory
+  const size_t up = inq ? x + ni : x, dn = inq ? x - ni : x, e = inq ? 1 : 0;
+  const float kc = g.kcell[x], hd = g.head[x];
+  const float k_ul = g.kcell[up - e], k_l = g.kcell[x - e], k_dl = g.kcell[dn - e], k_u = g.kcell[up],
+              k_d = g.kcell[dn], k_ur = g.kcell[up + e], k_r = g.kcell[x + e], k_dr = g.kcell[dn + e];
+  const float h_ul = g.head[up - e], h_l = g.head[x - e], h_dl = g.head[dn - e], h_u = g.head[up],
+              h_d = g.head[dn], h_ur = g.head[up + e], h_r = g.head[x + e], h_dr = g.head[dn + e];
+  if (!inq) return 0.f;
+  return gw_qlat_sum(kc, hd, k_ul, k_l, k_dl, k_u, k_d, k_ur, k_r, k_dr, h_ul, h_l, h_dl, h_u, h_d, h_ur, h_r, h_dr, g.deltat, area);
 }
 NMP_DEV bool gw_is_land(const noahmp_wtable_args& a, float xland, float xice, int ivgtyp) {
   return (xland - 1.5f < 0.f) && (xice < a.xice_threshold) && (ivgtyp != a.isice);                // gw:97-101
 }
-// Split form, first half (tile order): QLAT of cell (i, j) into the plane g.qlat -- zero on non-land cells and outside the rectangle
-NMP_DEV void gw_qlat_cell(const GwArgs& g, int i, int j, int gi, int gj) {
-  const noahmp_wtable_args& a = g.a;
-  const size_t x = (size_t)j * g.ni + i;
-  const bool inq = (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1);
-  const bool land = gw_is_land(a, a.xland[x], a.xice[x], a.ivgtyp[x]);
-  const float q = gw_qlat_stencil(g, x, inq, a.area[x]);
-  g.qlat[x] = land ? q : 0.f;
-}
-
 // STENCIL = true: the whole cell update (stencil included; tile order).  false: the per-column half of the split form -- QLAT comes from
 // the plane g.qlat (same column order as the other arrays, any order), nothing else of the call depends on the neighbours.
 template <bool STENCIL>
@@ -297,7 +298,8 @@ NMP_DEV int gw_column_t(const GwArgs& g, int i, int j, int gi, int gj) {
   }
   // stencil operands (whole form) or the QLAT plane (split form)
   const bool inq = STENCIL && (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1);
-  const float qlat_in = STENCIL ? gw_qlat_stencil(g, x, inq, area) : g.qlat[x];
+  const size_t xq = (!STENCIL && g.lat_pos) ? (size_t)g.lat_pos[x] : x;          // the column's cell in the tile-order block
+  const float qlat_in = STENCIL ? gw_qlat_stencil(g, x, inq, area) : g.qlat[xq];
 
   // ---- compute
   const bool land = gw_is_land(a, xland, xice, ivgtyp);
@@ -344,6 +346,7 @@ NMP_DEV int gw_column_t(const GwArgs& g, int i, int j, int gi, int gj) {
       a.sh2oxy[x3 + k * plane] = c.sh2o.v[k];
     }
     a.wtd[x] = c.wtd;
+    if (!STENCIL && g.zwt_block) g.zwt_block[xq] = c.wtd;
     a.smcwtd[x] = c.smcwtd;
     a.qspring[x] = qspring;
   }

@@ -74,6 +74,7 @@ struct Engine {
   int trust_out_mirror = 0;     // do not re-upload OUT arrays after the first call (caller leaves them alone between calls)
   bool out_mirror_valid = false;
   std::vector<const void*> pipe_host;      // the caller's arrays at the last row-chunk call: other arrays = the OUT mirrors say nothing about them
+  int pipe_extents[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // ... and their memory extents (ims ime jms jme kms kme nsoil)
   // resident host path: the device mirrors ARE the state between calls; only IN arrays are uploaded, INOUT / OUT arrays come back
   // on request (noahmp_hip_fetch) unless lazy_download is off
   int resident_state = 0, lazy_download = 0;
@@ -121,6 +122,7 @@ struct LaunchDesc {
   unsigned long long err_base;
   long t_offset, t_first, t_count;
   unsigned char* cost;           // Ctx::cost of this launch (already offset to its first column) or NULL
+  const int* lat_pos; float* lat_zwt;   // KArgs::lat_pos / lat_zwt (noahmp_hip_step_async_mirror) or NULL
 };
 // mode: 0 mixed tile, 1 land-only range, 2 land-ice-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
 void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);

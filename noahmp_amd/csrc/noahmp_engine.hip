@@ -14,6 +14,7 @@
 #include "noahmp_hip.h"
 #define NMP_WIDE_INDEX 1     // this unit's kernels (run-time options; land ice; skipped cells) address arrays of any size (nmp_dev_column.hpp)
 #include "nmp_kernel.hpp"
+#include "nmp_stage.hpp"
 
 using namespace nmp;
 
@@ -107,15 +108,6 @@ void launch(const KArgs& k, long ncol, bool lds, hipStream_t st) {
 
 }  // namespace
 
-// Before the process makes its first HIP call (a Fortran / C host: that call is the engine's): keep the HIP runtime from page-locking
-// pageable host buffers IN PLACE.  It does so for every copy of ~2 MiB and more (GPU_PINNED_MIN_XFER_SIZE; measured: tools/micro/
-// pageable_copy.py) and caches the mapping; on the ROCm 7.0 runtime such cached mappings of heap memory that has since been freed and
-// reused fault in a later copy ("Memory access fault by GPU ... Write access to a read-only page" on a host heap address: 7 of 10 runs of the
-// GPU test suite, 0 of 16 with the threshold out of reach -- profiles/r05_experiments.md section 3).  Copies of pageable memory then go
-// through the runtime's staging buffers (~25 instead of ~48 GB/s up: callers that care page-lock their arrays, "pin_host_arrays", as the
-// Fortran shim does).  An explicit setting of the variable in the environment wins; a process whose HIP runtime is already up is not affected.
-__attribute__((constructor)) static void nmp_runtime_env() { setenv("GPU_PINNED_MIN_XFER_SIZE", "1048576", 0); }
-
 extern "C" {
 
 int noahmp_hip_abi_version(void) { return NOAHMP_HIP_ABI_VERSION; }
@@ -146,8 +138,12 @@ void* noahmp_hip_malloc(size_t bytes) {
 int noahmp_hip_memcpy(void* dst, const void* src, size_t bytes, int kind) {
   int rc = ensure_init();
   if (rc) return rc;
-  const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, k));
+  if (!bytes) return 0;
+  if (kind == 2) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice)); return 0; }
+  // host memory of the caller: through the engine's staging unless it is page-locked (nmp_stage.hpp)
+  rc = kind == 0 ? nmp_host::copy_h2d(dst, src, bytes, g.own_stream) : nmp_host::copy_d2h(dst, src, bytes, g.own_stream);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(g.own_stream));
   return 0;
 }
 void noahmp_hip_free(void* p) { if (p) hipFree(p); }
@@ -165,6 +161,7 @@ int noahmp_hip_set_tables(const noahmp_tables* t) {
   int rc = ensure_init();
   if (rc) return rc;
   drop_host_regs();           // a new set of tables = a new run of the caller: nothing known about its arrays carries over
+  g.out_mirror_valid = false;
   // the ABI struct followed by the per-type constants derived from it (Derived, nmp_dev_common.hpp), evaluated here on the host
   static nmp::TablesDev img;
   img.t = *t;
@@ -189,9 +186,9 @@ int noahmp_hip_set_option(const char* key, int value) {
   int prev = -1;
   if (!strcmp(key, "block")) { prev = g.block; if (value == 64 || value == 128 || value == 256) g.block = value; }
   else if (!strcmp(key, "lds")) { prev = g.use_lds; g.use_lds = value ? 1 : 0; }
-  else if (!strcmp(key, "host_chunks")) {        // -1: the engine picks by tile size (the default, and what a query returns then)
-    prev = g.host_chunks_auto ? -1 : g.host_chunks;
-    if (value == -1) g.host_chunks_auto = true;
+  else if (!strcmp(key, "host_chunks")) {        // -2 (or -1): the engine picks by tile size (the default); a query then returns -2 -- not -1, which means "unknown option"
+    prev = g.host_chunks_auto ? -2 : g.host_chunks;
+    if (value == -1 || value == -2) g.host_chunks_auto = true;
     else if (value >= 0 && value <= 32) { g.host_chunks = value; g.host_chunks_auto = false; }
   }
   else if (!strcmp(key, "pin_host_arrays")) {
@@ -232,7 +229,15 @@ int noahmp_hip_set_option(const char* key, int value) {
     }
   }
   else if (!strcmp(key, "overlap_class_kernels")) { prev = g.overlap_class_kernels; if (value == 0 || value == 1) g.overlap_class_kernels = value; }
-  else if (!strcmp(key, "static_inputs")) { prev = g.static_inputs; if (value == 0 || value == 1) g.static_inputs = value; }
+  else if (!strcmp(key, "static_inputs")) {
+    prev = g.static_inputs;
+    if ((value == 0 || value == 1) && value != g.static_inputs) {
+      // the declaration decides which IN arrays travel per call and whether the sorted set may exist (XLAND / XICE / IVGTYP place a
+      // column in its class range): bring the host arrays up to date and rebuild both mirror sets at the next call
+      if (g.resident_dirty || g.deferred_pending) note_fetch(noahmp_hip_fetch(nullptr));
+      g.static_inputs = value; g.sorted_ok = false; g.sorted_newer = false; g.resident_valid = false;
+    }
+  }
   else if (!strcmp(key, "deferred_status")) {
     prev = g.deferred_status;
     if (value == 0 || value == 1) {
@@ -317,6 +322,7 @@ static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
   d.ni = k.ni; d.nka = k.nka; d.nti = k.nti; d.ntj = k.ntj; d.k1 = k.k1; d.kp_lo = k.kp_lo; d.kp_hi = k.kp_hi; d.yearlen = k.yearlen;
   d.err = k.err; d.counts = k.counts; d.err_base = k.err_base; d.t_offset = k.t_offset; d.t_first = k.t_first; d.t_count = k.t_count;
   d.cost = k.c.cost;
+  d.lat_pos = k.lat_pos; d.lat_zwt = k.lat_zwt;
   if (level > 0) { kFixed[level - 1].launch(d, mode, s); return true; }
   const Opt& o = k.c.O;
   const int opts[12] = {o.dveg, o.crs, o.btr, o.run, o.sfc, o.frz, o.inf, o.rad, o.alb, o.snf, o.tbot, o.stc};
@@ -465,6 +471,10 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
   const int nchunk = (int)rows.size() - 1;
   while ((int)g.pipe_events.size() < 3 * nchunk) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); g.pipe_events.push_back(e); }
   if (g.pipe_host.size() != (size_t)kNumFields) { g.pipe_host.assign(kNumFields, nullptr); g.out_mirror_valid = false; }
+  {                                              // ... and about their extents: another memory shape = another layout of the mirrors
+    const int ext[9] = {a->ims, a->ime, a->jms, a->jme, a->kms, a->kme, a->nsoil, 0, 0};
+    if (memcmp(ext, g.pipe_extents, sizeof ext)) { memcpy(g.pipe_extents, ext, sizeof ext); g.out_mirror_valid = false; }
+  }
   for (int f = 0; f < kNumFields; f++) {       // "trust_out_mirror" speaks about the arrays of the previous call only
     const void* host = *(void* const*)((const char*)a + kFields[f].off);
     if (g.pipe_host[f] != host) { g.pipe_host[f] = host; g.out_mirror_valid = false; }
@@ -481,7 +491,6 @@ static int step_host_pipelined(const noahmp_step_args* a, hipStream_t s, noahmp_
       g.mirror_bytes[f] = bytes;
       g.out_mirror_valid = false;
     }
-    maybe_pin(*(void* const*)((const char*)a + fd.off), bytes);
     *(void**)((char*)&k.a + fd.off) = g.mirror[f];
   }
   const bool up_out = upload_out || !g.out_mirror_valid;
@@ -591,7 +600,8 @@ static int nlev_of(const FieldDesc& fd, const noahmp_step_args* a) {
 }
 // (and "static_inputs": XLAND / XICE / IVGTYP decide a column's class range; a caller that may rewrite them between calls keeps tile order)
 static bool resident_sorted_possible(const noahmp_step_args* a) {      // the column sort needs memory block == tile, 32-bit offsets
-  return g.resident_sorted && g.static_inputs && a->ims == a->its && a->ime == a->ite && a->jms == a->jts && a->jme == a->jte &&
+  // (kms == 1: the incremental exchange of level-1-only forcing arrays moves memory level 0, which is level 1 only then)
+  return g.resident_sorted && g.static_inputs && a->kms == 1 && a->ims == a->its && a->ime == a->ite && a->jms == a->jts && a->jme == a->jte &&
          (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) > 0 && (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) < 0x7FFFFFFFL &&
          a->jme - a->jms + 1 <= 65535;
 }
@@ -703,6 +713,7 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
   hipStream_t up = defer ? g.s_up : s;
   const bool second = defer && (g.resident_calls & 1);
   const size_t ni = a->ime - a->ims + 1, nj = a->jme - a->jms + 1, nka = a->kme - a->kms + 1;
+  std::vector<nmp_host::CopySeg> up_segs;
   for (int f = 0; f < kNumFields; f++) {
     const FieldDesc& fd = kFields[f];
     const size_t bytes = field_elems(fd, a) * 4;
@@ -712,16 +723,17 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
     // static IN arrays and the state live in `mirror`; the IN arrays that change per call alternate between the two buffers
     void* target = (second && fd.io == 0 && !(g.static_inputs && stat)) ? g.mirror_b[f] : g.mirror[f];
     if (!valid || (fd.io == 0 && !(g.static_inputs && stat))) {
-      if (valid && fd.lev == 1 && nka > 1 && level1_only(fd)) {            // only the level the kernel reads
+      if (valid && fd.lev == 1 && nka > 1 && level1_only(fd) && nmp_host::host_page_locked(host, bytes)) {   // only the level the kernel reads
         const size_t off = (size_t)k.k1 * ni * 4;
         HIPCHK(hipMemcpy2DAsync((char*)target + off, nka * ni * 4, (const char*)host + off, nka * ni * 4, ni * 4, nj, hipMemcpyHostToDevice, up));
       } else {
-        HIPCHK(hipMemcpyAsync(target, host, bytes, hipMemcpyHostToDevice, up));
+        up_segs.push_back(nmp_host::CopySeg{host, target, bytes});        // page-locked: direct; pageable: the engine's bounce buffers
       }
     }
     g.mirror_host[f] = host;
     *(void**)((char*)&k.a + fd.off) = target;
   }
+  if (!up_segs.empty()) { int rc = nmp_host::copy_segments(up_segs.data(), (int)up_segs.size(), true, up); if (rc) return rc; }
   g.out_mirror_valid = false;
   int prev_code = 0;
   if (defer) {
@@ -759,6 +771,11 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
       }
     }
     for (int f = 0; f < kNumFields; f++) *(void**)((char*)&k.a + kFields[f].off) = g.smirror[f];
+  } else if (g.sorted_ok) {
+    // a call the sorted set cannot serve (a sub-tile of the same arrays, other extents): this kernel runs on the tile-order mirrors, so
+    // they must hold the newest state first, and the sorted set is dropped -- it would be stale from here on (state AND static inputs)
+    if (valid && g.sorted_newer) { int rc = sorted_to_tile(&g.resident_args, s); if (rc) return rc; }
+    g.sorted_ok = false; g.sorted_newer = false;
   }
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
@@ -788,11 +805,14 @@ static int step_host_resident(const noahmp_step_args* a, hipStream_t s, noahmp_s
   }
   if (!g.lazy_download) {
     if (run_sorted) { int rc = sorted_to_tile(a, s); if (rc) return rc; }
+    std::vector<nmp_host::CopySeg> down;
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
-      HIPCHK(hipMemcpyAsync(*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+      down.push_back(nmp_host::CopySeg{*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4});
     }
+    int rc = nmp_host::copy_segments(down.data(), (int)down.size(), false, s);
+    if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(s));
   int code = 0;
@@ -823,10 +843,15 @@ int noahmp_hip_fetch(const noahmp_step_args* a) {
       }
   if (!g.resident_dirty) return take_deferred_code(pending_code);
   if (g.sorted_ok && g.sorted_newer) { rc = sorted_to_tile(r, g.own_stream); if (rc) return rc; }    // "resident_sorted": results back to tile order
-  for (int f = 0; f < kNumFields; f++) {
-    const FieldDesc& fd = kFields[f];
-    if (fd.io == 0) continue;
-    HIPCHK(hipMemcpyAsync(const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4, hipMemcpyDeviceToHost, g.own_stream));
+  {
+    std::vector<nmp_host::CopySeg> down;
+    for (int f = 0; f < kNumFields; f++) {
+      const FieldDesc& fd = kFields[f];
+      if (fd.io == 0) continue;
+      down.push_back(nmp_host::CopySeg{const_cast<void*>(g.mirror_host[f]), g.mirror[f], field_elems(fd, r) * 4});
+    }
+    rc = nmp_host::copy_segments(down.data(), (int)down.size(), false, g.own_stream);
+    if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(g.own_stream));
   g.resident_dirty = false;
@@ -848,8 +873,21 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
     if (rc > 0) { if (st) st->code = rc; g.last_error = "a fatal column of the previous (deferred) step"; return rc; }   // never drop a pending fatal
   }
   if (mem == NOAHMP_MEM_HOST) g.resident_valid = false;
-  // the row-chunk pipeline only pays with pinned arrays (pageable asynchronous copies are staged and serialise)
-  if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && pipeline_chunks(a) > 1 &&
+  // "pin_host_arrays": page-lock what shows up a second time; the row-chunk pipeline needs EVERY array page-locked (its copies are
+  // asynchronous DMAs out of / into the caller's memory) -- until then, and for pageable callers, the single-shot path below stages
+  // through the engine's own bounce buffers (nmp_stage.hpp)
+  bool all_locked = false;
+  if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays) {
+    all_locked = true;
+    for (int f = 0; f < kNumFields; f++) {
+      const void* host = *(void* const*)((const char*)a + kFields[f].off);
+      const size_t bytes = field_elems(kFields[f], a) * 4;
+      maybe_pin(host, bytes);
+      auto it = g.host_regs.find(host);
+      if (bytes && !(it != g.host_regs.end() && it->second.state == 1)) all_locked = false;
+    }
+  }
+  if (mem == NOAHMP_MEM_HOST && g.pin_host_arrays && all_locked && pipeline_chunks(a) > 1 &&
       (long)(a->ite - a->its + 1) * (a->jte - a->jts + 1) >= 32768 &&
       a->jme - a->jms + 1 >= 2 * pipeline_chunks(a))
     return step_host_pipelined(a, s, st);
@@ -859,7 +897,9 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
 
   if (mem == NOAHMP_MEM_HOST) {
     g.out_mirror_valid = false;
-    // stage every array H2D into persistent device mirrors (caller's arrays stay the source of truth)
+    // stage every array H2D into persistent device mirrors (caller's arrays stay the source of truth); pageable arrays travel through
+    // the engine's own page-locked bounce buffers (nmp_stage.hpp), never through the runtime's pageable path
+    std::vector<nmp_host::CopySeg> up;
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       size_t bytes = field_elems(fd, a) * 4;
@@ -869,13 +909,14 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
         g.mirror_bytes[f] = bytes;
       }
       void* host = *(void* const*)((const char*)a + fd.off);
-      maybe_pin(host, bytes);
       // OUT arrays are uploaded too: columns the call does not touch (open water, sea ice, cells
       // outside its:ite/jts:jte, a column that raised a fatal) must come back unchanged, exactly
       // as the reference leaves them.
-      HIPCHK(hipMemcpyAsync(g.mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      up.push_back(nmp_host::CopySeg{host, g.mirror[f], bytes});
       *(void**)((char*)&k.a + fd.off) = g.mirror[f];
     }
+    rc = nmp_host::copy_segments(up.data(), (int)up.size(), true, s);
+    if (rc) return rc;
   }
 
   *g.h_err = ~0ULL;
@@ -890,12 +931,14 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, kCountSlots * kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
 
   if (mem == NOAHMP_MEM_HOST) {
+    std::vector<nmp_host::CopySeg> down;
     for (int f = 0; f < kNumFields; f++) {
       const FieldDesc& fd = kFields[f];
       if (fd.io == 0) continue;
-      void* host = *(void* const*)((const char*)a + fd.off);
-      HIPCHK(hipMemcpyAsync(host, g.mirror[f], field_elems(fd, a) * 4, hipMemcpyDeviceToHost, s));
+      down.push_back(nmp_host::CopySeg{*(void* const*)((const char*)a + fd.off), g.mirror[f], field_elems(fd, a) * 4});
     }
+    rc = nmp_host::copy_segments(down.data(), (int)down.size(), false, s);
+    if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(s));
   float ms = 0.f;
@@ -916,7 +959,14 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
 // ---- asynchronous stepping for device-resident state: enqueue and return.  Fatal columns and tallies
 // accumulate on the device until noahmp_hip_sync(); the error word carries the step ordinal above the column index,
 // so the earliest step wins, then the first column in loop order -- the column the reference would have STOPped at.
-int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
+int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) { return noahmp_hip_step_async_mirror(a, stream, nullptr, nullptr); }
+
+// The same step for a SORTED OPT_RUN = 5 run whose LATERALFLOW planes live in a tile-order block beside the sorted store: every column the
+// step advances also stores its ZWTXY at cell block_pos[column] of zwt_block (block_pos: shaped like the store's 2-D arrays,
+// noahmp_hip_sorted_block_positions), so that the stencil of the next WTABLE_mmf_noahmp finds the water table in (i,j) order without a
+// permutation launch in between (cells the step does not advance -- open water, sea ice -- keep what the block holds).  Both NULL: plain step.
+int noahmp_hip_step_async_mirror(const noahmp_step_args* a, void* stream, const int32_t* block_pos, float* zwt_block) {
+  if ((block_pos == nullptr) != (zwt_block == nullptr)) { g.last_error = "noahmp_hip_step_async_mirror: block_pos and zwt_block go together"; return -105; }
   int rc = ensure_init();
   if (rc) return rc;
   rc = check_step_args(a, nullptr);
@@ -941,6 +991,7 @@ int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
     }
   }
   k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
+  k.lat_pos = block_pos; k.lat_zwt = zwt_block;
   // three events per step (launch_any): kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
   // else the caller puts on the stream between them
   while ((int)g.async_events.size() < 3 * (g.async_pending + 1)) {
@@ -1148,6 +1199,7 @@ void noahmp_hip_finalize(void) {
   for (auto e : g.async_events) hipEventDestroy(e);
   for (auto e : g.pipe_events) hipEventDestroy(e);
   drop_host_regs();
+  nmp_host::stage_finalize();
   if (g.s_up) hipStreamDestroy(g.s_up);
   if (g.s_dn) hipStreamDestroy(g.s_dn);
   if (g.gw_kcell) hipFree(g.gw_kcell);

@@ -14,6 +14,8 @@
 #include "noahmp_hip.h"
 #include "nmp_dev_groundwater.hpp"
 #include "nmp_engine_host.hpp"
+#include "nmp_stage.hpp"
+#include <vector>
 
 using namespace nmp;
 using nmp_host::g;
@@ -52,11 +54,46 @@ __global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
   }
 }
 
-// split form, first half: the QLAT stencil over the tile into the plane k.qlat (tile order)
-__global__ void __launch_bounds__(BX * BY) gw_qlat_kernel(const GwArgs k) {
-  const int gi = k.a.its + blockIdx.x * BX + threadIdx.x;
-  const int gj = k.a.jts + blockIdx.y * BY + threadIdx.y;
-  if (gi <= k.a.ite && gj <= k.a.jte) gw_qlat_cell(k, gi - k.a.ims, gj - k.a.jms, gi, gj);
+// Split form, first half: KCELL / HEAD and the QLAT stencil over the tile into the plane k.qlat (tile order), ONE launch.  The lateral half
+// never writes WTD, so the old head need not be frozen in HBM planes first (the whole-call form below must: gw_head_kernel): a workgroup
+// evaluates KCELL / HEAD (gw:237-252) of its BX x QY cells plus their 1-cell ring into LDS -- (BX+2)(QY+2) / (BX QY) = 1.29 evaluations
+// per cell instead of one, but no 8 B / cell written and 72 B / cell read back through the caches, and one launch less per call (round 6:
+// at the 1152 x 768 tile of an 8-rank run the two launches took 12.4 + 9.6 us, the fused one NN us).  Same gw_cell_head_values, same
+// sum order (gw_qlat_sum): same bits.
+constexpr int QY = 2 * BY;
+__global__ void __launch_bounds__(BX * BY) gw_qlat_fused_kernel(const GwArgs k) {
+  libm::libm_stage_tables();
+  constexpr int LX = BX + 2, LY = QY + 2;
+  __shared__ float s_kc[LY * LX], s_hd[LY * LX];
+  const int gi0 = k.a.its + blockIdx.x * BX - 1, gj0 = k.a.jts + blockIdx.y * QY - 1;      // Fortran indices of the LDS tile's first cell
+  const int tid = threadIdx.y * BX + threadIdx.x;
+  for (int c = tid; c < LY * LX; c += BX * BY) {
+    const int lj = c / LX, li = c - lj * LX;
+    const int gi = gi0 + li, gj = gj0 + lj;
+    float kc = 0.f, hd = 0.f;
+    if (gi >= k.hi0 && gi <= k.hi1 && gj >= k.hj0 && gj <= k.hj1) {                      // the KCELL / HEAD rectangle, gw:231-234
+      const size_t x = (size_t)(gj - k.a.jms) * k.ni + (gi - k.a.ims);
+      gw_cell_head_values(k, k.a.fdepth[x], k.a.wtd[x], k.a.topo[x], k.a.isltyp[x], kc, hd);
+    }
+    s_kc[c] = kc; s_hd[c] = hd;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < QY / BY; r++) {
+    const int li = threadIdx.x + 1, lj = threadIdx.y + r * BY + 1;
+    const int gi = gi0 + li, gj = gj0 + lj;
+    if (gi > k.a.ite || gj > k.a.jte) continue;
+    const size_t x = (size_t)(gj - k.a.jms) * k.ni + (gi - k.a.ims);
+    const bool inq = (gi >= k.qi0 && gi <= k.qi1 && gj >= k.qj0 && gj <= k.qj1);         // the QLAT rectangle, gw:254-257
+    const bool land = gw_is_land(k.a, k.a.xland[x], k.a.xice[x], k.a.ivgtyp[x]);
+    float q = 0.f;
+    if (inq && land) {
+      const int c = lj * LX + li, up = c + LX, dn = c - LX;
+      q = gw_qlat_sum(s_kc[c], s_hd[c], s_kc[up - 1], s_kc[c - 1], s_kc[dn - 1], s_kc[up], s_kc[dn], s_kc[up + 1], s_kc[c + 1], s_kc[dn + 1],
+                      s_hd[up - 1], s_hd[c - 1], s_hd[dn - 1], s_hd[up], s_hd[dn], s_hd[up + 1], s_hd[c + 1], s_hd[dn + 1], k.deltat, k.a.area[x]);
+    }
+    k.qlat[x] = q;
+  }
 }
 
 // stencil + per-cell update over the tile (gw:105-195); STENCIL = false: the per-column half of the split form (any column order)
@@ -104,7 +141,7 @@ size_t noahmp_hip_sizeof_wtable_args(void) { return sizeof(noahmp_wtable_args); 
 // part: 0 = the whole WTABLE_mmf_noahmp; 1 = KCELL / HEAD + the QLAT stencil into `qlat` (tile order); 2 = the per-column half with
 // QLAT read from `qlat` (the block may hold the columns in any order)
 static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only = false,
-                   int part = 0, float* qlat = nullptr);
+                   int part = 0, float* qlat = nullptr, const int32_t* lat_pos = nullptr, float* zwt_block = nullptr);
 
 int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, false, 0);
@@ -130,6 +167,16 @@ int noahmp_hip_wtable_columns_async(const noahmp_wtable_args* a, const float* ql
   if (!qlat) { g.last_error = "noahmp_hip_wtable_columns_async: qlat is required"; return -105; }
   return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true, 2, const_cast<float*>(qlat));
 }
+// The per-column half on a SORTED store that sits beside the tile-order block of the lateral half: `qlat_block` is the plane
+// noahmp_hip_wtable_lateral_async wrote (tile order, shaped like that block), block_pos[x] = cell of the store's column x inside the block
+// (noahmp_hip_sorted_block_positions) -- QLAT's way into the sorted order is one indexed load per column instead of a permutation launch --
+// and zwt_block (may be NULL) = the block's ZWTXY plane, which receives every land column's new water table beside the store's own
+// (with noahmp_hip_step_async_mirror: the block's ZWTXY is always current, no sorted -> (i,j) move before the next stencil).
+int noahmp_hip_wtable_columns_gather_async(const noahmp_wtable_args* a, const float* qlat_block, const int32_t* block_pos, float* zwt_block,
+                                           void* stream) {
+  if (!qlat_block || !block_pos) { g.last_error = "noahmp_hip_wtable_columns_gather_async: qlat_block and block_pos are required"; return -105; }
+  return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true, 2, const_cast<float*>(qlat_block), block_pos, zwt_block);
+}
 
 int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, true, iswater);
@@ -138,7 +185,7 @@ int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int me
 }  // extern "C"
 
 static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only,
-                   int part, float* qlat) {
+                   int part, float* qlat, const int32_t* lat_pos, float* zwt_block) {
   if (st) memset(st, 0, sizeof(*st));
   int rc = nmp_host::ensure_init();
   if (rc) return rc;
@@ -168,13 +215,15 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     k.hi0 = k.qi0 = a->its; k.hi1 = k.qi1 = a->ite; k.hj0 = k.qj0 = a->jts; k.hj1 = k.qj1 = a->jte;
   }
   k.qlat = qlat;
+  k.lat_pos = lat_pos;
+  k.zwt_block = zwt_block;
   if (k.hi0 < a->ims || k.hi1 > a->ime || k.hj0 < a->jms || k.hj1 > a->jme ||
       a->its < a->ims || a->ite > a->ime || a->jts < a->jms || a->jte > a->jme) {
     g.last_error = "noahmp_hip_wtable_mmf: memory dims (ims:ime,jms:jme) do not hold the tile plus its 1-cell ring";
     return -103;
   }
   const size_t plane = (size_t)k.ni * nj * sizeof(float);
-  {
+  if (part == 0) {                   // the KCELL / HEAD planes of the whole-call form (the lateral half keeps them in LDS)
     size_t have = g.gw_plane_bytes;
     rc = nmp_host::ensure_bytes((void**)&g.gw_kcell, &have, plane);
     if (rc) return rc;
@@ -198,14 +247,15 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     if (g.resident_dirty) { rc = noahmp_hip_fetch(nullptr); if (rc) return rc; }
     g.resident_valid = false;
     if (g.gw_mirror.empty()) { g.gw_mirror.assign(kNW, nullptr); g.gw_mirror_bytes.assign(kNW, 0); }
+    std::vector<nmp_host::CopySeg> up;
     for (int f = 0; f < kNW; f++) {
       const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);
       rc = nmp_host::ensure_bytes(&g.gw_mirror[f], &g.gw_mirror_bytes[f], bytes);
       if (rc) return rc;
-      void* host = *(void* const*)((const char*)a + kW[f].off);
-      HIPCHK(hipMemcpyAsync(g.gw_mirror[f], host, bytes, hipMemcpyHostToDevice, s));
+      up.push_back(nmp_host::CopySeg{*(void* const*)((const char*)a + kW[f].off), g.gw_mirror[f], bytes});
       *(void**)((char*)&k.a + kW[f].off) = g.gw_mirror[f];
     }
+    if ((rc = nmp_host::copy_segments(up.data(), (int)up.size(), true, s))) return rc;       // pageable arrays: the engine's bounce buffers
   }
 
   const int hni = k.hi1 - k.hi0 + 1, hnj = k.hj1 - k.hj0 + 1;
@@ -213,7 +263,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   const bool timed = !enqueue_only && tni > 0 && tnj > 0;       // an empty tile: no kernel, no events
   if (!enqueue_only) HIPCHK(hipMemsetAsync(g.d_counts, 0, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), s));
   if (timed) HIPCHK(hipEventRecord(g.ev0, s));
-  if (hni > 0 && hnj > 0 && part != 2)
+  if (hni > 0 && hnj > 0 && part == 0)
     hipLaunchKernelGGL(gw_head_kernel, dim3((hni + BX * HEAD_ILP - 1) / (BX * HEAD_ILP), (hnj + BY - 1) / BY), dim3(BX, BY), 0, s, k);
   if (init) {
     const int itf = imin(a->ite, a->ide - 1), jtf = imin(a->jte, a->jde - 1);
@@ -223,7 +273,7 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
                          iswater);
   } else if (tni > 0 && tnj > 0) {
     const dim3 grid((tni + BX - 1) / BX, (tnj + BY - 1) / BY), block(BX, BY);
-    if (part == 1) hipLaunchKernelGGL(gw_qlat_kernel, grid, block, 0, s, k);
+    if (part == 1) hipLaunchKernelGGL(gw_qlat_fused_kernel, dim3((tni + BX - 1) / BX, (tnj + QY - 1) / QY), block, 0, s, k);
     else if (part == 2) hipLaunchKernelGGL(gw_column_kernel<false>, grid, block, 0, s, k);
     else hipLaunchKernelGGL(gw_column_kernel<true>, grid, block, 0, s, k);
   }
@@ -232,12 +282,13 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
   if (timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_counts, g.d_counts, nmp_host::kCountSlots * nmp_host::kCountStride * sizeof(int), hipMemcpyDeviceToHost, s));
   if (mem == NOAHMP_MEM_HOST) {
+    std::vector<nmp_host::CopySeg> down;
     for (int f = 0; f < kNW; f++) {
       if (kW[f].io == 0 && !(init && !strcmp(kW[f].name, "smoiseq"))) continue;   // GROUNDWATER_INIT writes SMOISEQ
       const size_t bytes = plane * (kW[f].lev == 2 ? a->nsoil : 1);
-      void* host = *(void* const*)((const char*)a + kW[f].off);
-      HIPCHK(hipMemcpyAsync(host, g.gw_mirror[f], bytes, hipMemcpyDeviceToHost, s));
+      down.push_back(nmp_host::CopySeg{*(void* const*)((const char*)a + kW[f].off), g.gw_mirror[f], bytes});
     }
+    if ((rc = nmp_host::copy_segments(down.data(), (int)down.size(), false, s))) return rc;
   }
   HIPCHK(hipStreamSynchronize(s));
   if (st) {

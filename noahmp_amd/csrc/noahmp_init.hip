@@ -8,6 +8,7 @@
 #include "noahmp_hip.h"
 #include "nmp_dev_init.hpp"
 #include "nmp_engine_host.hpp"
+#include "nmp_stage.hpp"
 
 using namespace nmp;
 using nmp_host::g;
@@ -66,15 +67,16 @@ extern "C" int noahmp_hip_init(const noahmp_step_args* a, int iswater, int fndsn
   std::vector<void*>& mir = g.init_mirror;
   if (mem == NOAHMP_MEM_HOST) {
     if (mir.empty()) { mir.assign(kNI, nullptr); g.init_mirror_bytes.assign(kNI, 0); }
+    std::vector<nmp_host::CopySeg> up;
     for (int f = 0; f < kNI; f++) {
       const size_t nk = kI[f].lev == 2 ? NOAHMP_NSOIL : kI[f].lev == 3 ? 3 : kI[f].lev == 4 ? NOAHMP_NSOIL + 3 : 1;
       const size_t bytes = (size_t)k.ni * nj * nk * 4;
       rc = nmp_host::ensure_bytes(&mir[f], &g.init_mirror_bytes[f], bytes);
       if (rc) return rc;
-      void* host = *(void* const*)((const char*)a + kI[f].off);
-      HIPCHK(hipMemcpyAsync(mir[f], host, bytes, hipMemcpyHostToDevice, s));      // outputs too: untouched cells survive
+      up.push_back(nmp_host::CopySeg{*(void* const*)((const char*)a + kI[f].off), mir[f], bytes});      // outputs too: untouched cells survive
       *(void**)((char*)&k.a + kI[f].off) = mir[f];
     }
+    if ((rc = nmp_host::copy_segments(up.data(), (int)up.size(), true, s))) return rc;        // pageable arrays: the engine's bounce buffers (nmp_stage.hpp)
   }
   *g.h_err = ~0ULL;
   HIPCHK(hipMemsetAsync(g.d_err, 0xFF, sizeof(unsigned long long), s));
@@ -88,12 +90,13 @@ extern "C" int noahmp_hip_init(const noahmp_step_args* a, int iswater, int fndsn
   if (timed) HIPCHK(hipEventRecord(g.ev1, s));
   HIPCHK(hipMemcpyAsync(g.h_err, g.d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   if (mem == NOAHMP_MEM_HOST) {
+    std::vector<nmp_host::CopySeg> down;
     for (int f = 0; f < kNI; f++) {
       if (!kI[f].out) continue;
       const size_t nk = kI[f].lev == 2 ? NOAHMP_NSOIL : kI[f].lev == 3 ? 3 : kI[f].lev == 4 ? NOAHMP_NSOIL + 3 : 1;
-      void* host = *(void* const*)((const char*)a + kI[f].off);
-      HIPCHK(hipMemcpyAsync(host, mir[f], (size_t)k.ni * nj * nk * 4, hipMemcpyDeviceToHost, s));
+      down.push_back(nmp_host::CopySeg{*(void* const*)((const char*)a + kI[f].off), mir[f], (size_t)k.ni * nj * nk * 4});
     }
+    if ((rc = nmp_host::copy_segments(down.data(), (int)down.size(), false, s))) return rc;
   }
   HIPCHK(hipStreamSynchronize(s));
   int code = 0;

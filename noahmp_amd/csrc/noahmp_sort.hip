@@ -24,6 +24,7 @@ struct KeyArgs {
   float xice_thres, inv_bin;
   int isice, flags;
   long n;
+  unsigned char veg_rank[64];                                 // vegetation category -> its place in the key (noahmp_hip_sort_set_veg_order)
 };
 
 // key = class(2) | vegetation type and snow-layer count (8, in the order the flags ask for) | band(5) | cost(4) | tsk bin(8): class 0 land,
@@ -43,7 +44,7 @@ __device__ __forceinline__ unsigned column_key(const KeyArgs& k, long p) {
   const unsigned cls = ((xland - 1.5f) >= 0.f || xice >= k.xice_thres) ? 2u : (ivg == k.isice ? 1u : 0u);
   if (cls == 2u) return 2u << kClsShift;
   unsigned veg = 0, sn = 0, tb = 0, band = 0, cost = 0;
-  if (cls == 0u && (k.flags & NOAHMP_SORT_VEG)) veg = (unsigned)min(max(ivg, 0), 63);
+  if (cls == 0u && (k.flags & NOAHMP_SORT_VEG)) veg = k.veg_rank[min(max(ivg, 0), 63)];
   if (k.flags & NOAHMP_SORT_SNOW) sn = (unsigned)min(max(-k.isnow[p], 0), 3);
   if (k.band) band = (unsigned)min(max(k.band[p], 0), 31);
   if (k.cost && cls == 0u) cost = cost_bucket(k.cost[2 * p], k.cost[2 * p + 1]);
@@ -60,6 +61,9 @@ constexpr int kKeyBits = 27;
 // host-side: the plane the NEXT sort / staleness call of this thread reads (device pointer, the store's column order); consumed by that
 // call (fill_key_args), so that a failed or forgotten call leaves nothing behind
 thread_local const int* g_band_plane = nullptr;
+// vegetation category -> place in the key; identity until noahmp_hip_sort_set_veg_order names another order.  Process-wide like the engine:
+// a staleness count must be taken with the order the layout was sorted by.
+struct VegRank { unsigned char r[64]; VegRank() { for (int v = 0; v < 64; v++) r[v] = (unsigned char)v; } } g_veg_rank;
 
 __global__ void __launch_bounds__(256) sort_key_kernel(const KeyArgs k, unsigned* keys, int* idx) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,6 +104,15 @@ __global__ void __launch_bounds__(256) stale_sum_kernel(unsigned long long* slot
 __global__ void __launch_bounds__(256) invert_perm_kernel(const int* perm, int* inv, long n) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) inv[perm[p]] = (int)p;
+}
+
+// pos[p] = cell, inside a tile-order memory block (rows ni_mem long, tile origin at (i_off, j_off)), of the column at sorted position p
+__global__ void __launch_bounds__(256) block_pos_kernel(const int* perm, long n, int nti, int ni_mem, int i_off, int j_off, int* pos) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int t = perm ? perm[p] : (int)p;
+  const int tj = t / nti, ti = t - tj * nti;
+  pos[p] = (tj + j_off) * ni_mem + ti + i_off;
 }
 
 // Scatter plan (noahmp_hip_scatter_fields): per chunk of 1024 consecutive tile columns, the columns ordered by their
@@ -148,6 +161,7 @@ int fill_key_args(KeyArgs& k, const noahmp_step_args* a, int flags, int tsk_bin_
   k.xice_thres = a->xice_thres; k.isice = a->isice; k.flags = flags;
   k.band = g_band_plane;
   g_band_plane = nullptr;                 // one-shot (noahmp_hip_sort_set_band)
+  memcpy(k.veg_rank, g_veg_rank.r, sizeof k.veg_rank);
   k.n = (long)(a->ime - a->ims + 1) * (a->jme - a->jms + 1);
   // the cost record is in the order the last step found the tile in: usable only if no permutation happened since
   k.cost = ((flags & NOAHMP_SORT_COST) && g.cost_fresh && g.d_cost && g.cost_cols == k.n) ? g.d_cost : nullptr;
@@ -177,6 +191,7 @@ void sort_finalize() {
   hipFree(sc.slots_async); if (sc.h_async) hipHostFree(sc.h_async); if (sc.ev_async) hipEventDestroy(sc.ev_async);
   sc.async_pending = false;
   sc = SortScratch();
+  g_veg_rank = VegRank();
 }
 }  // namespace nmp_host
 
@@ -184,6 +199,27 @@ extern "C" {
 
 int noahmp_hip_sort_set_band(const int32_t* band_plane) {
   g_band_plane = band_plane;
+  return 0;
+}
+
+// Order of the vegetation categories inside the land range: rank[v] (0..63) = place of category v in the key's vegetation field, for
+// v = 0 .. n-1 (categories >= n keep their own number); NULL or n <= 0: the categories' own numbers (the default).  Workgroups start in
+// key order, so the categories named first run first: a caller that names the EXPENSIVE categories first (forests before barren ground)
+// leaves the cheap waves for the tail of the launch, where wave slots idle while the last workgroups finish -- the longest-first rule of
+// list scheduling; what a tile of an 8-rank run (6.75 rounds of the chip's 2 048 wave slots) loses there is measured in
+// profiles/r06_experiments.md.  Pure function of the category, so staleness logic and results are untouched.  Stays in force for every
+// later sort / staleness call of the process (a layout must be checked with the order it was sorted by).
+int noahmp_hip_sort_set_veg_order(const int32_t* rank, int n) {
+  for (int v = 0; v < 64; v++) g_veg_rank.r[v] = (unsigned char)v;
+  if (!rank || n <= 0) return 0;
+  for (int v = 0; v < n && v < 64; v++) {
+    if (rank[v] < 0 || rank[v] > 63) {
+      for (int w = 0; w < 64; w++) g_veg_rank.r[w] = (unsigned char)w;
+      g.last_error = "noahmp_hip_sort_set_veg_order: ranks must be 0..63";
+      return -105;
+    }
+    g_veg_rank.r[v] = (unsigned char)rank[v];
+  }
   return 0;
 }
 
@@ -296,6 +332,25 @@ int noahmp_hip_sort_staleness_result(int64_t* changed, int wait) {
   }
   *changed = *(volatile long*)sc.h_async;
   sc.async_pending = false;
+  return 0;
+}
+
+// For a sorted store of a tile (nti x ntj columns; perm[p] = linear tile index of the column at sorted position p, NULL = tile order)
+// that sits beside a tile-order memory block (rows ni_mem long, the tile's origin at (i_off, j_off): a block that carries the
+// LATERALFLOW ring): pos_out[p] = linear cell index of that column inside the block.  What noahmp_hip_step_async_mirror and
+// noahmp_hip_wtable_columns_gather_async index the block's planes with.  Asynchronous on `stream`.
+int noahmp_hip_sorted_block_positions(const int32_t* perm, int nti, int ntj, int ni_mem, int i_off, int j_off, int32_t* pos_out, void* stream) {
+  int rc = nmp_host::ensure_init();
+  if (rc) return rc;
+  if (!pos_out || nti < 0 || ntj < 0 || i_off < 0 || j_off < 0 || ni_mem < nti + i_off) {
+    g.last_error = "noahmp_hip_sorted_block_positions: the tile does not fit the memory block";
+    return -105;
+  }
+  const long n = (long)nti * ntj;
+  if (((long)ntj + j_off) * (long)ni_mem > 0x7FFFFFFFL) { g.last_error = "noahmp_hip_sorted_block_positions: more than 2^31 cells"; return -105; }
+  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
+  if (n > 0) hipLaunchKernelGGL(block_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, n, nti, ni_mem, i_off, j_off, pos_out);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 

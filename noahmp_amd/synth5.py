@@ -56,8 +56,31 @@ def config5_tile(gx, gy, x0=0, y0=0, nx=None, ny=None, seed=5, cfg=None, **kw):
     return out, lon, static
 
 
-def _config5_rows(ni, gy, r0, nj, seed, cfg, water_frac=0.03, urban_frac=0.01, polar_glacier=0.30):
-    """Rows r0 .. r0+nj-1 (all ni columns) of the global ni x gy grid."""
+def smooth_uniform(ni, gy, r0, nj, seed, nmodes=24):
+    """A spatially smooth random field with U(0, 1) marginals on rows r0 .. r0+nj-1 of the global ni x gy lat/lon grid, as a closed form
+    of the GLOBAL cell indices (so a tile is the same cells whatever the decomposition): a sum of `nmodes` plane waves with random
+    directions, phases and wavelengths of 1 000 .. 10 000 km at the equator (zonal wavenumbers 4 .. 40: periodic in longitude;
+    correlation length a few hundred km -- synoptic scale, what reanalysis forcing interpolated to 0.1 degree looks like,
+    hdrv:332-366, netcdf_io:1369-1404), mapped through the normal CDF."""
+    r = _rng(seed)
+    m = r.integers(4, 41, size=nmodes).astype(np.float64) * r.choice([-1.0, 1.0], size=nmodes)      # zonal wavenumber (cycles per 360 degrees)
+    n = r.uniform(-20.0, 20.0, size=nmodes)                                                         # meridional cycles per 180 degrees
+    ph = r.uniform(0.0, 2.0 * math.pi, size=nmodes)
+    x = (np.arange(ni, dtype=np.float64) + 0.5) * (2.0 * math.pi / ni)
+    y = (np.arange(r0, r0 + nj, dtype=np.float64) + 0.5) * (math.pi / gy)
+    f = np.zeros((nj, ni))
+    for k in range(nmodes):
+        f += np.cos(m[k] * x[None, :] + 2.0 * n[k] * y[:, None] + ph[k])
+    f *= math.sqrt(2.0 / nmodes)                                                                    # unit variance
+    from scipy.special import ndtr
+    return ndtr(f)
+
+
+def _config5_rows(ni, gy, r0, nj, seed, cfg, water_frac=0.03, urban_frac=0.01, polar_glacier=0.30, smooth=False):
+    """Rows r0 .. r0+nj-1 (all ni columns) of the global ni x gy grid.  smooth: the forcing factors (sky transmissivity, relative humidity,
+    surface pressure / elevation, wind, rain timing) are spatially smooth fields (smooth_uniform) with the marginal distributions of the
+    default's i.i.d. draws -- round 6's second generator, to tell what of config 5's lane utilisation is the model and what is white noise
+    in the forcing; everything else (vegetation, soil, snow, temperatures) is the same cells."""
     cfg = cfg or ModelConfig(idveg=1)
     r = _rng(seed)
     s = _base_store(ni, nj, cfg)
@@ -107,6 +130,14 @@ def _config5_rows(ni, gy, r0, nj, seed, cfg, water_frac=0.03, urban_frac=0.01, p
         vwind=r.uniform(-3.0, 3.0, size=shp).astype(F),
         phase=r.integers(0, 16, size=shp).astype(F),               # when this column's rain events come
     )
+    if smooth:
+        base = int(seed[0]) if isinstance(seed, (list, tuple)) else int(seed)
+        u = {k: smooth_uniform(ni, gy, r0, nj, [base, 900 + i]) for i, k in enumerate(("cloud", "rh", "psfc", "uwind", "vwind", "phase"))}
+        static.update(
+            cloud=(0.4 + 0.5 * u["cloud"]).astype(F), rh=(0.4 + 0.5 * u["rh"]).astype(F),
+            psfc=(101325.0 * np.exp(-(2500.0 * u["psfc"]) / 8000.0)).astype(F),
+            uwind=(1.0 + 7.0 * u["uwind"]).astype(F), vwind=(-3.0 + 6.0 * u["vwind"]).astype(F),
+            phase=np.minimum(np.floor(16.0 * u["phase"]), 15.0).astype(F))                        # rain comes in fronts, not cell by cell
     return s, lon, static
 
 

@@ -698,6 +698,59 @@ def test_resident_host_path_sorted_mirrors(engine, tables, deferred):
             engine.set_option(k, 0)
 
 
+@pytest.mark.parametrize("event", ["static_inputs_off_on", "sub_tile_call"])
+def test_resident_sorted_set_is_dropped_when_it_cannot_serve_a_call(engine, tables, event):
+    """The sorted mirror set of "resident_sorted" must never be used stale (round 5's advisor finding): while it holds the newest state,
+    (a) the caller withdraws and re-declares "static_inputs" (and changes a vegetation type in between), or (b) advances a SUB-tile of
+    the same arrays (its > ims: the sorted set cannot serve it) -- the kernels then run on the tile-order mirrors, which must have been
+    brought up to date first, and a later full-tile call must sort the state anew.  Bits of the ordinary host path throughout."""
+    s = synth.mixed_small(tables[1], ni=160, nj=16, glacier_frac=0.05, seed=91)
+    synth.first_step_fixups(s)
+    plain, res = s.copy(), s.copy()
+
+    def forcing(st, it):
+        synth.diurnal_forcing(st, (it + 7) % 24, t_offset=s.t_offset)
+
+    def both(it, **idx):
+        for st in (plain, res):
+            forcing(st, it)
+            if idx:
+                st.set_index(**idx)
+        for k in ("resident_state", "lazy_download", "static_inputs", "resident_sorted"):
+            prev[k] = engine.set_option(k, 0)                                   # the plain path for `plain` ...
+        engine.noahmplsm(plain, it, 2000, 180.0)
+        for k in ("resident_state", "lazy_download", "static_inputs", "resident_sorted"):
+            engine.set_option(k, prev[k])                                       # ... and whatever the test has switched on for `res`
+        assert engine.noahmplsm(res, it, 2000, 180.0).code == 0
+    prev = {}
+    opts = ("resident_state", "lazy_download", "static_inputs", "resident_sorted")
+    try:
+        for k in opts:
+            engine.set_option(k, 1)
+        for it in (1, 2, 3):
+            both(it)                                                            # the sorted set now holds the newest state
+        if event == "static_inputs_off_on":
+            engine.set_option("static_inputs", 0)                              # fetches; both mirror sets will be rebuilt
+            for st in (plain, res):
+                st["ivgtyp"][5, 40:60] = 14                                    # the caller MAY change static inputs now
+            both(4)
+            both(5)
+            engine.set_option("static_inputs", 1)
+            both(6)
+            both(7)
+        else:
+            full = dict(its=1, ite=160, jts=1, jte=16)
+            both(4, its=9, ite=150, jts=3, jte=14)                              # a sub-tile of the same arrays: tile-order kernel
+            both(5, its=9, ite=150, jts=3, jte=14)
+            both(6, **full)                                                     # full tile again: sorted anew
+            both(7, **full)
+        engine.fetch()
+        _check(plain, res, engine, steps=7, fields=_outs(plain))
+    finally:
+        for k in reversed(opts):
+            engine.set_option(k, 0)
+
+
 def test_resident_host_path_alternating_tiles_of_different_size(engine, tables):
     """Two tiles (nests) of different extents advanced alternately with "resident_state" + "lazy_download": a call with other
     arrays first brings the previous tile's host arrays up to date from the still intact mirrors, and only then re-sizes the

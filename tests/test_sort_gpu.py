@@ -82,6 +82,35 @@ def test_device_sort_is_the_stable_sort_of_the_key(engine, tables, kw):
     assert engine.sort_staleness(d) == 0
 
 
+def test_vegetation_order_of_the_key(engine, tables):
+    """noahmp_hip_sort_set_veg_order: the categories named first run first inside the land range (longest-first list scheduling puts the
+    cheap categories at the tail of the launch); a pure relabelling of the vegetation field of the key -- staleness 0 with the same order,
+    identity again after a reset."""
+    s = synth.mixed_small(tables[1], ni=160, nj=48, glacier_frac=0.06, seed=72)
+    first = [14, 15, 11, 2]                                       # forests and crops first; everything else follows in numeric order
+    seq = first + [v for v in range(64) if v not in first]
+    rank = np.empty(64, np.int64)
+    rank[seq] = np.arange(64)
+    try:
+        engine.set_veg_order(first)
+        d = s.to_device("cuda:0")
+        perm = engine.sort_store(d).cpu().numpy().astype(np.int64)
+        key, cls = _host_key(s)
+        vk = (key >> 19) & 63
+        key2 = np.where(cls == 0, (key & ~(63 << 19)) | (rank[vk] << 19), key)
+        np.testing.assert_array_equal(perm, np.argsort(key2, kind="stable"))
+        land = s.a["ivgtyp"].ravel()[perm][:d.class_ranges[0]]
+        seen = [v for i, v in enumerate(land) if i == 0 or land[i - 1] != v]
+        assert seen[:4] == [v for v in first if (s.a["ivgtyp"] == v).any()][:4] and len(seen) == len(set(seen))
+        assert engine.sort_staleness(d) == 0
+    finally:
+        engine.set_veg_order(None)
+    d2 = s.to_device("cuda:0")
+    np.testing.assert_array_equal(engine.sort_store(d2).cpu().numpy().astype(np.int64), np.argsort(_host_key(s)[0], kind="stable"))
+    bad = (C.c_int32 * 4)(0, 1, 64, 3)
+    assert engine.lib.noahmp_hip_sort_set_veg_order(bad, 4) == -105
+
+
 @pytest.mark.parametrize("ni,nj", [(333, 37), (1111, 517), (1153, 769), (2051, 1601), (3100, 2049)])     # chunks of 1024 / 2048 / 4096 / 16384 / 16384 columns
 def test_scatter_plan_on_device_equals_host_plan(engine, tables, ni, nj):
     import torch

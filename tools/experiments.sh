@@ -15,7 +15,7 @@
 #   tile8 [LIB]                    kernel trace of the config-4 step at the N = 8 tile size (1152 x 768)
 #   trace WORKLOAD [bench args]    rocprofv3 kernel trace of one workload (top kernels)
 #   pmc SET [LIB] [bench args]     counters of the land kernel: SET = sq | inst | mem  (see pmc_sets below)
-#   pmc5 [BAND...]                 config 5: lane utilisation / instructions per wave of the land kernel for longitude-band widths
+#   pmc5 [--smooth] [BAND...]      config 5 (--smooth: spatially smooth forcing factors): lane utilisation / instructions per wave of the land kernel for longitude-band widths
 #   band [WIDTH...]                config 5 bench for longitude-band widths (degrees; 0 = no band key)
 #   phase [LIB...]                 phase shares of the profiling build (-DNMP_PHASE_TIMERS: variants/lib_prof.so), after an optional A/B
 #   k2                             the flux solvers as a kernel of their own (variants/lib_k2.so: -DNMP_K2_EXPERIMENT) at 1..4 waves per SIMD, and
@@ -28,6 +28,9 @@
 #   fuzz [SEEDS [COLUMNS]]         randomised GPU-vs-oracle runs over option sets (tools/fuzz_parity.py) + a config-5 chain
 #   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
 #   fuzzopts5 [NSETS [SEED]]       the sorted config-5 chain (class-range kernels) under random option sets, sample vs the oracle
+#   gw6 [bench args]               config 4: round 6's index-plane data flow around WTABLE_mmf_noahmp vs the plane moves of rounds 3-5 (N = 8 tile, N = 1)
+#   vegcost [usgs|modis] [ni nj] [dveg]   land-kernel time per vegetation category (input of noahmp_hip_sort_set_veg_order)
+#   stage [THREADS...]             pageable arrays through the engine's bounce buffers by copy threads + a 10-process fault hunt without GPU_PINNED_MIN_XFER_SIZE
 #   profile TAG                    the evidence for profiles/: plain bench, kernel traces (config 3 / 4 / 5, groundwater), FETCH / WRITE /
 #                                  SQ passes; then in the dev container: python tools/collect_profile.py TAG
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -159,12 +162,14 @@ pmc)
   land_counters $O/$tag $tag
   ;;
 pmc5)
+  SM=""; TAG=""
+  if [ "$1" == "--smooth" ]; then SM="--config5-smooth"; TAG="smooth_"; shift; fi
   if [ $# -eq 0 ]; then set -- 0 15; fi
   cd /tmp && export TMPDIR=/tmp
   for band in "$@"; do
-    rm -rf $O/band$band
-    rocprofv3 --pmc $(pmc_sets sq) -d $O/band$band -o bench --output-format csv -- python3 $R/bench.py --workload config5 --no-cpu-baseline --steps 24 --warmup 2 --lon-band $band > $O/band$band.log 2>&1
-    land_counters $O/band$band "config5 lon-band $band"
+    rm -rf $O/${TAG}band$band
+    rocprofv3 --pmc $(pmc_sets sq) -d $O/${TAG}band$band -o bench --output-format csv -- python3 $R/bench.py --workload config5 $SM --no-cpu-baseline --steps 24 --warmup 2 --lon-band $band > $O/${TAG}band$band.log 2>&1
+    land_counters $O/${TAG}band$band "config5 ${TAG}lon-band $band"
   done
   ;;
 band)
@@ -272,6 +277,31 @@ try:
     else: print(d['options'], 'sample_bit_identical', d['sample_bit_identical'], d['checkpoints'], 'status_max', d.get('device_status_max'))
 except Exception as e: print('FAILED', '$o', e)" | tee -a $O/fuzzopts5.log
   done < $O/sets.txt
+  ;;
+gw6)              # round 6: config 4 with the index-plane data flow around WTABLE_mmf_noahmp vs rounds 3-5's plane moves, at the N = 8 tile and at N = 1
+  for rep in 1 2; do
+    for v in "" "--plane-moves"; do
+      python bench.py --ni 1152 --nj 768 --workload config4 --steps 96 --warmup 12 $QUIET $v "$@" > $O/t8$v.$rep.json 2> $O/t8$v.$rep.err
+      summarise $O/t8$v.$rep.json "tile of N=8 $v"
+    done
+  done
+  for v in "" "--plane-moves"; do
+    python bench.py --workload config4 --steps 48 --warmup 6 $QUIET $v "$@" > $O/n1$v.json 2> $O/n1$v.err
+    summarise $O/n1$v.json "config 4, N=1 $v"
+  done
+  ;;
+vegcost)          # land-kernel cost per vegetation category (tools/veg_cost.py [usgs|modis] [ni nj] [dveg]) -> gpurun_out/exp_vegcost/
+  timeout 1500 python tools/veg_cost.py "$@" > $O/veg_cost_${1:-usgs}_d${4:-3}.json 2> $O/veg_cost_${1:-usgs}_d${4:-3}.err; echo "rc=$?"
+  cat $O/veg_cost_${1:-usgs}_d${4:-3}.err | tail -30; tail -c 600 $O/veg_cost_${1:-usgs}_d${4:-3}.json
+  ;;
+stage)            # pageable host arrays through the engine's bounce buffers, by copy threads; then the churn fault hunt (10 processes)
+  timeout 1200 python tools/stage_exp.py "$@" 2>&1 | grep -v "FOUND\|INITIALIZE\|INPUT\|^$" | tee $O/stage.log
+  bad=0
+  for i in $(seq 1 10); do
+    env -u GPU_PINNED_MIN_XFER_SIZE NMP_STAGE_CHILD=1 NMP_STAGE_CHURN=30 NMP_STAGE_NI=1024 NMP_STAGE_NJ=1024 timeout 600 python tools/stage_exp.py > $O/churn$i.log 2>&1 || bad=$((bad+1))
+    tail -1 $O/churn$i.log
+  done
+  echo "stage churn: $bad of 10 processes failed"
   ;;
 profile)
   TAG=${1:-r05}
