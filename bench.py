@@ -1216,29 +1216,6 @@ def main():
         if not args.cost_key:
             eng.set_option("record_cost", 0)
 
-    if rank == 0 and os.environ.get("NMP_K2_EXP"):
-        # profiling library only (-DNMP_K2_EXPERIMENT, noahmp_amd/csrc/nmp_k2_experiment.hpp): the flux solvers as a kernel of their own,
-        # timed on the inputs the land kernel hands to VEGE_FLUX at a night and a day hour of this very run
-        import ctypes as C
-        eng.lib.noahmp_hip_debug_k2.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
-        for target in (2, 13):
-            while forcing_hour(it + 1, run.cfg.dt) != target:
-                it += 1
-                run.step(it)
-            run.collect()
-            if eng.lib.noahmp_hip_debug_k2(0, None, 0):
-                raise RuntimeError(eng.lib.noahmp_hip_last_error().decode())
-            it += 1
-            run.step(it)
-            run.collect()
-            land_ms = eng.sync_step_timing()[-1]
-            out = (C.c_float * 8)()
-            if eng.lib.noahmp_hip_debug_k2(1, out, 8):
-                raise RuntimeError(eng.lib.noahmp_hip_last_error().decode())
-            names = ("k2_2waves", "k2_3waves", "k2_4waves", "k2_3w_binary_at_2", "k2_2w_binary_at_1", "k2_4w_binary_at_3", "k2_4w_binary_at_2")
-            print("K2EXP " + json.dumps(dict({"hour": target, "land_kernel_ms_with_dump": land_ms, "columns": int(out[7])},
-                                             **{n: round(float(out[i]), 4) for i, n in enumerate(names)})), file=sys.stderr)
-
     # The default N > 1 workload is config 4 (the same grid with the groundwater exchange).  So that a scaling curve over
     # N = 1, 2, 4, 8 has its N = 1 point on the SAME workload, the default N = 1 run measures it too, after the headline (a second,
     # separately timed region of the same length; reported beside the headline, never as `value`).

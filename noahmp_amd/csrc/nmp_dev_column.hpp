@@ -66,10 +66,7 @@ typedef size_t nmp_ij_t;
 #else
 typedef uint32_t nmp_ij_t;
 template <class T> NMP_DEV T& at32(T* base, uint32_t idx) {
-  uint32_t o = idx * (uint32_t)sizeof(T);
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NMP_SADDR_LAUNDER)
-  asm volatile("" : "+v"(o));
-#endif
+  const uint32_t o = idx * (uint32_t)sizeof(T);
   return *(T*)((char*)base + (size_t)o);
 }
 #define G2(f) nmp::at32(k.a.f, ij)
@@ -266,9 +263,7 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   if (vegtyp == 25 || vegtyp == 26 || vegtyp == 27) { s.shdfac = 0.0f; s.lai = 0.0f; }      // drv:540-545
   s.vegtyp = (vegtyp >= 1 && vegtyp <= k.c.ts.lucats) ? vegtyp : 1;
   if (s.err) { failed = s.err; live = false; }                                     // REDPRM fatals, lsm:9266-9344
-  if (NMP_TRUNC == 1) s.err = 99;
   }  // cls <= 1
-  if (NMP_TRUNC == 1) live = false;
 
   float qfx_out = 0.f, lh_out = 0.f;
   if constexpr (MODE != 1)
@@ -286,7 +281,6 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
       scatter_energy_outputs(k, s, ij);
     }
   }
-  float beg_wb_trunc = 0.f;
   if constexpr (MODE != 2) {
     float beg_wb = 0.f;
     // the WATER phase's own inputs (state words only it reads, its rows of the soil tables) are requested before TSNOSOI and
@@ -298,32 +292,18 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
       water_inputs = true;
     };
     sflx_energy(k.c, P, s, y, beg_wb, live, runner, prefetch_water);               // all threads (see above)
-    if (NMP_TRUNC && NMP_TRUNC <= 8) live = false;
     if (live) {
       if (s.err) failed = s.err;
       else {
         lh_out = s.fcev + s.fgev + s.fctr;                                         // drv:714
         scatter_energy_outputs(k, s, ij);
-        if (!water_inputs) prefetch_water();          // (an ENERGY that returned early, e.g. a truncated profiling build)
+        if (!water_inputs) prefetch_water();          // (an ENERGY that returned before TSNOSOI)
         NMP_TIC(11);   // energy tail + early scatter
         sflx_water(k.c, P, s, y, beg_wb);
-        beg_wb_trunc = beg_wb;
         if (s.err) failed = s.err;
         qfx_out = s.ecan + s.edir + s.etran;                                       // drv:713
       }
     }
-  }
-  if (NMP_TRUNC && s.err == 99) {             // truncated profiling build: one checksum store instead of the outputs
-    float acc = beg_wb_trunc;
-    const float* w = reinterpret_cast<const float*>(&s);
-    for (int i = 0; i < (int)(sizeof(Col) / 4) - 1; i++) acc += w[i];
-    const float* pw = reinterpret_cast<const float*>(&P);
-    for (int i = 1; i < (int)(sizeof(Parm) / 4); i++) acc += pw[i];
-    for (int l = 0; l < NL; l++) acc += y.stc[l] + y.zsnso[l] + y.dzsnso[l] + y.imelt[l];
-    for (int l = 1; l <= NSOIL; l++) acc += y.smc[L(l)] + y.sh2o[L(l)] + y.sice[L(l)] + y.smceq[L(l)] + y.btrani[L(l)];
-    for (int l = -2; l <= 0; l++) acc += y.snice[L(l)] + y.snliq[L(l)] + y.ficeold[L(l)];
-    G2(tsk) = acc;
-    return 0;
   }
   if (cls > 1 || failed) return failed;
   // ---- scatter of everything the water phase (or the glacier tail) produced, drv:728-835

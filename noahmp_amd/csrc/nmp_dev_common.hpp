@@ -161,15 +161,6 @@ static __shared__ long long s_nmp_last[8];
 #define NMP_TIC0() ((void)0)
 #endif
 
-// Truncated builds (profiling only, -DNMP_TRUNC=n, tools/trunc_prof.sh): the column step stops after phase n and
-// stores a checksum of its whole state instead of its outputs, so that the difference between the kernel times of
-// consecutive truncations is the true cost of a phase (phase timers are blurred by instruction scheduling).
-#ifndef NMP_TRUNC
-#define NMP_TRUNC 0
-#endif
-#define NMP_TRUNC_AT(n) do { if (NMP_TRUNC == (n)) { s.err = 99; return; } } while (0)
-#define NMP_TRUNC_CHK() do { if (NMP_TRUNC && s.err == 99) return; } while (0)
-
 #ifdef NMP_FIXED_DVEG          // option-specialised translation unit (nmp_engine_fixed.inc, or compiled at run time by
                                // noahmp_jit.hip): the options are compile-time constants -- every other alternative's code folds
                                // away.  Unset ones default to the reference's namelist (run/namelist.hrldas).

@@ -522,11 +522,8 @@ NMP_DEV void stomata(const StomataP& T, float mpe, float apar, float foln, float
   float rlb = rb / cf;
   float cihi = 1.5f * co2, cilow = 0.0f;
   const double r_sfcprs = rc64(sfcprs);                 // divides once per bisection step
-#ifndef NMP_EXP_STOMATA_ITERS
-#define NMP_EXP_STOMATA_ITERS 20       // profiling variants only (tools): fewer bisection steps = wrong results, for timing
-#endif
 #pragma unroll 1
-  for (int iter = 1; iter <= NMP_EXP_STOMATA_ITERS; iter++) {
+  for (int iter = 1; iter <= 20; iter++) {                              // ITER = 1, 20 (lsm:5413)
     float ci = 0.5f * (cihi + cilow);
     float wj = nmp_max(ci - cp, 0.0f) * j / (ci + 2.0f * cp) * c3 + j * (1.f - c3);
     float wc = nmp_max(ci - cp, 0.0f) * vcmx / (ci + awc) * c3 + vcmx * (1.f - c3);
@@ -578,12 +575,6 @@ struct VegIn {
         parsun, parsha, df_top, dz_top, stc_top;
   double r_rhocp, r_gammav, r_gammag;     // 1 / (RHOAIR*CPAIR), 1 / GAMMAV, 1 / GAMMAG (div_rc)
 };
-
-#ifdef NMP_K2_EXPERIMENT
-}  // namespace nmp
-#include "nmp_k2_experiment.hpp"     // profiling build only: k2_dump
-namespace nmp {
-#endif
 
 // ---- the canopy iteration (loop1 of VEGE_FLUX, lsm:3234-3459) as an explicit state machine ------------------
 // Trip counts of this loop run from 6 to NITERC = 20 and differ from column to column: a 64-lane wavefront needs
@@ -782,11 +773,9 @@ NMP_DEV void vege_flux(const Ctx& c, const Parm& P, Col& s, const VegIn& q, floa
   } else {
     record_cost(c, 1, 0);
   }
-  if (NMP_TRUNC == 4) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch; s.err = 99; return; }
   runner.run(c, L, canopy);                             // iterations 2..20
   record_cost(c, 0, canopy ? L.iter - 1 : 0);
   NMP_TIC(21);
-  if (NMP_TRUNC == 5) { s.tv = L.tv + L.tah + L.eah + L.irc + L.shc + L.evc + L.tr + L.rssun + L.rssha + L.h + L.hg + L.cm + L.ch + L.mo.fv + L.mo.fh2; s.err = 99; return; }
   if (!canopy) return;
   if (L.err) raise(s, L.err);
   {                                                   // lsm:3426-3429 of the last iteration
@@ -1304,26 +1293,19 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   float cmv = 0.f, cmb = 0.f;
   const bool canopy = live && veg && s.fveg > 0;
   NMP_TIC(5);    // btran, rsurf, psychrometric constants
-  if (NMP_TRUNC == 3) { s.tv = s.tv + q.rsurf + q.rhsur + q.gammav + q.gammag + q.df_top + q.dz_top + q.stc_top + q.emv + q.emg + q.laisun + q.laisha + q.parsun + q.parsha + q.zlvl + q.zpd + q.z0m + q.cwp + df[3] + hcpct[3] + fact[3] + df[6] + hcpct[6] + fact[6] + r.laisun; s.err = 99; return; }
   if (canopy) {
     s.tgv = s.tg;
     cmv = s.cm;
     s.chv = s.ch;
   }
-#if defined(NMP_K2_EXPERIMENT) && defined(__HIP_DEVICE_COMPILE__)
-  if (live) k2_dump(s, q, canopy);
-#endif
   vege_flux(c, P, s, q, cmv, psnsun, psnsha, canopy, runner);
   NMP_TIC(6);    // vege_flux
   if (!live) return;
-  NMP_TRUNC_CHK();
-  if (NMP_TRUNC == 6) { s.tv = s.tv + cmv + psnsun + psnsha; s.err = 99; return; }
   s.tgb = s.tg;
   cmb = s.cm;
   s.chb = s.ch;
   bare_flux(c, P, s, q, zpdg, cmb);
   NMP_TIC(7);    // bare_flux
-  if (NMP_TRUNC == 7) { s.tv = s.tv + cmv + cmb + psnsun + psnsha; s.err = 99; return; }
   if (canopy) {
     s.fira = s.fveg * s.irg + (1.0f - s.fveg) * s.irb + s.irc;
     s.fsh = s.fveg * s.shg + (1.0f - s.fveg) * s.shb + s.shc;
@@ -1361,7 +1343,6 @@ NMP_DEV void energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, const 
   }
   phasechange(c, P, s, y, fact);
   NMP_TIC(10);   // phasechange
-  NMP_TRUNC_AT(8);
 }
 
 }  // namespace nmp

@@ -279,12 +279,10 @@ NMP_DEV void sflx_energy(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, f
   }
   if (s.vegtyp == c.isurban || s.vegtyp == c.ts.isbarren) s.fveg = 0.0f;
   if (s.elai + s.esai == 0.0f) s.fveg = 0.0f;
-  NMP_TRUNC_AT(2);
   }  // live
 
   energy(c, P, s, y, live, runner, before_soil_heat);
   if (!live) return;
-  NMP_TRUNC_CHK();
 
   s.sneqvo = s.sneqv;
   beg_wb_out = beg_wb;
@@ -309,7 +307,6 @@ NMP_DEV void sflx_water(const Ctx& c, const Parm& P, Col& s, const Lay<A>& y, fl
   NMP_TIC(12);   // water preamble
   water(c, P, s, y, qvap, qdew);
   NMP_TIC(13);   // water
-  NMP_TRUNC_AT(9);
 
   if (c.O.dveg == 2 || c.O.dveg == 5) carbon(c, P, s, y);
   NMP_TIC(14);   // carbon

@@ -78,17 +78,8 @@ __device__ __forceinline__ void column_kernel_body(const KArgs& k) {
   if (err) atomicMin(k.err, k.err_base | ((unsigned long long)(t + k.t_offset + 1) << 8) | (unsigned)err);   // first column wins
 }
 
-// Experiment knob (round 5): -DNMP_NUM_VGPR=120 holds the kernel at 240 unified registers (the attribute counts per register class, the
-// unified file doubles it) = 32 registers per SIMD lane left beside two land waves, room for a third wave of a <= 32-register helper kernel.
-// Measured: the land kernel is 3.2 % slower at 240 (7 spilled registers), and a helper that does co-reside (the 22-register gather as the
-// forcing permutation on a second stream) disappears from the step time but slows the land kernel by its own duration: no gain.
-#ifdef NMP_NUM_VGPR
-#define NMP_VGPR_ATTR __attribute__((amdgpu_num_vgpr(NMP_NUM_VGPR)))
-#else
-#define NMP_VGPR_ATTR
-#endif
 template <int BLOCK, bool USE_LDS, int MODE = 0>
-NMP_VGPR_ATTR __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(const KArgs k) {
+__global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(const KArgs k) {
   column_kernel_body<BLOCK, USE_LDS, MODE>(k);
 }
 

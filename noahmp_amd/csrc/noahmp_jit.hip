@@ -65,18 +65,6 @@ const char* kBuildMacros =
     "#define NMP_LIBM_LDS " NMP_STR(NMP_LIBM_LDS) "\n"
     "#define NMP_FIXED_BLOCK " NMP_STR(NMP_FIXED_BLOCK) "\n"
     "#define NOAHMP_NSOIL " NMP_STR(NOAHMP_NSOIL) "\n"
-#ifdef NMP_TRUNC
-    "#define NMP_TRUNC " NMP_STR(NMP_TRUNC) "\n"
-#endif
-#ifdef NMP_TRUNC_LIGHT
-    "#define NMP_TRUNC_LIGHT 1\n"
-#endif
-#ifdef NMP_SKIP_ENERGY
-    "#define NMP_SKIP_ENERGY 1\n"
-#endif
-#ifdef NMP_EXP_STOMATA_ITERS
-    "#define NMP_EXP_STOMATA_ITERS " NMP_STR(NMP_EXP_STOMATA_ITERS) "\n"
-#endif
 #ifdef NMP_PHASE_TIMERS
     "#define NMP_PHASE_TIMERS 1\n"
 #endif

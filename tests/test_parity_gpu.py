@@ -533,6 +533,50 @@ def test_free_run_option_mixes_bit_identical(engine, port, tables, kw):
     assert set(np.unique(o.a["isnowxy"]).tolist()) == {0, -1, -2, -3}
 
 
+def test_pageable_arrays_travel_through_the_engines_bounce_buffers(engine, tables):
+    """Round 6 (nmp_stage.hpp): no pageable pointer of the caller reaches the HIP runtime -- arrays of several MiB each (the size from
+    which the runtime would page-lock them in place) go through the engine's own page-locked bounce buffers, page-locked arrays are
+    copied directly; either way the bits of the device path.  noahmp_hip_debug_copy_stats counts both kinds."""
+    import ctypes as C
+    import torch
+    s = synth.mixed_small(tables[1], ni=1024, nj=640, seed=37)              # 2.6 MB per 2-D array, 18 MB for ZSNSOXY
+    synth.first_step_fixups(s)
+    synth.diurnal_forcing(s, 13, t_offset=s.t_offset)
+    d = s.to_device("cuda:0")
+    engine.noahmplsm(d, 1, 2000, 180.0)
+    want = d.to_host()
+
+    def stats():
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        engine.lib.noahmp_hip_debug_copy_stats(C.byref(a), C.byref(b))
+        return a.value, b.value
+    up = sum(v.nbytes for k, v in s.a.items() if k != "dzs")
+    down = sum(v.nbytes for k, v in s.a.items() if k != "dzs" and FIELD_INFO[k][2] != "in")
+    prev = engine.set_option("host_chunks", 0)
+    try:
+        h = s.copy()                                                        # plain numpy arrays: pageable
+        s0, d0 = stats()
+        engine.noahmplsm(h, 1, 2000, 180.0)
+        s1, d1 = stats()
+        assert (s1 - s0, d1 - d0) == (up + down, 0)
+        for k in _outs(h):
+            np.testing.assert_array_equal(h.a[k], want.a[k], err_msg=k)
+        p = s.copy()                                                        # the same arrays in page-locked memory (torch's allocator)
+        keep = {}
+        for k, v in p.a.items():
+            if k != "dzs":
+                keep[k] = torch.empty(v.shape, dtype=torch.from_numpy(v).dtype, pin_memory=True)
+                keep[k].numpy()[...] = v
+                p.a[k] = keep[k].numpy()
+        engine.noahmplsm(p, 1, 2000, 180.0)
+        s2, d2 = stats()
+        assert (s2 - s1, d2 - d1) == (0, up + down)
+        for k in _outs(p):
+            np.testing.assert_array_equal(p.a[k], want.a[k], err_msg=k)
+    finally:
+        engine.set_option("host_chunks", prev)
+
+
 def test_pipelined_host_path_bit_identical(engine, tables):
     """Large tiles on the host-memory path are advanced in row chunks (H2D | kernel | D2H on three streams): same bits as
     the device-resident path, untouched cells preserved, fatal column reported with its index in the whole tile."""

@@ -18,8 +18,7 @@
 #   pmc5 [--smooth] [BAND...]      config 5 (--smooth: spatially smooth forcing factors): lane utilisation / instructions per wave of the land kernel for longitude-band widths
 #   band [WIDTH...]                config 5 bench for longitude-band widths (degrees; 0 = no band key)
 #   phase [LIB...]                 phase shares of the profiling build (-DNMP_PHASE_TIMERS: variants/lib_prof.so), after an optional A/B
-#   k2                             the flux solvers as a kernel of their own (variants/lib_k2.so: -DNMP_K2_EXPERIMENT) at 1..4 waves per SIMD, and
-#                                  the land kernel truncated before / behind them (lib_t3.so, lib_t7.so: -DNMP_TRUNC=3 / 7)
+#                                  (round 5's `k2` command and the -DNMP_TRUNC=n builds went with their code in round 6: git show 5bb0a94:tools/experiments.sh)
 #   faulthunt [N [- [ENV=VALUE...]]]   the whole -m gpu suite N times (default 10), each in its own process, with the abort shim;
 #                                  GPU_PINNED_MIN_XFER_SIZE=128 restores the runtime default under which 7 of 10 runs died (round 5)
 #   cost [WORKLOAD...]             the cost sub-key of the column order (bench.py --cost-key: trip counts recorded by the step before the sort),
@@ -28,6 +27,7 @@
 #   fuzz [SEEDS [COLUMNS]]         randomised GPU-vs-oracle runs over option sets (tools/fuzz_parity.py) + a config-5 chain
 #   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
 #   fuzzopts5 [NSETS [SEED]]       the sorted config-5 chain (class-range kernels) under random option sets, sample vs the oracle
+#   spread5                        config 5 under the i.i.d. and the spatially smooth forcing-factor generator: trip-count spread per wavefront (cost-record build)
 #   gw6 [bench args]               config 4: round 6's index-plane data flow around WTABLE_mmf_noahmp vs the plane moves of rounds 3-5 (N = 8 tile, N = 1)
 #   vegcost [usgs|modis] [ni nj] [dveg]   land-kernel time per vegetation category (input of noahmp_hip_sort_set_veg_order)
 #   stage [THREADS...]             pageable arrays through the engine's bounce buffers by copy threads + a 10-process fault hunt without GPU_PINNED_MIN_XFER_SIZE
@@ -185,18 +185,6 @@ phase)
   NMP_PHASE_PROF=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_prof.so timeout 600 python bench.py --steps 24 --warmup 2 $QUIET > $O/prof.json 2> $O/prof.err
   grep "^phase" $O/prof.err; grep -v "^phase" $O/prof.err | tail -3
   ;;
-k2)
-  # build first (dev container): python tools/build_variants.py k2=-DNMP_K2_EXPERIMENT t3=-DNMP_TRUNC=3 t7=-DNMP_TRUNC=7
-  NMP_K2_EXP=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_k2.so timeout 900 python bench.py --steps 24 --warmup 2 $QUIET --no-options-reference --no-host-path-reference > $O/k2.json 2> $O/k2.err
-  grep "^K2EXP" $O/k2.err; grep -v "^K2EXP" $O/k2.err | tail -3
-  for v in t3 t7; do
-    [ -f noahmp_amd/csrc/variants/lib_$v.so ] || continue
-    NMP_LIB=$R/noahmp_amd/csrc/variants/lib_$v.so timeout 600 python bench.py $QUIET --no-options-reference --no-host-path-reference --steps 24 --warmup 6 --resort-every 0 > $O/$v.json 2> $O/$v.err
-    summarise $O/$v.json $v
-  done
-  timeout 600 python bench.py $QUIET --no-options-reference --no-host-path-reference --steps 24 --warmup 6 --resort-every 0 > $O/default.json 2> $O/default.err
-  summarise $O/default.json default
-  ;;
 faulthunt)
   n=${1:-10}; bad=0
   # (round 5: the sort tests' copies are pageable again by default; "pageable" is kept as a no-op second argument)
@@ -277,6 +265,19 @@ try:
     else: print(d['options'], 'sample_bit_identical', d['sample_bit_identical'], d['checkpoints'], 'status_max', d.get('device_status_max'))
 except Exception as e: print('FAILED', '$o', e)" | tee -a $O/fuzzopts5.log
   done < $O/sets.txt
+  ;;
+spread5)          # round 6: canopy-loop lane use of config 5 under the two forcing generators (i.i.d. factors | spatially smooth factors), same column order
+  # build first (dev container): python tools/build_variants.py cost=-DNMP_COST_RECORD
+  for v in "" "--config5-smooth"; do
+    NMP_COST_SPREAD=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_cost.so timeout 900 python bench.py --workload config5 $v --steps 24 --warmup 6 --no-cpu-baseline > $O/spread$v.json 2> $O/spread$v.err
+    summarise $O/spread$v.json "config5 $v (cost-record build)"
+    grep "^COSTSPREAD" $O/spread$v.err | python3 -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l[len('COSTSPREAD '):]); c = d['orders'][0]
+    print('   hour %2d: canopy iterations mean %.2f / wave-max mean %.2f  canopy-loop lane use %.3f  bisection lane use %.3f  waves without canopy %.3f' % (
+        d['hour'], c['canopy_iterations_mean'], c['canopy_iterations_wave_max_mean'], c['canopy_loop_lane_use'], c['bisection_lane_use'], c['waves_without_canopy']))"
+  done
   ;;
 gw6)              # round 6: config 4 with the index-plane data flow around WTABLE_mmf_noahmp vs rounds 3-5's plane moves, at the N = 8 tile and at N = 1
   for rep in 1 2; do
