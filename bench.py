@@ -412,7 +412,7 @@ class Run:
                 self.ts.wait_event(self.ev_scat[b])       # this step's forcing has arrived in set b
             sa = self.sargs2[b]
             sa.itimestep = it
-            self.eng.noahmplsm_async(sa, self.sp)
+            self.eng.noahmplsm_async(sa, self.sp, mirror=self.mirror)
             self.ev_kern[b].record(self.ts)
             h1 = forcing_hour(it + 1, self.cfg.dt)        # the next step's forcing into the other set, beside this step's kernel
             self.ts2.wait_event(self.ev_kern[1 - b])      # (the previous step's kernel read that set)

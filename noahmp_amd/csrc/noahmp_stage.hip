@@ -1,98 +1,17 @@
 // Engine-owned staging of pageable host memory (nmp_stage.hpp).
 #include <hip/hip_runtime.h>
-#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
-#include <atomic>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
 #include <vector>
 #include "nmp_engine_host.hpp"
 #include "nmp_stage.hpp"
+#include "nmp_copy_pool.hpp"
 
 namespace nmp_host {
 namespace {
 
 constexpr size_t kPiece = 32u << 20;      // one bounce buffer: 32 MiB (0.6 ms of DMA at 55 GB/s -- long enough to hide the refill, short enough to start early)
 constexpr int kBuffers = 4;
-
-// ---- a small pool of copy threads: one memcpy thread moves ~10 GB/s, a PCIe 5 x16 link 55 GB/s
-class CopyPool {
- public:
-  void copy(void* dst, const void* src, size_t bytes) {
-    const int n = workers();
-    if (bytes < (4u << 20) || n == 0) { memcpy(dst, src, bytes); return; }
-    const int parts = n + 1;
-    size_t slice = (bytes / parts + 4095) & ~(size_t)4095;
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      dst_ = (char*)dst; src_ = (const char*)src; bytes_ = bytes; slice_ = slice;
-      pending_ = n;
-      generation_++;
-    }
-    cv_work_.notify_all();
-    part(0);
-    std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [&] { return pending_ == 0; });
-  }
-  void stop() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-    }
-    cv_work_.notify_all();
-    for (auto& t : th_) t.join();
-    th_.clear();
-    started_ = false; stop_ = false;
-  }
-
- private:
-  int workers() {
-    if (!started_) {
-      started_ = true;
-      int want = 8;
-      if (const char* e = getenv("NMP_COPY_THREADS")) want = atoi(e);
-      cpu_set_t set;
-      int cpus = 1;
-      if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
-      if (want > cpus) want = cpus;
-      if (want < 1) want = 1;
-      for (int i = 1; i < want; i++) th_.emplace_back([this, i] { loop(i); });
-    }
-    return (int)th_.size();
-  }
-  void part(int i) {
-    const size_t lo = (size_t)i * slice_;
-    if (lo >= bytes_) return;
-    const size_t n = bytes_ - lo < slice_ ? bytes_ - lo : slice_;
-    memcpy(dst_ + lo, src_ + lo, n);
-  }
-  void loop(int i) {
-    unsigned seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_work_.wait(lk, [&] { return stop_ || generation_ != seen; });
-        if (stop_) return;
-        seen = generation_;
-      }
-      part(i);
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        if (--pending_ == 0) cv_done_.notify_one();
-      }
-    }
-  }
-  std::vector<std::thread> th_;
-  std::mutex m_;
-  std::condition_variable cv_work_, cv_done_;
-  char* dst_ = nullptr; const char* src_ = nullptr;
-  size_t bytes_ = 0, slice_ = 0;
-  unsigned generation_ = 0;
-  int pending_ = 0;
-  bool stop_ = false, started_ = false;
-};
 
 struct Stage {
   void* buf[kBuffers] = {};
@@ -101,7 +20,11 @@ struct Stage {
   bool ready = false;
   CopyPool pool;
   unsigned long long staged = 0, direct = 0;
-} S;
+};
+// Never destroyed: a process that exits without noahmp_hip_finalize() still has the copy threads parked on the pool's condition variable, and
+// destroying a condition variable with waiters blocks for ever (glibc's pthread_cond_destroy waits for them) -- the process would hang in its
+// static destructors.  noahmp_hip_finalize() stops the threads and frees the buffers; process exit just ends them.
+Stage& S = *new Stage;
 
 int stage_init() {
   if (S.ready) return 0;

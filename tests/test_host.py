@@ -223,3 +223,16 @@ def test_staleness_result_without_a_pending_count_is_an_error():
     assert lib.noahmp_hip_sort_staleness_result(C.byref(changed), 0) == -105
     assert lib.noahmp_hip_sort_staleness_result(None, 1) == -105
     assert b"no pending count" in lib.noahmp_hip_last_error()
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_copy_pool_of_the_staging_path(tmp_path, threads):
+    """noahmp_amd/csrc/nmp_copy_pool.hpp (the copy threads that fill / drain the engine's page-locked bounce buffers, nmp_stage.hpp) on the
+    CPU: exact copies at sizes around the threading threshold, stop + restart, and a process that never stops a pool it never destroys still
+    exits (round 6's first GPU run hung in a static destructor: pthread_cond_destroy waits for parked workers)."""
+    import subprocess
+    exe = str(tmp_path / "copy_pool_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "noahmp_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cxx", "copy_pool_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], env=dict(os.environ, NMP_COPY_THREADS=str(threads)), capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "copy pool ok" in out.stdout, out.stdout + out.stderr

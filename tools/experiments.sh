@@ -106,8 +106,8 @@ QUIET="--no-cpu-baseline --no-scaling-reference"
 case $CMD in
 tests)
   if [ $# -eq 0 ]; then set -- tests; fi
-  timeout 3000 python -m pytest "$@" -m gpu -x -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -25 $O/pytest.log
-  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+  timeout ${NMP_TEST_TIMEOUT:-900} python -m pytest "$@" -m gpu -x -q --durations=15 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -25 $O/pytest.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
   ;;
 bench)
   timeout 1200 python bench.py "$@" > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
@@ -282,12 +282,12 @@ for l in sys.stdin:
 gw6)              # round 6: config 4 with the index-plane data flow around WTABLE_mmf_noahmp vs rounds 3-5's plane moves, at the N = 8 tile and at N = 1
   for rep in 1 2; do
     for v in "" "--plane-moves"; do
-      python bench.py --ni 1152 --nj 768 --workload config4 --steps 96 --warmup 12 $QUIET $v "$@" > $O/t8$v.$rep.json 2> $O/t8$v.$rep.err
+      timeout 300 python bench.py --ni 1152 --nj 768 --workload config4 --steps 96 --warmup 12 $QUIET $v "$@" > $O/t8$v.$rep.json 2> $O/t8$v.$rep.err
       summarise $O/t8$v.$rep.json "tile of N=8 $v"
     done
   done
   for v in "" "--plane-moves"; do
-    python bench.py --workload config4 --steps 48 --warmup 6 $QUIET $v "$@" > $O/n1$v.json 2> $O/n1$v.err
+    timeout 600 python bench.py --workload config4 --steps 48 --warmup 6 $QUIET $v "$@" > $O/n1$v.json 2> $O/n1$v.err
     summarise $O/n1$v.json "config 4, N=1 $v"
   done
   ;;
@@ -295,14 +295,15 @@ vegcost)          # land-kernel cost per vegetation category (tools/veg_cost.py 
   timeout 1500 python tools/veg_cost.py "$@" > $O/veg_cost_${1:-usgs}_d${4:-3}.json 2> $O/veg_cost_${1:-usgs}_d${4:-3}.err; echo "rc=$?"
   cat $O/veg_cost_${1:-usgs}_d${4:-3}.err | tail -30; tail -c 600 $O/veg_cost_${1:-usgs}_d${4:-3}.json
   ;;
-stage)            # pageable host arrays through the engine's bounce buffers, by copy threads; then the churn fault hunt (10 processes)
-  timeout 1200 python tools/stage_exp.py "$@" 2>&1 | grep -v "FOUND\|INITIALIZE\|INPUT\|^$" | tee $O/stage.log
+stage)            # pageable host arrays through the engine's bounce buffers: copy threads at 1 M columns, the 7 M-column figure, then the churn fault hunt
+  NMP_STAGE_NI=1024 NMP_STAGE_NJ=1024 timeout 600 python tools/stage_exp.py ${@:-1 4 8 16} 2>&1 | grep "^copy threads" | tee $O/stage.log
+  timeout 900 python tools/stage_exp.py 8 2>&1 | grep "^copy threads" | tee -a $O/stage.log
   bad=0
-  for i in $(seq 1 10); do
-    env -u GPU_PINNED_MIN_XFER_SIZE NMP_STAGE_CHILD=1 NMP_STAGE_CHURN=30 NMP_STAGE_NI=1024 NMP_STAGE_NJ=1024 timeout 600 python tools/stage_exp.py > $O/churn$i.log 2>&1 || bad=$((bad+1))
-    tail -1 $O/churn$i.log
+  for i in $(seq 1 ${NMP_CHURN_PROCS:-5}); do
+    env -u GPU_PINNED_MIN_XFER_SIZE NMP_STAGE_CHILD=1 NMP_STAGE_CHURN=30 NMP_STAGE_NI=1024 NMP_STAGE_NJ=1024 timeout 300 python tools/stage_exp.py > $O/churn$i.log 2>&1 || bad=$((bad+1))
+    tail -1 $O/churn$i.log | cut -c1-200
   done
-  echo "stage churn: $bad of 10 processes failed"
+  echo "stage churn: $bad of ${NMP_CHURN_PROCS:-5} processes failed"
   ;;
 profile)
   TAG=${1:-r05}
