@@ -351,17 +351,8 @@ class Run:
 
     def _bind_sorted(self):
         d, eng = self.d, self.eng
-        self.mirror = None
         if self.gw is not None:
             self.wargs_col = d.wtable_args()                  # the per-column half works on the sorted store itself
-            if not self.args.plane_moves:
-                # Round 6: no permutation launch around WTABLE_mmf_noahmp.  The column kernels store every advanced column's ZWTXY also
-                # at its cell of the tile-order block (noahmp_hip_step_async_mirror), the per-column half reads QLAT from the block through
-                # the same index plane and writes the new water table to both places (noahmp_hip_wtable_columns_gather_async).  The block's
-                # ZWTXY is current from the start (it was cut from the same grid) and stays so across re-sorts (tile order does not change).
-                nti, ntj = self.geom["ite"] - self.geom["its"] + 1, self.geom["jte"] - self.geom["jts"] + 1
-                self.block_pos = eng.sorted_block_positions(self.perm, nti, ntj, self.gw.ni, self.i_off, self.j_off)
-                self.mirror = (self.block_pos, self.gw.a["zwtxy"])
         self.work = {k: d.a[k] for k in FKEYS}
         src0 = [self.work[k] for k in FKEYS] if self.block_forcing else [self.forcing[0][k] for k in FKEYS]   # (plan only; sources are set per step)
         # T3D has two levels in memory (HRLDAS passes kms:kme = 1:2) and noahmplsm reads level 1: only that level is permuted
@@ -412,7 +403,7 @@ class Run:
                 self.ts.wait_event(self.ev_scat[b])       # this step's forcing has arrived in set b
             sa = self.sargs2[b]
             sa.itimestep = it
-            self.eng.noahmplsm_async(sa, self.sp, mirror=self.mirror)
+            self.eng.noahmplsm_async(sa, self.sp)
             self.ev_kern[b].record(self.ts)
             h1 = forcing_hour(it + 1, self.cfg.dt)        # the next step's forcing into the other set, beside this step's kernel
             self.ts2.wait_event(self.ev_kern[1 - b])      # (the previous step's kernel read that set)
@@ -422,7 +413,7 @@ class Run:
         elif self.sorted and self.gw is not None:
             self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
-            self.eng.noahmplsm_async(self.sarg, self.sp, mirror=self.mirror)
+            self.eng.noahmplsm_async(self.sarg, self.sp)
         elif self.sorted:
             self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
@@ -440,7 +431,7 @@ class Run:
         """WTABLE_mmf_noahmp (gw:14) after the ZWTXY ring exchange (gw:231-252), enqueued on the run's stream."""
         torch = self.torch
         halo_store = self.gw if self.gw is not None else self.d
-        if self.gw is not None and self.mirror is None:                              # ZWTXY: sorted -> (i,j) order, into the ring-carrying block
+        if self.gw is not None:                                                      # ZWTXY: sorted -> (i,j) order, into the ring-carrying block
             self.scat.exchange([self.d.a["zwtxy"]], [self.gw.a["zwtxy"]], True, self.gw.ni, self.i_off, self.j_off, self.sp)
         if self.comm.world > 1:                # (one rank: nothing to exchange -- and two events are ~10 us between two kernels)
             with torch.cuda.stream(self.ts):
@@ -451,11 +442,8 @@ class Run:
             self.halo_events.append((e0, e1))
         if self.gw is not None:
             self.eng.wtable_lateral_async(self.wargs, self.gw.a["qlat"], self.sp)     # KCELL / HEAD + QLAT stencil, (i,j) order, one launch
-            if self.mirror is not None:                                              # everything else, on the sorted store; QLAT through the index plane
-                self.eng.wtable_columns_gather_async(self.wargs_col, self.gw.a["qlat"], self.block_pos, self.gw.a["zwtxy"], self.sp)
-            else:
-                self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order
-                self.eng.wtable_columns_async(self.wargs_col, self.d.a["qlat"], self.sp)
+            self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order
+            self.eng.wtable_columns_async(self.wargs_col, self.d.a["qlat"], self.sp)  # everything else, on the sorted store
         else:
             self.eng.wtable_mmf_async(self.wargs, self.sp)
         self.gw_calls += 1
@@ -873,8 +861,8 @@ def options_legs(args, comm, eng, tb, dev, barrier, torch):
             K = steps
             out.append({"options": label, "kernel": ("ahead-of-time specialised" if not opts else "run-time specialised (hiprtc)") if specialised else "generic",
                         "value": r.n_adv / dt, "unit": "column-steps/s", "ms_per_step": dt / K * 1e3, "steps": K,
-                        "land_kernel_ms": r.class_ms[0] / K, "columns_per_launch": int(r.n_land / K),
-                        "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_land / K) / (r.class_ms[0] / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "land_kernel_ms": r.class_ms[0] / K, "columns_per_launch": int(r.n_adv / K),
+                        "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_adv / K) / (r.class_ms[0] / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "first_forcing_hour": forcing_hour(warmup + 1, args.dt)})
             del r
         finally:
@@ -889,6 +877,7 @@ def options_legs(args, comm, eng, tb, dev, barrier, torch):
         from noahmp_amd.driver import Engine
         from noahmp_amd.tables import load_tables
         eng2 = Engine(load_tables("usgs")[0], device=dev.index, lib_path=ocml)
+        eng2.set_veg_order(getattr(args, "veg_order_list", None))
         try:
             a = argparse.Namespace(**vars(args))
             a.opts, a.dump = {}, None
@@ -897,8 +886,8 @@ def options_legs(args, comm, eng, tb, dev, barrier, torch):
             out.append({"options": "namelist options, ocml libm instead of the reference's (-DNMP_EXACT_LIBM=0; results NOT bit-identical, "
                                    "profiles/r05_parity_ocml.md)", "kernel": "ahead-of-time specialised, variants/lib_ocml.so",
                         "value": r.n_adv / dt, "unit": "column-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-                        "land_kernel_ms": r.class_ms[0] / steps, "columns_per_launch": int(r.n_land / steps),
-                        "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_land / steps) / (r.class_ms[0] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "land_kernel_ms": r.class_ms[0] / steps, "columns_per_launch": int(r.n_adv / steps),
+                        "roofline_frac": ALG_BYTES_PER_COLSTEP * (r.n_adv / steps) / (r.class_ms[0] / steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "first_forcing_hour": forcing_hour(warmup + 1, args.dt)})
             del r
         finally:
@@ -1072,12 +1061,10 @@ def main():
                          "working sets, one stream each).  Measured in round 5: no gain for configs 3 / 4 (two land waves per SIMD hold the whole "
                          "register file: a wave of another kernel only ever takes the place of one), 0-2 %% for config 5 depending on how the "
                          "runtime maps streams to hardware queues -- off by default")
-    ap.add_argument("--veg-order", default=None,
-                    help="vegetation categories in the order their columns run inside the sorted land range, comma-separated (the rest follow in "
-                         "numeric order); default: the categories' own numbers")
-    ap.add_argument("--plane-moves", action="store_true",
-                    help="config 4, sorted: rounds 3-5's data flow around WTABLE_mmf_noahmp -- ZWTXY permuted to (i,j) order before the stencil and "
-                         "QLAT permuted back behind it (two launches per call) instead of the index-plane accesses of round 6; same results (A/B)")
+    ap.add_argument("--veg-order", default="canopy-first",
+                    help="order of the vegetation categories inside the sorted land range: `canopy-first` (default: categories with a canopy, then "
+                         "the bare ones -- urban, barren, LAI + SAI = 0 -- whose waves cost 0.57x as much: cheap waves at the tail of the launch), "
+                         "`numeric` (the categories' own numbers, rounds 2-5), or a comma-separated list (the rest follow in numeric order)")
     ap.add_argument("--snow-first", action="store_true", help="sort key: snow-layer count above vegetation type")
     ap.add_argument("--tair-key", action="store_true", help="temperature bins of the sort key from the air temperature instead of TSK")
     ap.add_argument("--no-veg-key", action="store_true", help=argparse.SUPPRESS)
@@ -1127,8 +1114,13 @@ def main():
     eng = Engine(T, device=dev_index, lib_path=os.environ.get("NMP_LIB"))
     if os.environ.get("NMP_BLOCK"):
         eng.set_option("block", int(os.environ["NMP_BLOCK"]))
-    if args.veg_order:
-        eng.set_veg_order([int(v) for v in args.veg_order.split(",")])
+    args.veg_order_list = None
+    if args.veg_order == "canopy-first":
+        from noahmp_amd.tables import canopy_first_order
+        args.veg_order_list = canopy_first_order(tb)
+    elif args.veg_order and args.veg_order != "numeric":
+        args.veg_order_list = [int(v) for v in args.veg_order.split(",")]
+    eng.set_veg_order(args.veg_order_list)
 
     def barrier():
         comm.barrier()
@@ -1242,8 +1234,8 @@ def main():
         config2_ref = {"workload": WORKLOAD_TEXT["config2"] % dict(cols=1024 * 1024, ni=1024, nj=1024) + " (`--workload config2`), sorted on the device, "
                                    "forcing permutation inside the timed region",
                        "value": r2.n_adv / dt2, "unit": "column-steps/s", "ms_per_step": dt2 / K2 * 1e3, "steps": K2,
-                       "land_kernel_ms": r2.class_ms[0] / K2, "columns_per_launch": int(r2.n_land / K2),
-                       "roofline_frac": ALG_BYTES_PER_COLSTEP * (r2.n_land / K2) / (r2.class_ms[0] / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "land_kernel_ms": r2.class_ms[0] / K2, "columns_per_launch": int(r2.n_adv / K2),
+                       "roofline_frac": ALG_BYTES_PER_COLSTEP * (r2.n_adv / K2) / (r2.class_ms[0] / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "first_forcing_hour": forcing_hour(args.warmup + 1, args.dt)}
         del r2
         torch.cuda.empty_cache()
@@ -1257,7 +1249,7 @@ def main():
                            " (`--workload config5`)",
                            "value": r5.n_adv / dt5, "unit": "column-steps/s", "ms_per_step": dt5 / args.steps * 1e3, "steps": args.steps,
                            "columns_advanced_per_step": r5.n_adv // args.steps, "column_kernels_ms_per_step": r5.kernel_ms / args.steps,
-                           "land_kernel_ms": r5.class_ms[0] / args.steps, "land_ice_kernel_ms": r5.class_ms[1] / args.steps,
+                           "land_kernel_ms": r5.class_ms[0] / args.steps,          # (the one column kernel of a step: land + land-ice + skipped ranges)
                            "cold_start_s": r5.cold_start_s}
             del r5
             torch.cuda.empty_cache()
@@ -1271,7 +1263,7 @@ def main():
                                               "config-5 number",
                                   "value": r5.n_adv / dt5, "unit": "column-steps/s", "ms_per_step": dt5 / args.steps * 1e3, "steps": args.steps,
                                   "columns_advanced_per_step": r5.n_adv // args.steps, "column_kernels_ms_per_step": r5.kernel_ms / args.steps,
-                                  "land_kernel_ms": r5.class_ms[0] / args.steps, "land_ice_kernel_ms": r5.class_ms[1] / args.steps}
+                                  "land_kernel_ms": r5.class_ms[0] / args.steps}
             del r5
             torch.cuda.empty_cache()
         if not args.no_options_reference:
@@ -1303,8 +1295,10 @@ def main():
         prefetch5 = workload == "config5" and args.prefetch
         value = n_adv_all / dt
         # dominant kernel: the land range of the sorted layout (the mixed kernel of a tile-order run); its own event pair per step
+        # Round 6: ONE kernel per step either way -- a sorted run's land, land-ice and skipped ranges are workgroup ranges of one launch
+        # (noahmp_ranges_kernel), so the launch advances land AND land-ice columns; its own start / stop events ride on the dispatch
         dom_ms = run.class_ms[0] / K
-        dom_cols = (run.n_land if run.sorted else run.n_adv) / K       # columns one launch of that kernel advances
+        dom_cols = run.n_adv / K                                       # columns one launch of that kernel advances
         achieved = ALG_BYTES_PER_COLSTEP * dom_cols / (dom_ms * 1e-3) / 1e9
         traffic, valu, traffic_source = None, None, None
         # PMC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this very command,
@@ -1387,7 +1381,8 @@ def main():
             "achieved_hbm_gbs": achieved,          # the second half of BASELINE.json's metric: algorithmic GB/s of the dominant kernel (= roofline.achieved)
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "noahmp_column_kernel (%s)" % ("land range of the sorted layout" if run.sorted else "mixed tile"),
+                         "kernel": ("noahmp_ranges_kernel (the sorted layout's land + land-ice + skipped ranges in one launch)" if run.sorted
+                                    else "noahmp_column_kernel (mixed tile)"),
                          "kernel_ms_avg": dom_ms, "columns_per_launch": int(dom_cols),
                          "weighting": ("24-hour-weighted: mean over the 24 forcing hours of the per-hour kernel means (timed steps; warm-up steps only "
                                        "for hours the timed window does not reach)") if ms_24h else "mean over the timed window",

@@ -26,7 +26,13 @@ def _headers():
 # -fno-slp-vectorize: packed float32 (v_pk_*) is no throughput lever on this chip (a v_pk_mul_f32 occupies the SIMD as long as two v_mul_f32) and
 # pairing the operands costs moves and registers: without the SLP vectorizer the land kernel has 242 fewer static v_mov, 231 instead of 243
 # VGPRs and runs 0.6 % faster (A/B twice on one box: 3.210 / 3.215 -> 3.193 / 3.193 ms).  Same IEEE operations, same results.
+# -instcombine-max-copied-from-constant-users: the kernel-argument block (KArgs, 1.6 KB, passed by value) is read straight from the
+# kernel-argument segment by scalar loads only if InstCombine can prove that its private copy is never written -- and it gives up after 300
+# users of that copy.  The one-launch class-range kernel (noahmp_ranges_kernel: land + land-ice + skipped bodies, round 6) has more: without
+# the flag it starts by copying all 1 640 bytes into scratch memory and reads every array pointer back from there (ISA: 22 scratch stores,
+# 309 scratch loads, private_segment_fixed_size 1640); with it 0, and the registers of the land kernel alone (231).  noahmp_jit.hip passes it too.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+         "-mllvm", "-instcombine-max-copied-from-constant-users=100000",
          "-Wno-unused-value", "-I" + os.path.join(_HERE, "..", "include")]
 
 

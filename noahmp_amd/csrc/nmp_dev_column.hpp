@@ -23,11 +23,7 @@ struct KArgs {
   unsigned long long err_base;   // step ordinal << 40 for asynchronous stepping (0 otherwise)
   long t_offset;                 // tile index of this launch's first column when a tile is advanced in row chunks
   long t_first, t_count;         // class-range launches (sorted layout): this launch covers tile indices [t_first, t_first + t_count)
-  // noahmp_hip_step_async_mirror (a sorted OPT_RUN = 5 run): every advanced column also stores its ZWTXY at cell lat_pos[column] of the
-  // tile-order block the LATERALFLOW stencil reads, so that no sorted -> (i,j) permutation launch stands between the column step and
-  // WTABLE_mmf_noahmp's lateral half.  lat_pos is shaped like the block's 2-D arrays.  NULL: no mirror.
-  const int* lat_pos;
-  float* lat_zwt;
+  long r_land, r_ice, r_skip;    // noahmp_ranges_kernel: columns of the land, land-ice and skipped range (in this order in the arrays)
 };
 
 constexpr int LAY_SLOTS = 4 * NL + 5 * NSOIL + 3 * NSNOW;   // stc,zsnso,dzsnso,imelt | smc,sh2o,sice,smceq,btrani | snice,snliq,ficeold
@@ -62,7 +58,6 @@ NMP_DEV Lay<LArr<STRIDE>> make_lay(float* base) {
 typedef size_t nmp_ij_t;
 #define G2(f) k.a.f[ij]
 #define G3(f, lev, nk) k.a.f[((size_t)jj * (nk) + (lev)) * k.ni + ii]
-#define GK(p) k.p[ij]
 #else
 typedef uint32_t nmp_ij_t;
 template <class T> NMP_DEV T& at32(T* base, uint32_t idx) {
@@ -71,7 +66,6 @@ template <class T> NMP_DEV T& at32(T* base, uint32_t idx) {
 }
 #define G2(f) nmp::at32(k.a.f, ij)
 #define G3(f, lev, nk) nmp::at32(k.a.f, ((uint32_t)jj * (uint32_t)(nk) + (uint32_t)(lev)) * (uint32_t)k.ni + (uint32_t)ii)
-#define GK(p) nmp::at32(k.p, ij)
 #endif
 
 
@@ -144,7 +138,6 @@ NMP_DEV void gather_water_state(const KArgs& k, Col& s, nmp_ij_t ij) {
   s.smcwtd = G2(smcwtdxy);
   s.acc_sfcrunoff = G2(sfcrunoff); s.acc_udrunoff = G2(udrunoff); s.acc_acsnow = G2(acsnow); s.acc_acsnom = G2(acsnom);
   s.acc_rech = G2(rechxy); s.acc_deeprech = G2(deeprechxy);
-  if (k.lat_zwt) s.lat_pos = GK(lat_pos);             // KArgs::lat_pos: read here, used by the final scatter (no dependent round trip there)
 }
 
 // Gather -> REDPRM -> NOAHMP_SFLX | NOAHMP_GLACIER -> scatter for one land / glacier column.
@@ -324,7 +317,6 @@ NMP_DEV int column_step(const KArgs& k, int cls, int ii, int jj, nmp_ij_t ij, fl
   G2(isnowxy) = s.isnow; G2(tvxy) = s.tv; G2(canliqxy) = s.canliq; G2(canicexy) = s.canice;
   G2(fwetxy) = s.fwet; G2(qsnowxy) = s.qsnow;
   G2(wslakexy) = s.wslake; G2(zwtxy) = s.zwt; G2(waxy) = s.wa; G2(wtxy) = s.wt;
-  if (k.lat_zwt) k.lat_zwt[s.lat_pos] = s.zwt;        // the tile-order mirror of ZWTXY (KArgs::lat_zwt)
 #pragma unroll
   for (int l = -2; l <= 0; l++) {
     G3(tsnoxy, l + 2, 3) = y.stc[L(l)]; G3(snicexy, l + 2, 3) = y.snice[L(l)];

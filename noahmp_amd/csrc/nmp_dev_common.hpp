@@ -411,7 +411,6 @@ struct Col {
   float thair, qair, eair, rhoair, qprecc, qprecl, solad0, solad1, solai0, solai1, swdown;
   float elai, esai, htop, igs, btran, latheav, latheag, qmelt, fsrv, fsrg;
   int frozen_canopy, frozen_ground;
-  int lat_pos;                       // KArgs::lat_pos of this column (gather_water_state -> final scatter)
   int err;
 };
 

@@ -32,11 +32,6 @@ struct GwArgs {
   unsigned long long* err;
   int* counts;
   float* qlat;                     // split form (sorted layout): QLAT plane written by gw_qlat_fused_kernel / read by gw_column_t<false>
-  // split form, per-column half on a SORTED store beside a tile-order block (noahmp_hip_wtable_columns_gather_async): cell of column x
-  // inside the block (`qlat` is then that block's plane: the (i,j) -> sorted move is this one indexed load), and the block's ZWTXY plane,
-  // which receives the new water table too (so that no sorted -> (i,j) move precedes the next stencil).  NULL: qlat is in column order.
-  const int* __restrict__ lat_pos;
-  float* zwt_block;
 };
 
 // KLATFACTOR, gw:224-225 (indexed by soil category 1..19)
@@ -298,8 +293,7 @@ NMP_DEV int gw_column_t(const GwArgs& g, int i, int j, int gi, int gj) {
   }
   // stencil operands (whole form) or the QLAT plane (split form)
   const bool inq = STENCIL && (gi >= g.qi0 && gi <= g.qi1 && gj >= g.qj0 && gj <= g.qj1);
-  const size_t xq = (!STENCIL && g.lat_pos) ? (size_t)g.lat_pos[x] : x;          // the column's cell in the tile-order block
-  const float qlat_in = STENCIL ? gw_qlat_stencil(g, x, inq, area) : g.qlat[xq];
+  const float qlat_in = STENCIL ? gw_qlat_stencil(g, x, inq, area) : g.qlat[x];
 
   // ---- compute
   const bool land = gw_is_land(a, xland, xice, ivgtyp);
@@ -346,7 +340,6 @@ NMP_DEV int gw_column_t(const GwArgs& g, int i, int j, int gi, int gj) {
       a.sh2oxy[x3 + k * plane] = c.sh2o.v[k];
     }
     a.wtd[x] = c.wtd;
-    if (!STENCIL && g.zwt_block) g.zwt_block[xq] = c.wtd;
     a.smcwtd[x] = c.smcwtd;
     a.qspring[x] = qspring;
   }

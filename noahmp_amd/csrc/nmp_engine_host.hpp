@@ -1,6 +1,7 @@
 // Host-side engine state shared by the translation units of libnoahmp_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <string>
 #include <unordered_map>
@@ -33,9 +34,6 @@ struct Engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_timed = false;                    // ev0 / ev1 were recorded by the resident-path call now pending (not for an empty tile)
   hipStream_t own_stream = nullptr;
-  hipStream_t aux_stream = nullptr;      // land-ice / skipped class kernels beside the land kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int overlap_class_kernels = 1;
   // host-mode mirrors of the noahmp_step_args arrays (one per field of nmp_fields.inc)
   std::vector<void*> mirror;
   std::vector<size_t> mirror_bytes;
@@ -122,20 +120,21 @@ struct LaunchDesc {
   unsigned long long err_base;
   long t_offset, t_first, t_count;
   unsigned char* cost;           // Ctx::cost of this launch (already offset to its first column) or NULL
-  const int* lat_pos; float* lat_zwt;   // KArgs::lat_pos / lat_zwt (noahmp_hip_step_async_mirror) or NULL
+  long r_land, r_ice, r_skip;    // mode 4 (noahmp_ranges_kernel): columns per class range
 };
-// mode: 0 mixed tile, 1 land-only range, 2 land-ice-only range (template parameter MODE of the kernel); d<DVEG>_r<RUN>, the other options = namelist values
-void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s);
+// mode: 0 mixed tile, 4 the three class ranges of a sorted layout in one launch; ev0 / ev1: the kernel's start / stop events or NULL;
+// d<DVEG>_r<RUN>, the other options = namelist values
+void launch_fixed_d1_r1(const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 #ifdef NMP_PHASE_TIMERS
 void prof_fixed_d1_r1(unsigned long long*, int); void prof_fixed_d3_r1(unsigned long long*, int); void prof_fixed_d3_r5(unsigned long long*, int);
 void prof_fixed_d4_r1(unsigned long long*, int); void prof_fixed_d4_r3(unsigned long long*, int);
 #endif
-void launch_fixed_d3_r1(const LaunchDesc& d, int mode, hipStream_t s);
-void launch_fixed_d3_r5(const LaunchDesc& d, int mode, hipStream_t s);
-void launch_fixed_d4_r1(const LaunchDesc& d, int mode, hipStream_t s);
-void launch_fixed_d4_r3(const LaunchDesc& d, int mode, hipStream_t s);
+void launch_fixed_d3_r1(const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_fixed_d3_r5(const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_fixed_d4_r1(const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_fixed_d4_r3(const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 // noahmp_jit.hip: the same for any option set o[12] = (DVEG, CRS, BTR, RUN, SFC, FRZ, INF, RAD, ALB, SNF, TBOT, STC), compiled on first use
-bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s);
+bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void jit_finalize();
 void jit_stats(int* out);
 std::string cache_dir_public();

@@ -33,27 +33,28 @@ using namespace nmp;
 // MODE 0: the tile as it is (any mix of classes).  MODE 1 / 2 / 3: a range of a class-sorted layout that holds only land /
 // only glacier / only skipped (open water, sea ice) columns -- kernels without the other classes' code; a column of another
 // class in such a range raises NOAHMP_ERR_CLASS_RANGE (its class changed since the sort, e.g. sea ice: sort again).
+// lds: the workgroup's layer slots (LAY_SLOTS * BLOCK floats; unused by MODE 3).  blk: the workgroup's index inside its launch (MODE 0) or
+// inside its class range, which covers tile indices [first, first + count).
 template <int BLOCK, bool USE_LDS, int MODE>
-__device__ __forceinline__ void column_kernel_body(const KArgs& k) {
+__device__ __forceinline__ void column_kernel_body(const KArgs& k, float* lds, const long blk, const long first, const long count) {
   constexpr int STRIDE = USE_LDS ? BLOCK : 1;
-  __shared__ float lds[(USE_LDS && MODE != 3) ? LAY_SLOTS * BLOCK : 1];
   float priv[(USE_LDS || MODE == 3) ? 1 : LAY_SLOTS];
   float* base = USE_LDS ? (lds + threadIdx.x) : priv;
 
   if (MODE != 3) libm::libm_stage_tables();
-  const long tl = (long)blockIdx.x * BLOCK + threadIdx.x;
-  const long t = k.t_first + tl;
+  const long tl = blk * BLOCK + threadIdx.x;
+  const long t = first + tl;
   int ii = 0, jj = 0;
   nmp_ij_t ij = 0;
   int cls = 3, err = 0;
   if (MODE == 1 || MODE == 2) {
     // class range of a sorted layout: the gather does not wait for the classification (column_step<.., EARLY>)
-    if (tl < k.t_count && column_index(k, t, ii, jj, ij)) {
+    if (tl < count && column_index(k, t, ii, jj, ij)) {
       SimpleLoop runner;
       err = column_step<STRIDE, MODE, true>(k, -1, ii, jj, ij, base, runner, &cls);
     }
   } else {
-    cls = (MODE != 0 && tl >= k.t_count) ? 3 : column_classify(k, t, ii, jj, ij);
+    cls = (MODE != 0 && tl >= count) ? 3 : column_classify(k, t, ii, jj, ij);
   }
   {                                           // per-wave tallies (64-wide wavefront)
     unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
@@ -80,7 +81,25 @@ __device__ __forceinline__ void column_kernel_body(const KArgs& k) {
 
 template <int BLOCK, bool USE_LDS, int MODE = 0>
 __global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_column_kernel(const KArgs k) {
-  column_kernel_body<BLOCK, USE_LDS, MODE>(k);
+  __shared__ float lds[(USE_LDS && MODE != 3) ? LAY_SLOTS * BLOCK : 1];
+  column_kernel_body<BLOCK, USE_LDS, MODE>(k, lds, (long)blockIdx.x, k.t_first, k.t_count);
+}
+
+// The three class ranges of a sorted layout in ONE launch (round 6): workgroups [0, nb_ice) advance the land-ice range, the next nb_land the
+// land range, the rest the skipped cells -- every wave runs the code of one class only, as in the three separate kernels of rounds 2-5,
+// whose side-by-side execution needed a second stream with a fork and a join event: three barrier packets per step on the run's queue,
+// ~18 us in which no kernel ran (kernel trace, profiles/r06_experiments.md), 3 % of the step of an 8-rank tile.  Land ice goes FIRST: its
+// waves are the longest (84 vs ~60 us) and there are few of them, the skipped cells (a few instructions per wave) last -- the order of
+// longest-first list scheduling.  Registers: the maximum over the three bodies (they share nothing but the kernel arguments); LDS: one
+// array for whichever body the workgroup runs.  KArgs::r_land / r_ice / r_skip = columns per class (land columns come first in the arrays).
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, NMP_WAVES_PER_EU) noahmp_ranges_kernel(const KArgs k) {
+  __shared__ float lds[LAY_SLOTS * BLOCK];
+  const long nb_ice = (k.r_ice + BLOCK - 1) / BLOCK, nb_land = (k.r_land + BLOCK - 1) / BLOCK;
+  const long b = (long)blockIdx.x;
+  if (b < nb_ice) column_kernel_body<BLOCK, true, 2>(k, lds, b, k.r_land, k.r_ice);
+  else if (b < nb_ice + nb_land) column_kernel_body<BLOCK, true, 1>(k, lds, b - nb_ice, 0L, k.r_land);
+  else column_kernel_body<BLOCK, true, 3>(k, lds, b - nb_ice - nb_land, k.r_land + k.r_ice, k.r_skip);
 }
 
 }  // namespace

@@ -228,7 +228,7 @@ int noahmp_hip_set_option(const char* key, int value) {
       g.lazy_download = value;
     }
   }
-  else if (!strcmp(key, "overlap_class_kernels")) { prev = g.overlap_class_kernels; if (value == 0 || value == 1) g.overlap_class_kernels = value; }
+  else if (!strcmp(key, "overlap_class_kernels")) prev = 1;          // (rounds 2-5: a second stream for the small class kernels; one launch now)
   else if (!strcmp(key, "static_inputs")) {
     prev = g.static_inputs;
     if ((value == 0 || value == 1) && value != g.static_inputs) {
@@ -287,7 +287,7 @@ static void fill_kargs(KArgs& k, const noahmp_step_args* a) {
 
 // the option-specialised translation units (noahmp_engine_d*_r*.hip): (DVEG, RUN) with the other ten options at the namelist values
 #ifndef NMP_NO_FIXED_KERNELS
-struct FixedKernel { int dveg, run; void (*launch)(const nmp_host::LaunchDesc&, int, hipStream_t); };
+struct FixedKernel { int dveg, run; void (*launch)(const nmp_host::LaunchDesc&, int, hipStream_t, hipEvent_t, hipEvent_t); };
 static const FixedKernel kFixed[] = {{1, 1, nmp_host::launch_fixed_d1_r1}, {3, 1, nmp_host::launch_fixed_d3_r1},
                                      {3, 5, nmp_host::launch_fixed_d3_r5}, {4, 1, nmp_host::launch_fixed_d4_r1},
                                      {4, 3, nmp_host::launch_fixed_d4_r3}};      // (4, 3): the WRF defaults
@@ -309,7 +309,7 @@ static int fixed_level(const KArgs& k) {
 }
 
 // level > 0: ahead-of-time kernel kFixed[level-1]; level < 0: compile one for this option set at run time.  false: not available.
-static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
+static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
 #ifdef NMP_NO_FIXED_KERNELS
   return false;
 #else
@@ -322,31 +322,33 @@ static bool launch_fixed(const KArgs& k, int level, int mode, hipStream_t s) {
   d.ni = k.ni; d.nka = k.nka; d.nti = k.nti; d.ntj = k.ntj; d.k1 = k.k1; d.kp_lo = k.kp_lo; d.kp_hi = k.kp_hi; d.yearlen = k.yearlen;
   d.err = k.err; d.counts = k.counts; d.err_base = k.err_base; d.t_offset = k.t_offset; d.t_first = k.t_first; d.t_count = k.t_count;
   d.cost = k.c.cost;
-  d.lat_pos = k.lat_pos; d.lat_zwt = k.lat_zwt;
-  if (level > 0) { kFixed[level - 1].launch(d, mode, s); return true; }
+  d.r_land = k.r_land; d.r_ice = k.r_ice; d.r_skip = k.r_skip;
+  if (level > 0) { kFixed[level - 1].launch(d, mode, s, ev0, ev1); return true; }
   const Opt& o = k.c.O;
   const int opts[12] = {o.dveg, o.crs, o.btr, o.run, o.sfc, o.frz, o.inf, o.rad, o.alb, o.snf, o.tbot, o.stc};
-  return nmp_host::launch_jit(opts, d, mode, s);
+  return nmp_host::launch_jit(opts, d, mode, s, ev0, ev1);
 #endif
 }
 
-template <int MODE>
-static void launch_range(KArgs k, long first, long count, hipStream_t s) {
-  if (count <= 0) return;
-  k.t_first = first; k.t_count = count;
-  if (k.c.cost) k.c.cost += 2 * first;                 // the kernel indexes it by its own thread number
-  const int fx = (MODE != 3) ? fixed_level(k) : 0;      // skipped cells do not depend on the options
-  if (fx && launch_fixed(k, fx, MODE, s)) return;
-  // the generic (run-time options) class-range kernels: one wave per workgroup like the specialised ones (nmp_kernel.hpp: NMP_FIXED_BLOCK)
-  hipLaunchKernelGGL((noahmp_column_kernel<NMP_FIXED_BLOCK, true, MODE>), dim3((unsigned)((count + NMP_FIXED_BLOCK - 1) / NMP_FIXED_BLOCK)),
-                     dim3(NMP_FIXED_BLOCK), 0, s, k);
+// The three class ranges of a sorted layout in one launch (noahmp_ranges_kernel, nmp_kernel.hpp): option-specialised ahead of time, at
+// run time, or generic.  ev0 / ev1: the kernel's own start / stop events (attached to the dispatch: no packet of their own) or NULL.
+static void launch_ranges(KArgs k, long n_land, long n_ice, long n_skip, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  constexpr long B = NMP_FIXED_BLOCK;
+  k.r_land = n_land; k.r_ice = n_ice; k.r_skip = n_skip;
+  k.t_first = 0; k.t_count = n_land + n_ice + n_skip;
+  const long nb_ice = (n_ice + B - 1) / B, nb = nb_ice + (n_land + B - 1) / B + (n_skip + B - 1) / B;
+  if (nb <= 0) return;
+  // "record_cost": the kernel indexes the record by its global thread number, and the land range's workgroups follow the land-ice ones
+  if (k.c.cost) k.c.cost -= 2 * nb_ice * B;
+  const int fx = fixed_level(k);
+  if (fx && launch_fixed(k, fx, 4, s, ev0, ev1)) return;
+  hipExtLaunchKernelGGL((noahmp_ranges_kernel<NMP_FIXED_BLOCK>), dim3((unsigned)nb), dim3(NMP_FIXED_BLOCK), 0, s, ev0, ev1, 0, k);
 }
 
 // class_ranges: the call is a whole device-resident tile, the only kind of call the declared class ranges can describe
-// ev: the step's three timing events (noahmp_hip_sync_timing): start | end of the land (or only) kernel | end of the land-ice + skipped
-// kernels.  Every event is one more packet between two kernels of the caller's stream (~5 us each on this chip), so they double as the
-// fork / join events of the second stream and nothing else is recorded; g.last_launch_kind tells noahmp_hip_sync which of them exist
-// (-1: an empty tile, none).
+// ev: the step's timing events (noahmp_hip_sync_timing): [0] start, [1] end of the step's column kernel ([2]: unused since round 6).
+// kind 1 (class ranges, one launch): the events are the dispatch's own start / stop events -- an event RECORDED on the stream is one more
+// packet between two kernels (~5 us each on this chip); kind 0 (tile order): recorded around the launch; -1: an empty tile, none.
 static void launch_any(const KArgs& k_in, hipStream_t s, bool class_ranges = false, hipEvent_t* ev = nullptr) {
   KArgs k = k_in;
   const long ncol = (long)k.nti * k.ntj;
@@ -361,34 +363,21 @@ static void launch_any(const KArgs& k_in, hipStream_t s, bool class_ranges = fal
       k.c.cost = g.d_cost; g.cost_cols = ncol; g.cost_fresh = true;
     }
   }
-  // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): one kernel per class
+  // class-sorted layout whose ranges the caller declared ("sorted_land_columns", "sorted_glacier_columns"): ONE launch, every workgroup
+  // runs the code of its class only (rounds 2-5: three kernels, the small ones on a second stream beside the land kernel -- a fork and a
+  // join event per step; the kernel trace of round 6 showed ~18 us per step in which those packets kept the queue idle)
   if (class_ranges && g.sorted_land >= 0 && g.sorted_glacier >= 0 && g.sorted_land + g.sorted_glacier <= ncol && k.t_offset == 0 &&
       g.block == 256 && g.use_lds) {
-    // The land-ice and skipped ranges are tiny next to the land range and latency-bound (a column-step takes a wave ~50 us whatever the
-    // launch size): they run on a second stream beside the land kernel -- disjoint columns -- and join before anything else follows.
-    const long n_rest = ncol - g.sorted_land;
-    const bool fork = g.overlap_class_kernels && g.sorted_land > 0 && n_rest > 0;
-    g.last_launch_kind = fork ? 2 : 1;
-    if (fork && !g.aux_stream) {
-      hipStreamCreateWithFlags(&g.aux_stream, hipStreamNonBlocking);       // (a high-priority stream: no gain, profiles/r05_experiments.md section 7)
-      hipEventCreateWithFlags(&g.ev_fork, hipEventDisableTiming);
-      hipEventCreateWithFlags(&g.ev_join, hipEventDisableTiming);
-    }
-    hipEvent_t e_fork = ev ? ev[0] : g.ev_fork, e_join = ev ? ev[2] : g.ev_join;
-    if (fork || ev) hipEventRecord(e_fork, s);
-    if (fork) hipStreamWaitEvent(g.aux_stream, e_fork, 0);
-    hipStream_t s2 = fork ? g.aux_stream : s;
-    launch_range<1>(k, 0, g.sorted_land, s);
-    if (ev) hipEventRecord(ev[1], s);
-    launch_range<2>(k, g.sorted_land, g.sorted_glacier, s2);
-    launch_range<3>(k, g.sorted_land + g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s2);
-    if (fork || ev) hipEventRecord(e_join, s2);
-    if (fork) hipStreamWaitEvent(s, e_join, 0);
+    g.last_launch_kind = 1;
+    launch_ranges(k, g.sorted_land, g.sorted_glacier, ncol - g.sorted_land - g.sorted_glacier, s, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr);
     return;
   }
   if (ev) hipEventRecord(ev[0], s);
   struct EndEvent { hipEvent_t* e; hipStream_t s; ~EndEvent() { if (e) hipEventRecord(e[1], s); } } at_end{ev, s};
-  if (g.block == 256 && g.use_lds && fixed_level(k)) { launch_range<0>(k, 0, ncol, s); return; }
+  if (g.block == 256 && g.use_lds) {                                  // the option-specialised mixed-class kernel (tile order)
+    const int fx = fixed_level(k);
+    if (fx) { k.t_first = 0; k.t_count = ncol; if (launch_fixed(k, fx, 0, s)) return; }
+  }
   if (g.block == 256) launch<256>(k, ncol, g.use_lds, s);
   else if (g.block == 128) launch<128>(k, ncol, g.use_lds, s);
   else launch<64>(k, ncol, g.use_lds, s);
@@ -959,14 +948,7 @@ int noahmp_hip_step(const noahmp_step_args* a, int mem, void* stream, noahmp_sta
 // ---- asynchronous stepping for device-resident state: enqueue and return.  Fatal columns and tallies
 // accumulate on the device until noahmp_hip_sync(); the error word carries the step ordinal above the column index,
 // so the earliest step wins, then the first column in loop order -- the column the reference would have STOPped at.
-int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) { return noahmp_hip_step_async_mirror(a, stream, nullptr, nullptr); }
-
-// The same step for a SORTED OPT_RUN = 5 run whose LATERALFLOW planes live in a tile-order block beside the sorted store: every column the
-// step advances also stores its ZWTXY at cell block_pos[column] of zwt_block (block_pos: shaped like the store's 2-D arrays,
-// noahmp_hip_sorted_block_positions), so that the stencil of the next WTABLE_mmf_noahmp finds the water table in (i,j) order without a
-// permutation launch in between (cells the step does not advance -- open water, sea ice -- keep what the block holds).  Both NULL: plain step.
-int noahmp_hip_step_async_mirror(const noahmp_step_args* a, void* stream, const int32_t* block_pos, float* zwt_block) {
-  if ((block_pos == nullptr) != (zwt_block == nullptr)) { g.last_error = "noahmp_hip_step_async_mirror: block_pos and zwt_block go together"; return -105; }
+int noahmp_hip_step_async(const noahmp_step_args* a, void* stream) {
   int rc = ensure_init();
   if (rc) return rc;
   rc = check_step_args(a, nullptr);
@@ -991,7 +973,6 @@ int noahmp_hip_step_async_mirror(const noahmp_step_args* a, void* stream, const 
     }
   }
   k.err_base = (unsigned long long)g.async_pending << 40;      // step ordinal since the last sync (columns < 2^32)
-  k.lat_pos = block_pos; k.lat_zwt = zwt_block;
   // three events per step (launch_any): kernel_ms of noahmp_hip_sync is the sum of the column kernels' own durations, whatever
   // else the caller puts on the stream between them
   while ((int)g.async_events.size() < 3 * (g.async_pending + 1)) {
@@ -1032,18 +1013,15 @@ int noahmp_hip_sync(noahmp_status* st, int* step_out) {
     for (int c = 0; c < 3; c++) g.sync_class_ms[c] = 0.f;
     g.sync_step_ms.assign(nsteps, 0.f);
     for (int i = 0; i < nsteps; i++) {
-      // kind 0: one kernel (events 0, 1).  1: class kernels one after the other (0 | land | 1 | land ice + skipped | 2).
-      // 2: land ice + skipped on the second stream beside the land kernel (both measured from the start of the step).
+      // kind 0: the tile-order kernel between two recorded events; 1: the class ranges in one launch, events 0 / 1 = the dispatch's own
+      // start / stop.  Either way ONE kernel per step since round 6: out[1] (land ice + skipped beside the land kernel) stays 0.
       hipEvent_t* e = &g.async_events[3 * i];
       const int kind = i < (int)g.async_kind.size() ? g.async_kind[i] : 0;
-      float land = 0.f, rest = 0.f;
+      float land = 0.f;
       if (kind < 0) continue;                            // an empty tile: no kernel, no events
       hipEventElapsedTime(&land, e[0], e[1]);
-      if (kind) hipEventElapsedTime(&rest, e[kind == 2 ? 0 : 1], e[2]);
-      if (rest < 0.f) rest = 0.f;
-      ms += kind == 2 ? (land > rest ? land : rest) : land + rest;
+      ms += land;
       g.sync_class_ms[0] += land;
-      g.sync_class_ms[1] += rest;
       g.sync_step_ms[i] = land;
     }
     g.sync_steps = nsteps;
@@ -1222,7 +1200,6 @@ void noahmp_hip_finalize(void) {
   if (g.h_counts) hipHostFree(g.h_counts);
   if (g.ev0) hipEventDestroy(g.ev0);
   if (g.ev1) hipEventDestroy(g.ev1);
-  if (g.aux_stream) { hipStreamDestroy(g.aux_stream); hipEventDestroy(g.ev_fork); hipEventDestroy(g.ev_join); }
   if (g.own_stream) hipStreamDestroy(g.own_stream);
   g = nmp_host::Engine();
 }

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(BX * BY) gw_head_kernel(const GwArgs k) {
 // never writes WTD, so the old head need not be frozen in HBM planes first (the whole-call form below must: gw_head_kernel): a workgroup
 // evaluates KCELL / HEAD (gw:237-252) of its BX x QY cells plus their 1-cell ring into LDS -- (BX+2)(QY+2) / (BX QY) = 1.29 evaluations
 // per cell instead of one, but no 8 B / cell written and 72 B / cell read back through the caches, and one launch less per call (round 6:
-// at the 1152 x 768 tile of an 8-rank run the two launches took 12.4 + 9.6 us, the fused one NN us).  Same gw_cell_head_values, same
+// at the 1152 x 768 tile of an 8-rank run the two launches took 12.4 + 9.6 us, the fused one 14.8-15.1 us; at 4608 x 1536 ~95 -> 91 us).  Same gw_cell_head_values, same
 // sum order (gw_qlat_sum): same bits.
 constexpr int QY = 2 * BY;
 __global__ void __launch_bounds__(BX * BY) gw_qlat_fused_kernel(const GwArgs k) {
@@ -141,7 +141,7 @@ size_t noahmp_hip_sizeof_wtable_args(void) { return sizeof(noahmp_wtable_args); 
 // part: 0 = the whole WTABLE_mmf_noahmp; 1 = KCELL / HEAD + the QLAT stencil into `qlat` (tile order); 2 = the per-column half with
 // QLAT read from `qlat` (the block may hold the columns in any order)
 static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only = false,
-                   int part = 0, float* qlat = nullptr, const int32_t* lat_pos = nullptr, float* zwt_block = nullptr);
+                   int part = 0, float* qlat = nullptr);
 
 int noahmp_hip_wtable_mmf(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, false, 0);
@@ -167,17 +167,6 @@ int noahmp_hip_wtable_columns_async(const noahmp_wtable_args* a, const float* ql
   if (!qlat) { g.last_error = "noahmp_hip_wtable_columns_async: qlat is required"; return -105; }
   return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true, 2, const_cast<float*>(qlat));
 }
-// The per-column half on a SORTED store that sits beside the tile-order block of the lateral half: `qlat_block` is the plane
-// noahmp_hip_wtable_lateral_async wrote (tile order, shaped like that block), block_pos[x] = cell of the store's column x inside the block
-// (noahmp_hip_sorted_block_positions) -- QLAT's way into the sorted order is one indexed load per column instead of a permutation launch --
-// and zwt_block (may be NULL) = the block's ZWTXY plane, which receives every land column's new water table beside the store's own
-// (with noahmp_hip_step_async_mirror: the block's ZWTXY is always current, no sorted -> (i,j) move before the next stencil).
-int noahmp_hip_wtable_columns_gather_async(const noahmp_wtable_args* a, const float* qlat_block, const int32_t* block_pos, float* zwt_block,
-                                           void* stream) {
-  if (!qlat_block || !block_pos) { g.last_error = "noahmp_hip_wtable_columns_gather_async: qlat_block and block_pos are required"; return -105; }
-  return gw_call(a, NOAHMP_MEM_DEVICE, stream, nullptr, false, 0, true, 2, const_cast<float*>(qlat_block), block_pos, zwt_block);
-}
-
 int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int mem, void* stream, noahmp_status* st) {
   return gw_call(a, mem, stream, st, true, iswater);
 }
@@ -185,7 +174,7 @@ int noahmp_hip_groundwater_init(const noahmp_wtable_args* a, int iswater, int me
 }  // extern "C"
 
 static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_status* st, bool init, int iswater, bool enqueue_only,
-                   int part, float* qlat, const int32_t* lat_pos, float* zwt_block) {
+                   int part, float* qlat) {
   if (st) memset(st, 0, sizeof(*st));
   int rc = nmp_host::ensure_init();
   if (rc) return rc;
@@ -215,8 +204,6 @@ static int gw_call(const noahmp_wtable_args* a, int mem, void* stream, noahmp_st
     k.hi0 = k.qi0 = a->its; k.hi1 = k.qi1 = a->ite; k.hj0 = k.qj0 = a->jts; k.hj1 = k.qj1 = a->jte;
   }
   k.qlat = qlat;
-  k.lat_pos = lat_pos;
-  k.zwt_block = zwt_block;
   if (k.hi0 < a->ims || k.hi1 > a->ime || k.hj0 < a->jms || k.hj1 > a->jme ||
       a->its < a->ims || a->ite > a->ime || a->jts < a->jms || a->jte > a->jme) {
     g.last_error = "noahmp_hip_wtable_mmf: memory dims (ims:ime,jms:jme) do not hold the tile plus its 1-cell ring";

@@ -73,13 +73,19 @@ const char* kBuildMacros =
 const char* kWrapper =
     "#include \"nmp_kernel.hpp\"\n"
     "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m0(const nmp::KArgs k) {\n"
-    "  column_kernel_body<NMP_FIXED_BLOCK, true, 0>(k); }\n"
-    "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m1(const nmp::KArgs k) {\n"
-    "  column_kernel_body<NMP_FIXED_BLOCK, true, 1>(k); }\n"
-    "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m2(const nmp::KArgs k) {\n"
-    "  column_kernel_body<NMP_FIXED_BLOCK, true, 2>(k); }\n";
+    "  __shared__ float lds[nmp::LAY_SLOTS * NMP_FIXED_BLOCK];\n"
+    "  column_kernel_body<NMP_FIXED_BLOCK, true, 0>(k, lds, (long)blockIdx.x, k.t_first, k.t_count); }\n"
+    "extern \"C\" __global__ void __launch_bounds__(NMP_FIXED_BLOCK, NMP_WAVES_PER_EU) nmp_jit_m4(const nmp::KArgs k) {\n"      // = noahmp_ranges_kernel
+    "  __shared__ float lds[nmp::LAY_SLOTS * NMP_FIXED_BLOCK];\n"
+    "  const long nb_ice = (k.r_ice + NMP_FIXED_BLOCK - 1) / NMP_FIXED_BLOCK, nb_land = (k.r_land + NMP_FIXED_BLOCK - 1) / NMP_FIXED_BLOCK;\n"
+    "  const long b = (long)blockIdx.x;\n"
+    "  if (b < nb_ice) column_kernel_body<NMP_FIXED_BLOCK, true, 2>(k, lds, b, k.r_land, k.r_ice);\n"
+    "  else if (b < nb_ice + nb_land) column_kernel_body<NMP_FIXED_BLOCK, true, 1>(k, lds, b - nb_ice, 0L, k.r_land);\n"
+    "  else column_kernel_body<NMP_FIXED_BLOCK, true, 3>(k, lds, b - nb_ice - nb_land, k.r_land + k.r_ice, k.r_skip); }\n";
 // (the scheduler strategy: as noahmp_amd/build.py -- fewer hazard s_nop in the issue-bound column kernel, round 5)
-const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"};
+// (-instcombine-max-copied-from-constant-users: without it the one-launch class-range kernel copies its 1.6 KB argument block to scratch, build.py)
+const char* kCompileFlags[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                               "-mllvm", "-instcombine-max-copied-from-constant-users=100000"};
 constexpr int kNumCompileFlags = sizeof(kCompileFlags) / sizeof(kCompileFlags[0]);
 
 uint64_t fnv1a(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
@@ -182,8 +188,7 @@ void store_code(const std::string& path, const std::vector<char>& code) {
 bool load_module(const std::vector<char>& code, JitKernels& out, std::string& log) {
   if (hipModuleLoadData(&out.mod, code.data()) != hipSuccess) { log = "hipModuleLoadData"; (void)hipGetLastError(); return false; }
   if (hipModuleGetFunction(&out.fn[0], out.mod, "nmp_jit_m0") != hipSuccess ||
-      hipModuleGetFunction(&out.fn[1], out.mod, "nmp_jit_m1") != hipSuccess ||
-      hipModuleGetFunction(&out.fn[2], out.mod, "nmp_jit_m2") != hipSuccess) { log = "hipModuleGetFunction"; (void)hipGetLastError(); return false; }
+      hipModuleGetFunction(&out.fn[1], out.mod, "nmp_jit_m4") != hipSuccess) { log = "hipModuleGetFunction"; (void)hipGetLastError(); return false; }
   return true;
 }
 
@@ -234,9 +239,9 @@ bool compile(const int* o, JitKernels& out, std::string& log) {
 }  // namespace
 
 // Launch the kernel specialised for the option values o[12] (DVEG, CRS, BTR, RUN, SFC, FRZ, INF, RAD, ALB, SNF, TBOT, STC), compiling
-// it first if this process has not seen the set yet.  mode 0 / 1 as in launch_fixed_*.  Returns false if the caller has to use the
-// generic kernel.
-bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
+// it first if this process has not seen the set yet.  mode 0 / 4 and the start / stop events as in launch_fixed_*.  Returns false if the
+// caller has to use the generic kernel.
+bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   std::string key;
   for (int i = 0; i < 12; i++) key += std::to_string(o[i]) + ",";
   auto it = cache.find(key);
@@ -255,11 +260,12 @@ bool launch_jit(const int* o, const LaunchDesc& d, int mode, hipStream_t s) {
   alignas(16) char buf[4096];
   size_t size = pack_fixed_kargs(d, buf, sizeof(buf));
   if (!size) return false;
-  const long n = mode == 0 ? (long)d.nti * d.ntj : d.t_count;
-  if (n <= 0) return true;
+  constexpr long B = NMP_FIXED_BLOCK;
+  const long nb = mode == 4 ? (d.r_ice + B - 1) / B + (d.r_land + B - 1) / B + (d.r_skip + B - 1) / B : ((long)d.nti * d.ntj + B - 1) / B;
+  if (nb <= 0) return true;
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const hipError_t e = hipModuleLaunchKernel(it->second.fn[(mode == 1 || mode == 2) ? mode : 0], (unsigned)((n + NMP_FIXED_BLOCK - 1) / NMP_FIXED_BLOCK), 1, 1, NMP_FIXED_BLOCK, 1, 1, 0, s,
-                                             nullptr, extra);
+  // (hipExtModuleLaunchKernel takes the grid in work-items)
+  const hipError_t e = hipExtModuleLaunchKernel(it->second.fn[mode == 4 ? 1 : 0], (uint32_t)(nb * B), 1, 1, NMP_FIXED_BLOCK, 1, 1, 0, s, nullptr, extra, ev0, ev1, 0);
   if (e != hipSuccess) { (void)hipGetLastError(); it->second.failed = true; g.last_error = "launch of a run-time compiled kernel failed: generic kernel used"; return false; }
   return true;
 }

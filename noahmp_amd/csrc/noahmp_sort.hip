@@ -106,15 +106,6 @@ __global__ void __launch_bounds__(256) invert_perm_kernel(const int* perm, int* 
   if (p < n) inv[perm[p]] = (int)p;
 }
 
-// pos[p] = cell, inside a tile-order memory block (rows ni_mem long, tile origin at (i_off, j_off)), of the column at sorted position p
-__global__ void __launch_bounds__(256) block_pos_kernel(const int* perm, long n, int nti, int ni_mem, int i_off, int j_off, int* pos) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int t = perm ? perm[p] : (int)p;
-  const int tj = t / nti, ti = t - tj * nti;
-  pos[p] = (tj + j_off) * ni_mem + ti + i_off;
-}
-
 // Scatter plan (noahmp_hip_scatter_fields): per chunk of 1024 consecutive tile columns, the columns ordered by their
 // destination in the sorted layout.  One workgroup sorts one chunk in LDS.
 constexpr int kChunk = 1024;
@@ -332,25 +323,6 @@ int noahmp_hip_sort_staleness_result(int64_t* changed, int wait) {
   }
   *changed = *(volatile long*)sc.h_async;
   sc.async_pending = false;
-  return 0;
-}
-
-// For a sorted store of a tile (nti x ntj columns; perm[p] = linear tile index of the column at sorted position p, NULL = tile order)
-// that sits beside a tile-order memory block (rows ni_mem long, the tile's origin at (i_off, j_off): a block that carries the
-// LATERALFLOW ring): pos_out[p] = linear cell index of that column inside the block.  What noahmp_hip_step_async_mirror and
-// noahmp_hip_wtable_columns_gather_async index the block's planes with.  Asynchronous on `stream`.
-int noahmp_hip_sorted_block_positions(const int32_t* perm, int nti, int ntj, int ni_mem, int i_off, int j_off, int32_t* pos_out, void* stream) {
-  int rc = nmp_host::ensure_init();
-  if (rc) return rc;
-  if (!pos_out || nti < 0 || ntj < 0 || i_off < 0 || j_off < 0 || ni_mem < nti + i_off) {
-    g.last_error = "noahmp_hip_sorted_block_positions: the tile does not fit the memory block";
-    return -105;
-  }
-  const long n = (long)nti * ntj;
-  if (((long)ntj + j_off) * (long)ni_mem > 0x7FFFFFFFL) { g.last_error = "noahmp_hip_sorted_block_positions: more than 2^31 cells"; return -105; }
-  hipStream_t s = stream ? (hipStream_t)stream : g.own_stream;
-  if (n > 0) hipLaunchKernelGGL(block_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perm, n, nti, ni_mem, i_off, j_off, pos_out);
-  HIPCHK(hipGetLastError());
   return 0;
 }
 

@@ -121,29 +121,6 @@ class Engine:
         if rc:
             raise RuntimeError("noahmp_hip_wtable_columns_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
 
-    def wtable_columns_gather_async(self, wargs, qlat_block, block_pos, zwt_block=None, stream=None):
-        """The second half on a sorted store beside the tile-order block of the first: QLAT is read from `qlat_block` (the plane
-        wtable_lateral_async wrote) at block_pos[column], and `zwt_block` (the block's ZWTXY plane) receives the new water table too."""
-        rc = self.lib.noahmp_hip_wtable_columns_gather_async(C.byref(wargs), qlat_block.data_ptr(), block_pos.data_ptr(),
-                                                             zwt_block.data_ptr() if zwt_block is not None else None, stream)
-        if rc:
-            raise RuntimeError("noahmp_hip_wtable_columns_gather_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
-
-    def sorted_block_positions(self, perm, nti, ntj, ni_mem, i_off, j_off):
-        """int32 device tensor (ntj, nti): cell, inside a tile-order block (rows ni_mem long, tile origin at (i_off, j_off)), of the
-        column at every sorted position (perm: what sort_store returned; None = tile order)."""
-        import torch
-        dev = perm.device if perm is not None else torch.device("cuda", torch.cuda.current_device())
-        pos = torch.empty((ntj, nti), dtype=torch.int32, device=dev)
-        torch.cuda.current_stream().synchronize()
-        rc = self.lib.noahmp_hip_sorted_block_positions(perm.data_ptr() if perm is not None else None, nti, ntj, ni_mem, i_off, j_off,
-                                                        pos.data_ptr(), None)
-        if rc == 0:
-            rc = self.lib.noahmp_hip_stream_sync(None)
-        if rc:
-            raise RuntimeError("noahmp_hip_sorted_block_positions: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
-        return pos
-
     def forcing_prep(self, store, lon, rain_rate, iday, ihour, iminute=0, isecond=0, scale_vegfra=False, stream=None,
                      first_step=False, wait=True):
         """Device-resident forcing preparation (reference hdrv:336-354 + CALC_DECLIN): `lon` and `rain_rate` are
@@ -419,14 +396,10 @@ class Engine:
         return st
 
     # ---- asynchronous stepping (device-resident state only)
-    def noahmplsm_async(self, args, stream=None, mirror=None):
-        """Enqueue one step described by a prepared StepArgs block (store.step_args(...), device pointers).  mirror = (block_pos,
-        zwt_block): noahmp_hip_step_async_mirror -- the advanced columns also store ZWTXY into the tile-order block of the stencil."""
+    def noahmplsm_async(self, args, stream=None):
+        """Enqueue one step described by a prepared StepArgs block (store.step_args(...), device pointers)."""
         self._apply_ranges(getattr(args, "_ranges", None))
-        if mirror is not None:
-            rc = self.lib.noahmp_hip_step_async_mirror(C.byref(args), stream, mirror[0].data_ptr(), mirror[1].data_ptr())
-        else:
-            rc = self.lib.noahmp_hip_step_async(C.byref(args), stream)
+        rc = self.lib.noahmp_hip_step_async(C.byref(args), stream)
         if rc:
             raise RuntimeError("noahmp_hip_step_async: rc=%d %s" % (rc, self.lib.noahmp_hip_last_error().decode()))
 

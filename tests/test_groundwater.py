@@ -174,71 +174,3 @@ def test_gpu_two_halves_equal_the_whole_call_in_any_column_order(tables, port, e
     assert_same(want, got, what="two halves")
     assert (want.a["qslat"] != 0).any()
 
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", CASES[:2], ids=lambda c: "stress%g_area%g" % (c["stress"], c["area"]))
-def test_gpu_gather_half_and_block_mirror(tables, port, engine, case):
-    """Round 6 data flow of a sorted OPT_RUN = 5 run: the stencil half on a tile-order BLOCK that carries a ring (its ZWTXY kept current by
-    the column kernels, noahmp_hip_step_async_mirror, and by the per-column half), the per-column half on a permuted store reading QLAT
-    from the block through the index plane of noahmp_hip_sorted_block_positions -- two noahmplsm + WTABLE_mmf_noahmp rounds equal the
-    oracle's on the whole grid, bit for bit, and the block's ZWTXY equals the store's at every tile cell."""
-    import torch
-    from noahmp_amd.abi import FIELD_INFO
-    gi, gj = 70, 44
-    s0 = gw_store(tables, ni=gi, nj=gj, seed=19, **case)
-    synth.first_step_fixups(s0)
-    its, ite, jts, jte = 2, gi - 1, 2, gj - 1                  # the tile: the grid without its outermost ring (the block carries it)
-    nti, ntj = ite - its + 1, jte - jts + 1
-    want = s0.copy()
-    want.set_index(its=its, ite=ite, jts=jts, jte=jte)
-    # the tile as a store of its own, columns randomly permuted
-    r = np.random.Generator(np.random.Philox(78))
-    perm = r.permutation(nti * ntj).astype(np.int32)
-
-    def cut(v):
-        return v[jts - 1:jte, ..., its - 1:ite]
-
-    def shuffle(v, p):
-        return (v.transpose(1, 0, 2).reshape(v.shape[1], -1)[:, p].reshape(v.shape[1], v.shape[0], v.shape[2]).transpose(1, 0, 2)
-                if v.ndim == 3 else v.reshape(-1)[p].reshape(v.shape))
-    inner = ColumnStore(nti, ntj, s0.cfg).add_groundwater()
-    for k in inner.a:
-        if k != "dzs":
-            inner.a[k][...] = shuffle(np.ascontiguousarray(cut(s0.a[k])), perm)
-    inner.set_index(ids=1, ide=gi, jds=1, jde=gj, ims=its, ime=ite, jms=jts, jme=jte, its=its, ite=ite, jts=jts, jte=jte)
-    d = inner.to_device("cuda:0")
-    # the tile-order block (tile + ring) of the stencil half: a whole-grid store of which only the lateral planes matter
-    blk = s0.copy()
-    blk.set_index(its=its, ite=ite, jts=jts, jte=jte)
-    b = blk.to_device("cuda:0")
-    qlat = torch.zeros((gj, gi), dtype=torch.float32, device="cuda:0")
-    pos = engine.sorted_block_positions(torch.from_numpy(perm).cuda(), nti, ntj, gi, its - 1, jts - 1)
-    np.testing.assert_array_equal(pos.cpu().numpy().reshape(-1), (perm // nti + jts - 1) * gi + perm % nti + its - 1)
-    for it in (1, 2):
-        hour = 10 + it
-        for st in (want, inner):
-            synth.diurnal_forcing(st, hour, t_offset=None)
-        assert port.noahmplsm(want, it, 2000, 180.0).code == 0
-        port.wtable_mmf(want)
-        for k in ("coszin", "swdown", "glw", "t3d", "rainbl"):
-            d.a[k].copy_(torch.from_numpy(inner.a[k]))
-        torch.cuda.synchronize()
-        engine.noahmplsm_async(d.step_args(it, 2000, 180.0), mirror=(pos, b.a["zwtxy"]))
-        engine.wtable_lateral_async(b.wtable_args(), qlat)
-        engine.wtable_columns_gather_async(d.wtable_args(), qlat, pos, b.a["zwtxy"])
-        st, _ = engine.sync()
-        assert st.code == 0
-    engine.stream_sync()
-    got = d.to_host()
-    inv = np.empty(perm.size, np.int64)
-    inv[perm] = np.arange(perm.size)
-    names = [k for k in got.a if k != "dzs" and (k in GW_OUT or (k in FIELD_INFO and FIELD_INFO[k][2] != "in"))]
-    assert "tslb" in names and "qslat" in names
-    for k in names:
-        x, y = cut(want.a[k]), shuffle(got.a[k], inv)
-        assert np.array_equal(x, y, equal_nan=True), k
-    assert np.array_equal(cut(b.a["zwtxy"].cpu().numpy()), cut(want.a["zwtxy"]))      # the mirror is current
-    ring = np.ones((gj, gi), bool)
-    ring[jts - 1:jte, its - 1:ite] = False
-    assert np.array_equal(b.a["zwtxy"].cpu().numpy()[ring], s0.a["zwtxy"][ring])       # and nobody wrote the ring
-    assert (cut(want.a["qslat"]) != 0).any()

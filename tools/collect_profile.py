@@ -10,11 +10,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-KERN = "noahmp_column_kernel"
+KERN = "noahmp_ranges_kernel"        # the step's column kernel: the class ranges of the sorted layout in one launch (round 6; before: noahmp_column_kernel<64, true, 1>)
 
 stats = (glob.glob(os.path.join(src, "trace", "*_kernel_stats.csv")) +
          glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))[0]
@@ -133,7 +133,7 @@ for d in ("fetch5", "write5", "sq5"):
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if KERN in r["Kernel_Name"] and "true, 1>" in r["Kernel_Name"]:
+        if KERN in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             k5name = r["Kernel_Name"]
     for k, v in acc.items():

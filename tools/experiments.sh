@@ -28,7 +28,6 @@
 #   fuzzopts [NSETS [SEED]]        the same over NSETS random option sets (every OPT_* drawn from its supported range; hiprtc kernels)
 #   fuzzopts5 [NSETS [SEED]]       the sorted config-5 chain (class-range kernels) under random option sets, sample vs the oracle
 #   spread5                        config 5 under the i.i.d. and the spatially smooth forcing-factor generator: trip-count spread per wavefront (cost-record build)
-#   gw6 [bench args]               config 4: round 6's index-plane data flow around WTABLE_mmf_noahmp vs the plane moves of rounds 3-5 (N = 8 tile, N = 1)
 #   vegcost [usgs|modis] [ni nj] [dveg]   land-kernel time per vegetation category (input of noahmp_hip_sort_set_veg_order)
 #   stage [THREADS...]             pageable arrays through the engine's bounce buffers by copy threads + a 10-process fault hunt without GPU_PINNED_MIN_XFER_SIZE
 #   profile TAG                    the evidence for profiles/: plain bench, kernel traces (config 3 / 4 / 5, groundwater), FETCH / WRITE /
@@ -37,7 +36,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R" || exit 1
 CMD=$1; shift
 O=$R/gpurun_out/exp_$CMD; mkdir -p "$O"
-LAND='noahmp_column_kernel<64, true, 1>'
+LAND='noahmp_ranges_kernel<64>'       # the step's column kernel (land + land-ice + skipped ranges in one launch since round 6)
 
 summarise() {      # summarise FILE TAG: one line of a bench JSON
   python3 - "$1" "$2" <<'PY'
@@ -277,18 +276,6 @@ for l in sys.stdin:
     d = json.loads(l[len('COSTSPREAD '):]); c = d['orders'][0]
     print('   hour %2d: canopy iterations mean %.2f / wave-max mean %.2f  canopy-loop lane use %.3f  bisection lane use %.3f  waves without canopy %.3f' % (
         d['hour'], c['canopy_iterations_mean'], c['canopy_iterations_wave_max_mean'], c['canopy_loop_lane_use'], c['bisection_lane_use'], c['waves_without_canopy']))"
-  done
-  ;;
-gw6)              # round 6: config 4 with the index-plane data flow around WTABLE_mmf_noahmp vs rounds 3-5's plane moves, at the N = 8 tile and at N = 1
-  for rep in 1 2; do
-    for v in "" "--plane-moves"; do
-      timeout 300 python bench.py --ni 1152 --nj 768 --workload config4 --steps 96 --warmup 12 $QUIET $v "$@" > $O/t8$v.$rep.json 2> $O/t8$v.$rep.err
-      summarise $O/t8$v.$rep.json "tile of N=8 $v"
-    done
-  done
-  for v in "" "--plane-moves"; do
-    timeout 600 python bench.py --workload config4 --steps 48 --warmup 6 $QUIET $v "$@" > $O/n1$v.json 2> $O/n1$v.err
-    summarise $O/n1$v.json "config 4, N=1 $v"
   done
   ;;
 vegcost)          # land-kernel cost per vegetation category (tools/veg_cost.py [usgs|modis] [ni nj] [dveg]) -> gpurun_out/exp_vegcost/

@@ -1,6 +1,6 @@
 """Static instruction mix of one kernel in a `hipcc -S --cuda-device-only` listing.
 
-usage: isa_stats.py listing.s [kernel-name-substring]      (default: the land-only column kernel, MODE 1)
+usage: isa_stats.py listing.s [kernel-name-substring]      (default: the class-range kernel noahmp_ranges_kernel)
 Prints resource usage (.vgpr_count, spills, LDS, scratch) and counts by class: VALU total, float64, packed float32, moves,
 selects, IEEE-division parts, lane moves of spilled SGPRs, transcendentals, conversions; s_nop, s_waitcnt, LDS and memory
 instructions; calls (s_swappc: none may exist in a column kernel, profiles/r03_experiments.md section 3d)."""
@@ -13,7 +13,7 @@ def kernel_body(lines, key):
     name, start = None, None
     for i, ln in enumerate(lines):
         m = re.match(r"^(_Z\w+):", ln)
-        if m and key in m.group(1) and "noahmp_column_kernel" in m.group(1):
+        if m and key in m.group(1) and ("noahmp_column_kernel" in m.group(1) or "noahmp_ranges_kernel" in m.group(1)):
             name, start = m.group(1), i
             break
     if start is None:
@@ -28,7 +28,7 @@ def kernel_body(lines, key):
 
 def main():
     path = sys.argv[1]
-    key = sys.argv[2] if len(sys.argv) > 2 else "ELb1ELi1EE"
+    key = sys.argv[2] if len(sys.argv) > 2 else "noahmp_ranges_kernel"        # the one-launch class-range kernel (land + land-ice + skipped bodies)
     lines = open(path).read().splitlines()
     name, body = kernel_body(lines, key)
     ops = collections.Counter()
