@@ -351,6 +351,7 @@ class Run:
 
     def _bind_sorted(self):
         d, eng = self.d, self.eng
+        self.forcing_ready_for = None                         # a forcing set permuted ahead dies with the old column order
         if self.gw is not None:
             self.wargs_col = d.wtable_args()                  # the per-column half works on the sorted store itself
         self.work = {k: d.a[k] for k in FKEYS}
@@ -411,9 +412,11 @@ class Run:
             self.ev_scat[1 - b].record(self.ts2)
             self.prefetched = it + 1
         elif self.sorted and self.gw is not None:
-            self._permute_forcing(h, 0, self.sp)
+            if getattr(self, "forcing_ready_for", None) != it:       # (else: it travelled with the previous step's QLAT plane, groundwater())
+                self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
             self.eng.noahmplsm_async(self.sarg, self.sp)
+            self.next_it = it + 1
         elif self.sorted:
             self._permute_forcing(h, 0, self.sp)
             self.sarg.itimestep = it
@@ -442,7 +445,16 @@ class Run:
             self.halo_events.append((e0, e1))
         if self.gw is not None:
             self.eng.wtable_lateral_async(self.wargs, self.gw.a["qlat"], self.sp)     # KCELL / HEAD + QLAT stencil, (i,j) order, one launch
-            self.scat.exchange([self.d.a["qlat"]], [self.gw.a["qlat"]], False, self.gw.ni, self.i_off, self.j_off, self.sp)   # QLAT -> sorted order
+            # QLAT -> sorted order -- and with it, in the same launch, the NEXT step's forcing (same direction, same plan; the column kernel
+            # that read the forcing working set has finished): one launch boundary less per step (round 6)
+            planes_s, planes_t, lvl1 = [self.d.a["qlat"]], [self.gw.a["qlat"]], ()
+            if self.work2 is None and getattr(self, "next_it", None) is not None:
+                hn = forcing_hour(self.next_it, self.cfg.dt)
+                planes_s += [self.work[k] for k in FKEYS]
+                planes_t += [self.forcing[hn][k] for k in FKEYS]
+                lvl1 = tuple(i + 1 for i in self.lvl1)
+                self.forcing_ready_for = self.next_it
+            self.scat.exchange(planes_s, planes_t, False, self.gw.ni, self.i_off, self.j_off, self.sp, first_level_only=lvl1)
             self.eng.wtable_columns_async(self.wargs_col, self.d.a["qlat"], self.sp)  # everything else, on the sorted store
         else:
             self.eng.wtable_mmf_async(self.wargs, self.sp)
@@ -563,7 +575,7 @@ class Run5:
         geom = tile_geometry(gx, gy, comm.world, comm.rank, halo=0)
         self.geom = geom
         nx, ny = geom["ite"] - geom["its"] + 1, geom["jte"] - geom["jts"] + 1
-        raw, lon, static = synth5.config5_tile(gx, gy, geom["its"] - 1, geom["jts"] - 1, nx, ny, cfg=cfg, smooth=bool(getattr(args, "config5_smooth", False)))
+        raw, lon, static = synth5.config5_tile(gx, gy, geom["its"] - 1, geom["jts"] - 1, nx, ny, cfg=cfg, smooth=int(getattr(args, "config5_smooth", 0) or 0))
         self.ni, self.nj, self.tile_cells = nx, ny, nx * ny
         self.raw_host = (raw, lon, static) if args.dump else None
         self.d = d = raw.to_device(dev)
@@ -1047,10 +1059,11 @@ def main():
                          "checked at the --resort-every cadence (0 = only at the end of the warm-up and when stale)")
     ap.add_argument("--lon-band", type=float, default=15.0,
                     help="config 5: width [degrees] of the longitude bands of the sort key (0 = no band key); 15 = one hour of local solar time")
-    ap.add_argument("--config5-smooth", action="store_true",
-                    help="config 5: the per-column forcing factors (cloud, humidity, pressure, wind, rain timing) are spatially smooth random "
+    ap.add_argument("--config5-smooth", type=int, nargs="?", const=1, default=0,
+                    help="config 5: 1 = the per-column forcing factors (cloud, humidity, pressure, wind, rain timing) are spatially smooth random "
                          "fields (synth5.smooth_uniform: correlation length a few hundred km) instead of i.i.d. draws per cell; same marginals, "
-                         "same state.  The i.i.d. generator stays the quoted config-5 number (the conservative one)")
+                         "same state.  2 = the state's per-cell noise (soil category, temperature scatter, vegetation fraction, soil moisture, "
+                         "snow) is smooth too.  The i.i.d. generator stays the quoted config-5 number (the conservative one)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-stage-records", action="store_true",
                     help="config 5: evaluate the synthetic 3-hourly forcing records inside the timed region, when a step first needs them "
@@ -1254,7 +1267,7 @@ def main():
             del r5
             torch.cuda.empty_cache()
             # the same leg with spatially smooth forcing factors: how much of config 5's divergence is white noise in the generator
-            a5.config5_smooth = True
+            a5.config5_smooth = 1
             r5 = Run5(a5, comm, eng, tb, dev)
             dt5 = timed_leg(r5, args.steps, args.warmup, barrier)
             config5_smooth_ref = {"workload": "config5_reference with spatially smooth forcing factors (`--workload config5 --config5-smooth`: cloud, humidity, "
@@ -1349,7 +1362,8 @@ def main():
             if prefetch5:
                 desc += "; the forcing chain (interpolation + preparation) runs three steps ahead on a second stream beside the column kernels (four forcing working sets)"
             if getattr(args, "config5_smooth", False):
-                desc += "; forcing factors (cloud, humidity, pressure, wind, rain timing) spatially smooth (--config5-smooth) instead of i.i.d. per cell"
+                desc += ("; forcing factors (cloud, humidity, pressure, wind, rain timing) spatially smooth (--config5-smooth) instead of i.i.d. per cell"
+                         + ("; soil category, temperature scatter, vegetation fraction, soil moisture and snow smooth too" if int(args.config5_smooth) >= 2 else ""))
             desc += ("; the 3-hourly forcing records of the timed window are resident in HBM when it starts (evaluated before it, as config 3's hourly sets are)"
                      if not args.no_stage_records else "; the synthetic 3-hourly forcing records are evaluated inside the timed region (torch elementwise kernels)")
         elif run.sorted:

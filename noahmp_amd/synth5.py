@@ -76,11 +76,20 @@ def smooth_uniform(ni, gy, r0, nj, seed, nmodes=24):
     return ndtr(f)
 
 
+def smooth_normal(ni, gy, r0, nj, seed, nmodes=24):
+    """The same field before the CDF: N(0, 1) marginals."""
+    from scipy.special import ndtri
+    return ndtri(np.clip(smooth_uniform(ni, gy, r0, nj, seed, nmodes), 1e-9, 1.0 - 1e-9))
+
+
 def _config5_rows(ni, gy, r0, nj, seed, cfg, water_frac=0.03, urban_frac=0.01, polar_glacier=0.30, smooth=False):
     """Rows r0 .. r0+nj-1 (all ni columns) of the global ni x gy grid.  smooth: the forcing factors (sky transmissivity, relative humidity,
     surface pressure / elevation, wind, rain timing) are spatially smooth fields (smooth_uniform) with the marginal distributions of the
     default's i.i.d. draws -- round 6's second generator, to tell what of config 5's lane utilisation is the model and what is white noise
-    in the forcing; everything else (vegetation, soil, snow, temperatures) is the same cells."""
+    in the forcing; everything else (vegetation, soil, snow, temperatures) is the same cells.  smooth = 2: the STATE's per-cell noise is
+    smooth too -- soil category, the 3-K temperature scatter, vegetation fraction, soil moisture, snow water equivalent and density come from
+    smooth fields with the default's marginals (vegetation category, water / urban / land-ice masks stay as they are: the column order
+    groups by them anyway) -- the upper bound of what spatial coherence of the inputs can buy."""
     cfg = cfg or ModelConfig(idveg=1)
     r = _rng(seed)
     s = _base_store(ni, nj, cfg)
@@ -130,6 +139,28 @@ def _config5_rows(ni, gy, r0, nj, seed, cfg, water_frac=0.03, urban_frac=0.01, p
         vwind=r.uniform(-3.0, 3.0, size=shp).astype(F),
         phase=r.integers(0, 16, size=shp).astype(F),               # when this column's rain events come
     )
+    if smooth and int(smooth) >= 2:
+        base = int(seed[0]) if isinstance(seed, (list, tuple)) else int(seed)
+        su = lambda i: smooth_uniform(ni, gy, r0, nj, [base, 950 + i])
+        land = ~(water | glacier)
+        a["isltyp"][land] = np.minimum(np.floor(12.0 * su(0)) + 1, 12).astype(np.int32)[land]
+        a["vegfra"][...] = (20.0 + 70.0 * su(1)).astype(F)
+        a["vegmax"][...] = np.maximum(a["vegfra"], F(90.0))
+        tb2 = (300.0 - 50.0 * sin2 + np.clip(3.0 * smooth_normal(ni, gy, r0, nj, [base, 952]), -8.0, 8.0)).astype(F)
+        tb2[glacier] = np.minimum(tb2[glacier], F(262.0))
+        tbase = tb2
+        a["tmn"][...] = (tbase - F(1.0)).astype(F)
+        a["tsk"][...] = tbase
+        cold = (tbase < F(272.0)) | glacier
+        swe = (5.0 + 295.0 * su(3)).astype(F)
+        rho = (100.0 + 250.0 * su(4)).astype(F)
+        a["snow"][...] = np.where(cold, swe, F(0.0))
+        a["snowh"][...] = np.where(cold, swe / rho, F(0.0))
+        dsm = (-0.05 + 0.10 * su(5)).astype(F)
+        for k, (dt_, sm) in enumerate(zip((0.0, 0.3, 0.6, 0.9), (0.25, 0.27, 0.30, 0.31))):
+            a["tslb"][:, k, :] = a["tsk"] * F(0.5) + a["tmn"] * F(0.5) + F(dt_)
+            a["smois"][:, k, :] = F(sm) + dsm
+        static["tbase"] = tbase
     if smooth:
         base = int(seed[0]) if isinstance(seed, (list, tuple)) else int(seed)
         u = {k: smooth_uniform(ni, gy, r0, nj, [base, 900 + i]) for i, k in enumerate(("cloud", "rh", "psfc", "uwind", "vwind", "phase"))}

@@ -162,7 +162,8 @@ pmc)
   ;;
 pmc5)
   SM=""; TAG=""
-  if [ "$1" == "--smooth" ]; then SM="--config5-smooth"; TAG="smooth_"; shift; fi
+  if [ "$1" == "--smooth" ]; then SM="--config5-smooth=1"; TAG="smooth_"; shift; fi
+  if [ "$1" == "--smooth2" ]; then SM="--config5-smooth=2"; TAG="smooth2_"; shift; fi
   if [ $# -eq 0 ]; then set -- 0 15; fi
   cd /tmp && export TMPDIR=/tmp
   for band in "$@"; do
@@ -267,7 +268,7 @@ except Exception as e: print('FAILED', '$o', e)" | tee -a $O/fuzzopts5.log
   ;;
 spread5)          # round 6: canopy-loop lane use of config 5 under the two forcing generators (i.i.d. factors | spatially smooth factors), same column order
   # build first (dev container): python tools/build_variants.py cost=-DNMP_COST_RECORD
-  for v in "" "--config5-smooth"; do
+  for v in "" "--config5-smooth=1" "--config5-smooth=2"; do
     NMP_COST_SPREAD=1 NMP_LIB=$R/noahmp_amd/csrc/variants/lib_cost.so timeout 900 python bench.py --workload config5 $v --steps 24 --warmup 6 --no-cpu-baseline > $O/spread$v.json 2> $O/spread$v.err
     summarise $O/spread$v.json "config5 $v (cost-record build)"
     grep "^COSTSPREAD" $O/spread$v.err | python3 -c "
