@@ -1317,7 +1317,7 @@ def main():
         # PMC counters cannot be collected inside this run (rocprofv3 --pmc passes are separate runs of this very command,
         # tools/run_profile.sh -> tools/collect_profile.py): the newest committed summary is quoted, and only when workload and
         # columns per launch are those of the profile
-        for tag in ("r05", "r04", "r03", "r02"):
+        for tag in ("r06", "r05", "r04", "r03", "r02"):
             tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % tag)
             if not os.path.exists(tpath):
                 continue
