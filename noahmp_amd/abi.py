@@ -183,6 +183,8 @@ def load_library(path=None):
     lib.noahmp_hip_jit_cache_info.restype = C.c_char_p
     lib.noahmp_hip_jit_source_hash.restype = C.c_uint64
     lib.noahmp_hip_set_option.argtypes = [C.c_char_p, C.c_int]
+    lib.noahmp_hip_debug_copy_stats.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.noahmp_hip_debug_copy_stats.restype = None
     lib.noahmp_hip_error_string.argtypes = [C.c_int]
     lib.noahmp_hip_error_string.restype = C.c_char_p
     lib.noahmp_hip_last_error.restype = C.c_char_p
@@ -202,7 +204,7 @@ def load_library(path=None):
 EXPORTED_SYMBOLS = [
     "noahmp_hip_abi_version", "noahmp_hip_nsoil", "noahmp_hip_sizeof_step_args", "noahmp_hip_sizeof_tables",
     "noahmp_hip_device_count", "noahmp_hip_set_device", "noahmp_hip_set_tables",
-    "noahmp_hip_step", "noahmp_hip_fetch", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_sync_timing", "noahmp_hip_sync_step_timing", "noahmp_hip_sync_counts", "noahmp_hip_fetch_cost", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_forcing_interpolate_prep", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_output_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_scatter_chunk_of", "noahmp_hip_index_width", "noahmp_hip_sorted_exchange", "noahmp_hip_sort_columns", "noahmp_hip_sort_set_band", "noahmp_hip_sort_set_veg_order", "noahmp_hip_sort_staleness", "noahmp_hip_sort_staleness_async", "noahmp_hip_sort_staleness_result", "noahmp_hip_permute_step_arrays", "noahmp_hip_scatter_plan", "noahmp_hip_stream_sync", "noahmp_hip_wtable_mmf", "noahmp_hip_wtable_mmf_async", "noahmp_hip_wtable_lateral_async", "noahmp_hip_wtable_columns_async", "noahmp_hip_groundwater_init", "noahmp_hip_halo_init", "noahmp_hip_exchange_halo", "noahmp_hip_halo_finalize", "noahmp_hip_halo_selftest_rccl", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_malloc", "noahmp_hip_memcpy", "noahmp_hip_free", "noahmp_hip_jit_compile_check", "noahmp_hip_jit_cache_info", "noahmp_hip_jit_source_hash", "noahmp_hip_set_option", "noahmp_hip_debug_live_host_registrations", "noahmp_hip_error_string",
+    "noahmp_hip_step", "noahmp_hip_fetch", "noahmp_hip_step_async", "noahmp_hip_sync", "noahmp_hip_sync_timing", "noahmp_hip_sync_step_timing", "noahmp_hip_sync_counts", "noahmp_hip_fetch_cost", "noahmp_hip_init", "noahmp_hip_forcing_prep", "noahmp_hip_forcing_interpolate", "noahmp_hip_forcing_interpolate_prep", "noahmp_hip_declination", "noahmp_hip_gather_fields", "noahmp_hip_output_fields", "noahmp_hip_scatter_fields", "noahmp_hip_scatter_chunk", "noahmp_hip_scatter_chunk_of", "noahmp_hip_index_width", "noahmp_hip_sorted_exchange", "noahmp_hip_sort_columns", "noahmp_hip_sort_set_band", "noahmp_hip_sort_set_veg_order", "noahmp_hip_sort_staleness", "noahmp_hip_sort_staleness_async", "noahmp_hip_sort_staleness_result", "noahmp_hip_permute_step_arrays", "noahmp_hip_scatter_plan", "noahmp_hip_stream_sync", "noahmp_hip_wtable_mmf", "noahmp_hip_wtable_mmf_async", "noahmp_hip_wtable_lateral_async", "noahmp_hip_wtable_columns_async", "noahmp_hip_groundwater_init", "noahmp_hip_halo_init", "noahmp_hip_exchange_halo", "noahmp_hip_halo_finalize", "noahmp_hip_halo_selftest_rccl", "noahmp_hip_sizeof_wtable_args", "noahmp_hip_malloc", "noahmp_hip_memcpy", "noahmp_hip_free", "noahmp_hip_jit_compile_check", "noahmp_hip_jit_cache_info", "noahmp_hip_jit_source_hash", "noahmp_hip_set_option", "noahmp_hip_debug_live_host_registrations", "noahmp_hip_debug_copy_stats", "noahmp_hip_error_string",
     "noahmp_hip_last_error", "noahmp_hip_finalize",
 ]
 
