@@ -84,3 +84,33 @@ def test_gpu_config5_full_size_sample_bit_identical():
     assert res["glacier_in_sample"] > 10 and res["water_in_sample"] > 10
     assert set(res["isnow_states_in_sample"]) >= {0, -3}
     assert res["land_columns"] > 6_000_000
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_smooth_generators_keep_marginals_cells_and_decomposition(level):
+    """Round 6's second / third config-5 generator (synth5.smooth_uniform: forcing factors -- and with level 2 the state's per-cell noise --
+    as spatially smooth fields): a tile is the same cells whatever the decomposition, the marginal ranges are the default generator's,
+    neighbouring cells are close (the default's are independent), and what is documented as unchanged is unchanged."""
+    gx, gy = 360, 180
+    raw0, lon0, st0 = synth5.config5_tile(gx, gy)
+    raw, lon, st = synth5.config5_tile(gx, gy, smooth=level)
+    part = synth5.config5_tile(gx, gy, 100, 40, 90, 50, smooth=level)
+    for k in st:
+        assert np.array_equal(st[k][40:90, 100:190], part[2][k]), k
+    for k in ("isltyp", "tsk", "snow", "smois", "ivgtyp", "xland"):
+        assert np.array_equal(raw.a[k][40:90, ..., 100:190], part[0].a[k]), k
+    for k, (lo, hi) in dict(cloud=(0.4, 0.9), rh=(0.4, 0.9), uwind=(1.0, 8.0), vwind=(-3.0, 3.0), phase=(0, 15)).items():
+        assert lo <= st[k].min() and st[k].max() <= hi and st[k].std() > 0.1 * (hi - lo), k
+        rough = lambda f: np.abs(np.diff(f, axis=1)).mean()
+        assert rough(st[k]) < 0.6 * rough(st0[k]), k                       # smooth along a row where the default is white noise
+    assert np.array_equal(raw.a["ivgtyp"], raw0.a["ivgtyp"]) and np.array_equal(raw.a["xland"], raw0.a["xland"])
+    if level == 1:
+        for k in raw.a:
+            if k != "dzs":
+                assert np.array_equal(raw.a[k], raw0.a[k]), k                # the state is the default's
+        assert np.array_equal(st["tbase"], st0["tbase"])
+    else:
+        land = (raw.a["xland"] < 1.5) & (raw.a["ivgtyp"] != 24)
+        assert set(np.unique(raw.a["isltyp"][land])) <= set(range(1, 13)) and len(np.unique(raw.a["isltyp"][land])) == 12
+        assert abs(float((raw.a["snow"] > 0).mean()) - float((raw0.a["snow"] > 0).mean())) < 0.02
+        assert np.abs(np.diff(raw.a["tsk"], axis=1)).mean() < 0.5 * np.abs(np.diff(raw0.a["tsk"], axis=1)).mean()
