@@ -4,7 +4,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); CS=$R/noahmp_amd/csrc; W=/tmp/nmp_asan; mkdir -p $W
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-for f in noahmp_engine noahmp_forcing noahmp_groundwater noahmp_init noahmp_halo noahmp_jit noahmp_sort; do
+for f in noahmp_engine noahmp_forcing noahmp_groundwater noahmp_init noahmp_halo noahmp_jit noahmp_sort noahmp_stage; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -g -fPIC -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-option-ignored \
       -fsanitize=address -fno-omit-frame-pointer -I$R/include -c $CS/$f.hip -o $W/$f.o &
 done; wait
